@@ -1,0 +1,150 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors that pin the oracle to the REFERENCE implementation.
+
+Run in the build container only (it imports /root/reference, which does not exist
+on the GPU box):
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+
+Outputs (committed):
+    tests/golden/schema.json            state_dict keys/shapes/kinds of Generator(R), R = 8..512
+    tests/golden/units.npz              lrelu_agc / Downsample2d / Upsample2d / SeparableConv2d cases
+    tests/golden/generator_*.npz        whole-generator outputs + per-layer taps
+
+Weights and inputs come from mi-gan_amd/synth.py (seeded, RNG-library independent),
+so the fixtures hold only outputs, a few sampled intermediate values and checksums.
+"""
+import importlib
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = os.environ.get("MIGAN_REFERENCE", "/root/reference")
+sys.path.insert(0, ROOT)
+sys.path.insert(0, REF)
+sys.dont_write_bytecode = True
+
+pkg = importlib.import_module("mi-gan_amd")
+synth = pkg.synth
+import lib.model_zoo.migan_inference as ref  # noqa: E402  (the reference module itself)
+
+torch.manual_seed(0)
+torch.set_num_threads(max(1, os.cpu_count() or 1))
+
+
+def tap_summary(t: torch.Tensor) -> np.ndarray:
+    """[mean, std, absmax, 13 sampled values at fixed flat positions]."""
+    a = t.detach().double().numpy().ravel()
+    idx = (np.arange(13, dtype=np.int64) * 2654435761 + 12345) % a.size
+    return np.concatenate([[a.mean(), a.std(), np.abs(a).max()], a[idx]]).astype(np.float64)
+
+
+def schema_json():
+    out = {}
+    for r in (8, 16, 32, 64, 128, 256, 512):
+        g = ref.Generator(resolution=r)
+        params = {k for k, _ in g.named_parameters()}
+        out[str(r)] = [[k, list(v.shape), "param" if k in params else "buffer"]
+                       for k, v in g.state_dict().items()]
+    with open(os.path.join(HERE, "schema.json"), "w") as f:
+        json.dump(out, f, indent=0)
+    print("schema.json", {k: len(v) for k, v in out.items()})
+
+
+def units():
+    d = {}
+    act = ref.lrelu_agc(alpha=0.2, gain="sqrt_2", clamp=256)
+    xa = np.concatenate([np.linspace(-400, 400, 41), [0.0, -0.0, 1e-30, -1e-30, 181.0, 181.1, -905.0, -906.0]]).astype(np.float32)
+    d["act_x"] = xa
+    d["act_y"] = act(torch.from_numpy(xa.copy())).numpy()
+
+    x = synth.normal((2, 8, 10, 10), 1, "unit/x").astype(np.float32)
+    with torch.no_grad():
+        d["fir_x"] = x
+        d["down_y"] = ref.Downsample2d(8)(torch.from_numpy(x)).numpy()
+        d["up_y"] = ref.Upsample2d(8, resolution=20)(torch.from_numpy(x)).numpy()
+        # odd sizes and single pixel rows exercise the zero padding
+        x2 = synth.normal((1, 3, 6, 4), 2, "unit/x2").astype(np.float32)
+        d["fir_x2"] = x2
+        d["down_y2"] = ref.Downsample2d(3)(torch.from_numpy(x2)).numpy()
+
+    def sep_case(tag, cin, cout, res_in, **kw):
+        m = ref.SeparableConv2d(cin, cout, 3, activation=act, **kw)
+        sd = m.state_dict()
+        new = {}
+        for k, v in sd.items():
+            if k.endswith("filter.weight") or k.endswith("filter_const"):
+                new[k] = v
+            elif k.endswith("noise_strength"):
+                new[k] = torch.tensor(0.37)
+            else:
+                new[k] = torch.from_numpy(synth.normal(tuple(v.shape), 3, f"unit/{tag}/{k}").astype(np.float32) * 0.5)
+        m.load_state_dict(new)
+        xin = synth.normal((2, cin, res_in, res_in), 4, f"unit/{tag}/x").astype(np.float32) * 2.0
+        with torch.no_grad():
+            y = m(torch.from_numpy(xin.copy())).numpy()
+        d[f"sep_{tag}_x"] = xin
+        d[f"sep_{tag}_y"] = y
+        for k, v in new.items():
+            d[f"sep_{tag}_sd/{k}"] = v.numpy()
+
+    sep_case("plain", 16, 24, 12)
+    sep_case("down", 16, 24, 12, down=2)
+    sep_case("up", 16, 8, 8, up=2, resolution=16, use_noise=True)
+    sep_case("noise", 8, 8, 8, resolution=8, use_noise=True)
+    np.savez_compressed(os.path.join(HERE, "units.npz"), **d)
+    print("units.npz", len(d), "arrays")
+
+
+def generator_case(tag, resolution, batch, seed, regime, kind="demo", scale=1.0, stride=1):
+    sd_np = synth.make_state_dict(resolution, seed=seed, regime=regime)
+    x = synth.make_input(batch, resolution, seed=seed, kind=kind) * np.float32(scale)
+    g = ref.Generator(resolution=resolution)
+    g.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd_np.items()}, strict=True)
+    g.eval()
+    taps = {}
+    hooks = []
+    for name, mod in g.named_modules():
+        if isinstance(mod, (ref.SeparableConv2d, ref.EncoderBlock, ref.SynthesisBlock, ref.SynthesisBlockFirst)):
+            def hook(m, inp, out, name=name):
+                o = out[0] if isinstance(out, tuple) else out
+                taps[name] = tap_summary(o)
+                if isinstance(out, tuple) and out[1] is not None and isinstance(m, (ref.SynthesisBlock, ref.SynthesisBlockFirst)):
+                    taps[name + ".img"] = tap_summary(out[1])
+            hooks.append(mod.register_forward_hook(hook))
+    with torch.no_grad():
+        y = g(torch.from_numpy(x.copy())).numpy()
+    for h in hooks:
+        h.remove()
+    d = {
+        "resolution": np.int64(resolution), "batch": np.int64(batch), "seed": np.int64(seed),
+        "regime": np.array(regime), "kind": np.array(kind), "scale": np.float64(scale), "stride": np.int64(stride),
+        "y": y[:, :, ::stride, ::stride].copy(),
+        "y_sum": y.astype(np.float64).sum(axis=(2, 3)),
+        "y_abs_sum": np.abs(y.astype(np.float64)).sum(axis=(2, 3)),
+        "y_absmax": np.float64(np.abs(y).max()),
+        "x_abs_sum": np.float64(np.abs(x.astype(np.float64)).sum()),
+        "sd_abs_sum": np.float64(sum(np.abs(v.astype(np.float64)).sum() for v in sd_np.values())),
+    }
+    for k, v in taps.items():
+        d["tap/" + k] = v
+    np.savez_compressed(os.path.join(HERE, f"generator_{tag}.npz"), **d)
+    print(f"generator_{tag}.npz  R={resolution} N={batch} |y|max={d['y_absmax']:.4f} taps={len(taps)}")
+
+
+if __name__ == "__main__":
+    schema_json()
+    units()
+    generator_case("r8_export", 8, 3, 11, "export")
+    generator_case("r16_export", 16, 2, 12, "export")
+    generator_case("r16_clamp", 16, 2, 13, "export", kind="randn", scale=1e3)
+    generator_case("r32_init", 32, 2, 14, "init")
+    generator_case("r64_export", 64, 2, 15, "export")
+    generator_case("r256_export", 256, 1, 16, "export", stride=4)
+    generator_case("r512_export", 512, 1, 17, "export", stride=8)
+    generator_case("r512_randn", 512, 1, 18, "export", kind="randn", stride=8)

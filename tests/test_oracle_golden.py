@@ -1,0 +1,110 @@
+"""Pin both oracles to the REFERENCE's own outputs (tests/golden/*.npz, produced
+by tests/golden/make_golden.py from /root/reference).  Tolerances: the
+reference's two own implementations differ by 2.7e-5 at |y|~30;
+op-order differences between oneDNN and numpy land in the same class."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from oracle import migan_oracle as orc
+from oracle import migan_torch_cpu as torc
+
+
+def _tap_summary(a):
+    a = np.asarray(a, dtype=np.float64).ravel()
+    idx = (np.arange(13, dtype=np.int64) * 2654435761 + 12345) % a.size
+    return np.concatenate([[a.mean(), a.std(), np.abs(a).max()], a[idx]])
+
+
+@pytest.fixture(scope="module")
+def units(golden_dir):
+    return np.load(os.path.join(golden_dir, "units.npz"))
+
+
+def test_act_matches_reference(units):
+    y = orc.lrelu_agc(units["act_x"].copy())
+    np.testing.assert_array_equal(y, units["act_y"])          # elementwise fp32: bit exact
+
+
+def test_fir_down_up_match_reference(units):
+    x = units["fir_x"]
+    np.testing.assert_allclose(orc.downsample2d(x), units["down_y"], rtol=0, atol=2e-6)
+    np.testing.assert_allclose(orc.upsample2d(x), units["up_y"], rtol=0, atol=2e-6)
+    np.testing.assert_allclose(orc.upsample2d_closed_form(x), units["up_y"], rtol=0, atol=2e-6)
+    np.testing.assert_allclose(orc.downsample2d(units["fir_x2"]), units["down_y2"], rtol=0, atol=2e-6)
+
+
+@pytest.mark.parametrize("tag", ["plain", "down", "up", "noise"])
+def test_separable_conv_matches_reference(units, tag):
+    sd = {k.split("/", 1)[1]: units[k] for k in units.files if k.startswith(f"sep_{tag}_sd/")}
+    sd = {"m." + k: v for k, v in sd.items()}
+    y = orc.separable_conv(units[f"sep_{tag}_x"].copy(), sd, "m")
+    ref = units[f"sep_{tag}_y"]
+    assert y.shape == ref.shape
+    np.testing.assert_allclose(y, ref, rtol=0, atol=2e-5 * max(1.0, np.abs(ref).max()))
+
+
+def _cases(golden_dir, max_res):
+    out = []
+    for f in sorted(glob.glob(os.path.join(golden_dir, "generator_*.npz"))):
+        g = np.load(f)
+        if int(g["resolution"]) <= max_res:
+            out.append(f)
+    return out
+
+
+def _check_case(pkg, path, fn, tol_scale):
+    g = np.load(path)
+    r, n, seed = int(g["resolution"]), int(g["batch"]), int(g["seed"])
+    sd = pkg.synth.make_state_dict(r, seed=seed, regime=str(g["regime"]))
+    x = pkg.synth.make_input(n, r, seed=seed, kind=str(g["kind"])) * np.float32(float(g["scale"]))
+    # the synthetic generators must reproduce what the golden script fed the reference
+    sd_sum = sum(np.abs(v.astype(np.float64)).sum() for v in sd.values())
+    assert abs(sd_sum - float(g["sd_abs_sum"])) <= 1e-9 * float(g["sd_abs_sum"])
+    assert abs(np.abs(x.astype(np.float64)).sum() - float(g["x_abs_sum"])) <= 1e-9 * max(1.0, float(g["x_abs_sum"]))
+    taps = {}
+    y = np.asarray(fn(x, sd, r, taps))
+    s = int(g["stride"])
+    amax = float(g["y_absmax"])
+    tol = tol_scale * max(1.0, amax)
+    np.testing.assert_allclose(y[:, :, ::s, ::s], g["y"], rtol=0, atol=tol)
+    np.testing.assert_allclose(y.astype(np.float64).sum(axis=(2, 3)), g["y_sum"], rtol=0, atol=tol * y.shape[2] * y.shape[3])
+    # per-layer taps recorded by forward hooks on the reference modules
+    n_checked = 0
+    for k in g.files:
+        if not k.startswith("tap/"):
+            continue
+        name = k[4:]
+        if name in taps:
+            got = _tap_summary(np.asarray(taps[name]))
+            ref = g[k]
+            np.testing.assert_allclose(got, ref, rtol=0, atol=tol_scale * max(1.0, ref[2]), err_msg=name)
+            n_checked += 1
+    assert n_checked >= 2 * (int(np.log2(r)) - 1)
+
+
+def test_numpy_oracle_generator_goldens(pkg, golden_dir):
+    cases = _cases(golden_dir, 64)
+    assert len(cases) >= 5
+    for path in cases:
+        _check_case(pkg, path, lambda x, sd, r, taps: orc.generator(x, sd, r, taps=taps), 3e-5)
+
+
+def test_torch_cpu_oracle_generator_goldens(pkg, golden_dir):
+    cases = _cases(golden_dir, 512)
+    assert len(cases) >= 8
+    for path in cases:
+        _check_case(pkg, path, lambda x, sd, r, taps: torc.generator(x, sd, r, taps=taps).numpy(), 3e-5)
+
+
+def test_numpy_fp64_oracle_bounds_fp32_error(pkg, golden_dir):
+    """fp64 restatement vs the reference's fp32 output: the gap is the fp32
+    rounding budget (<1e-3 abs is the product target)."""
+    g = np.load(os.path.join(golden_dir, "generator_r64_export.npz"))
+    r, n, seed = int(g["resolution"]), int(g["batch"]), int(g["seed"])
+    sd = pkg.synth.make_state_dict(r, seed=seed, regime="export")
+    x = pkg.synth.make_input(n, r, seed=seed)
+    y64 = orc.generator(x, sd, r, dtype=np.float64)
+    assert np.abs(y64 - g["y"]).max() < 2e-4
