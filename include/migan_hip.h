@@ -1,0 +1,128 @@
+/* migan_hip.h -- C ABI of libmigan_hip.so: MI355X (gfx950) MI-GAN generator forward.
+ *
+ * Drop-in boundary for the hot path of Picsart-AI-Research/MI-GAN,
+ *   lib/model_zoo/migan_inference.py::Generator        (reference :355-369)
+ * i.e. what a binding for that module would call instead of torch.nn.Conv2d / F.pad /
+ * nn.Upsample.  Plain pointers and sizes only: no torch, no HIP types in the signatures
+ * (`stream` is a hipStream_t passed as void*; 0 = the default stream).
+ *
+ * Conventions
+ *   - every function returns 0 on success, a MIGAN_E* code otherwise; the message for the last
+ *     failure on the calling thread is migan_last_error().  Nothing throws across the boundary.
+ *   - all tensors are fp32 device pointers owned by the caller.  Weights are passed in the
+ *     reference's own state_dict layouts (conv weights [Co][Ci][kh][kw], etc.) and are read in
+ *     place: they must stay valid and unmodified-in-address until the next migan_set_weight /
+ *     migan_destroy.  The library allocates no device memory.
+ *   - activations inside the library are NHWC; the network input/output keep the reference's
+ *     NCHW contract ([N,4,R,R] -> [N,3,R,R], reference :362-369).
+ *   - all launches are asynchronous on `stream`; no device synchronisation happens inside
+ *     migan_forward.  A handle is not safe for concurrent forwards (same as an nn.Module whose
+ *     forward uses in-place ops, reference :21,:167,:313); use one handle per stream.
+ */
+#ifndef MIGAN_HIP_H_
+#define MIGAN_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MIGAN_OK 0
+#define MIGAN_EINVAL 1      /* bad argument (shape, name, null pointer, unsupported resolution) */
+#define MIGAN_ESTATE 2      /* call order: weights missing / not committed */
+#define MIGAN_ERUNTIME 3    /* HIP runtime error (launch failure, copy failure) */
+#define MIGAN_EUNSUPPORTED 4 /* checkpoint uses FIR taps other than setup_filter([1,3,3,1]) */
+
+#define MIGAN_DTYPE_F32 0
+
+typedef struct migan_handle migan_handle;
+
+/* Generator(resolution) -- reference :356-360.  resolution must be a power of two in [8,512]
+ * (the reference raises ValueError for non powers of two, :215-216,:330-331 -> MIGAN_EINVAL). */
+int migan_create(int resolution, int dtype, int device, migan_handle** out);
+int migan_destroy(migan_handle* h);
+
+/* state_dict schema (same keys, shapes and parameter/buffer split as
+ * reference Generator(resolution).state_dict(); 177 entries at 512, 154 at 256). */
+int migan_num_weights(const migan_handle* h, int* n);
+int migan_weight_info(const migan_handle* h, int index, const char** name,
+                      int64_t shape[4], int* ndim, int* is_buffer);
+
+/* load_state_dict: bind one tensor by its reference key (reference scripts/demo.py:110).
+ * Unknown key or shape mismatch -> MIGAN_EINVAL, as load_state_dict(strict=True) would raise. */
+int migan_set_weight(migan_handle* h, const char* name, const void* dev_ptr,
+                     const int64_t* shape, int ndim);
+/* Check that every entry is bound and that the FIR parameters/buffers hold the constants the
+ * kernels implement in closed form (filter.weight == setup_filter([1,3,3,1]) reference :71-72,
+ * :95-96; filter_const == even/even pattern :83-85).  Copies those small tensors to the host
+ * (synchronises `stream`).  Must be called after the last migan_set_weight. */
+int migan_commit(migan_handle* h, void* stream);
+
+/* Scratch (skip tensors, ping-pong activations, running RGB image) for a batch of n images. */
+int migan_workspace_bytes(const migan_handle* h, int batch, size_t* bytes);
+
+/* Generator.forward (reference :362-369).  x: [batch,4,R,R] = cat([mask-0.5, img*mask])
+ * (reference scripts/demo.py:56-66); y: [batch,3,R,R].  x is not modified. */
+int migan_forward(migan_handle* h, const void* x_nchw, void* y_nchw, int batch,
+                  void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- measurement and debugging ---------------------------------------------------------- */
+
+/* The forward is a fixed sequence of kernel launches (one per SeparableConv2d, plus un-fused
+ * ToRGB launches at low resolution). */
+int migan_num_launches(const migan_handle* h, int* n);
+/* layer: reference module path ("encoder.b512.conv1", "synthesis.b8.torgb", ...);
+ * kernel: kernel symbol as rocprofv3 prints it; flops / bytes: algorithmic work PER IMAGE
+ * (2*MAC of every fused stage; one read of each input, one write of each output). */
+int migan_launch_info(const migan_handle* h, int index, const char** layer, const char** kernel,
+                      double* flops_per_image, double* mfma_flops_per_image,
+                      double* bytes_per_image, int* workgroups_batch1);
+/* Same as migan_forward, with a hipEvent pair around every launch on `stream`;
+ * layer_ms[i] = duration of launch i.  Synchronises the stream before returning. */
+int migan_forward_timed(migan_handle* h, const void* x_nchw, void* y_nchw, int batch,
+                        void* workspace, size_t workspace_bytes, void* stream,
+                        float* layer_ms, int n_layer_ms);
+/* keep_intermediates != 0: every layer writes to its own workspace region (no ping-pong) so
+ * tests can compare each reference module output.  Changes migan_workspace_bytes. */
+int migan_set_debug(migan_handle* h, int keep_intermediates);
+/* Location of a layer output inside the workspace after a forward with keep_intermediates:
+ * NHWC [batch][r][r][c] for "<block>.conv1|conv2", planar [batch][3][r][r] for "<block>.img". */
+int migan_debug_tensor(const migan_handle* h, int batch, const char* layer,
+                       size_t* byte_offset, int64_t shape[4]);
+
+/* ---- single operator --------------------------------------------------------------------- */
+
+/* One SeparableConv2d.forward (reference :106-170) on NHWC tensors; used by the operator-level
+ * parity tests.  Pointers follow the reference parameter layouts; optional ones may be null. */
+typedef struct migan_sepconv_desc {
+  const void* x;              /* NHWC [batch][res_in][res_in][cin]; with fromrgb: NCHW [batch][4][res_in][res_in] */
+  void* y;                    /* NHWC [batch][res_out][res_out][cout] */
+  const void* skip;           /* NHWC like y, added after the activation (reference :272,:305) */
+  const void* conv1_weight;   /* [cin][1][3][3] */
+  const void* conv1_bias;     /* [cin] */
+  const void* conv2_weight;   /* [cout][cin][1][1] */
+  const void* noise_const;    /* [res_out][res_out] or null */
+  const void* noise_strength; /* scalar (device) */
+  const void* fromrgb_weight; /* [cin][4][1][1] or null: x = act(fromrgb(x)) first (reference :193-196) */
+  const void* fromrgb_bias;   /* [cin] */
+  const void* torgb_weight;   /* [3][cout][1][1] or null: also produce img (reference :308-313) */
+  const void* torgb_bias;     /* [3] */
+  const void* img_prev;       /* planar [batch][3][res_out/2][res_out/2] or null */
+  void* img_out;              /* planar [batch][3][res_out][res_out] */
+  int batch, cin, cout, res_in;
+  int down;                   /* 1 or 2 (Downsample2d, reference :58-76) */
+  int up;                     /* 1 or 2 (Upsample2d, reference :79-103) */
+} migan_sepconv_desc;
+int migan_sepconv_forward(const migan_sepconv_desc* d, void* stream);
+
+const char* migan_last_error(void);
+/* "hip:gfx950" for the product library. */
+const char* migan_backend(void);
+int migan_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MIGAN_HIP_H_ */

@@ -1,0 +1,42 @@
+// HIP runtime shim for the product build (hipcc --offload-arch=gfx950).  The same `rt` interface
+// is implemented by tests/emu/hip_emu.h for the CPU test harness.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <string>
+
+#define MIGAN_DEVICE __device__
+#define MIGAN_INLINE __forceinline__
+#define MIGAN_GLOBAL __global__
+#define MIGAN_LAUNCH_BOUNDS(threads, waves_per_simd) __launch_bounds__(threads, waves_per_simd)
+#define MIGAN_DYN_SMEM(name) extern __shared__ __attribute__((aligned(16))) float name[]
+// v_mfma_f32_32x32x2_f32: exact-f32 matrix FMA (D = A[32x2] * B[2x32] + C), 64 cycles per SIMD
+#define MIGAN_MFMA_F32_32X32X2(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+#define MIGAN_FMUL_RN(a, b) __fmul_rn((a), (b))
+
+namespace rt {
+typedef hipStream_t stream_t;
+typedef hipEvent_t event_t;
+
+inline const char* backend_name() { return "hip:gfx950"; }
+inline std::string error_string(int rc) { return hipGetErrorString((hipError_t)rc); }
+inline int set_device(int dev) { return (int)hipSetDevice(dev); }
+inline int allow_dynamic_lds(const void* fn, size_t bytes) {
+  return (int)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+template <class Args>
+inline int launch(void (*kernel)(const Args), const Args& a, unsigned grid, unsigned block, size_t lds, stream_t s) {
+  hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), lds, s, a);
+  return (int)hipGetLastError();
+}
+inline int memcpy_d2h(void* dst, const void* src, size_t bytes, stream_t s) {
+  hipError_t e = hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, s);
+  if (e != hipSuccess) return (int)e;
+  return (int)hipStreamSynchronize(s);
+}
+inline int stream_sync(stream_t s) { return (int)hipStreamSynchronize(s); }
+inline int event_create(event_t* e) { return (int)hipEventCreate(e); }
+inline int event_destroy(event_t e) { return (int)hipEventDestroy(e); }
+inline int event_record(event_t e, stream_t s) { return (int)hipEventRecord(e, s); }
+inline int event_elapsed(float* ms, event_t a, event_t b) { return (int)hipEventElapsedTime(ms, a, b); }
+}  // namespace rt

@@ -1,0 +1,54 @@
+"""Batch sharding of the generator forward over the GPUs of one node.
+
+Images in a batch are independent (no batch statistics anywhere in the generator), so the only
+exchange step is the gather of the output shards: one ``all_gather`` (RCCL over xGMI when the
+backend is "nccl"; gloo on CPU in the tests).  One process per GPU, weights replicated.
+
+The reference has no multi-GPU inference path (its only parallelism is training-time DDP,
+lib/utils.py:41-46); the contract here is: gathered output == single-GPU output of the same batch.
+"""
+from __future__ import annotations
+
+from typing import Callable, Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def shard_range(total: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous shard [start, stop) of ``total`` images for ``rank``; sizes differ by at most 1."""
+    if world <= 0 or not (0 <= rank < world):
+        raise ValueError("bad rank/world")
+    base, rem = divmod(total, world)
+    start = rank * base + min(rank, rem)
+    return start, start + base + (1 if rank < rem else 0)
+
+
+def gather_outputs(y_local: torch.Tensor, total: int, group=None) -> torch.Tensor:
+    """All-gather output shards [n_r,3,R,R] into [total,3,R,R] on every rank (rank order)."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return y_local
+    world = dist.get_world_size(group)
+    sizes = [shard_range(total, r, world)[1] - shard_range(total, r, world)[0] for r in range(world)]
+    if len(set(sizes)) == 1:
+        out = torch.empty((total,) + tuple(y_local.shape[1:]), dtype=y_local.dtype, device=y_local.device)
+        dist.all_gather_into_tensor(out, y_local.contiguous(), group=group)
+        return out
+    # ragged shards: pad to the largest, gather, drop the padding
+    mx = max(sizes)
+    pad = torch.zeros((mx,) + tuple(y_local.shape[1:]), dtype=y_local.dtype, device=y_local.device)
+    pad[: y_local.shape[0]] = y_local
+    parts = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(parts, pad, group=group)
+    return torch.cat([p[:s] for p, s in zip(parts, sizes)], dim=0)
+
+
+def sharded_forward(forward: Callable[[torch.Tensor], torch.Tensor], x_global: torch.Tensor,
+                    group=None, gather: bool = True) -> torch.Tensor:
+    """Run ``forward`` on this rank's slice of ``x_global`` and (optionally) gather all outputs."""
+    if not dist.is_initialized():
+        return forward(x_global)
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    lo, hi = shard_range(x_global.shape[0], rank, world)
+    y = forward(x_global[lo:hi])
+    return gather_outputs(y, x_global.shape[0], group) if gather else y

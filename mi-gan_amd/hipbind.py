@@ -1,9 +1,203 @@
-# placeholder, filled in below
+"""ctypes binding of the C ABI in include/migan_hip.h (libmigan_hip.so).
+
+This is the binding a maintainer of the reference would add next to
+``lib/model_zoo/migan_inference.py``.  It deals in raw
+addresses and sizes only; torch appears nowhere in this file.  There is no
+fallback: if the shared library is missing or fails to load, ``load_library``
+raises ``MiganError`` naming the build command.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Dict, List, Optional, Sequence, Tuple
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIBNAME = "libmigan_hip.so"
+
+MIGAN_OK, MIGAN_EINVAL, MIGAN_ESTATE, MIGAN_ERUNTIME, MIGAN_EUNSUPPORTED = 0, 1, 2, 3, 4
+
+
 class MiganError(RuntimeError):
-    pass
-class MiganLib:  # noqa
-    pass
-def load_library(path=None):
-    raise MiganError("not built")
-def library_path():
-    return None
+    def __init__(self, msg: str, code: int = MIGAN_ERUNTIME):
+        super().__init__(msg)
+        self.code = code
+
+
+def library_path() -> str:
+    return os.environ.get("MIGAN_HIP_LIBRARY", os.path.join(_HERE, "csrc", _LIBNAME))
+
+
+class SepConvDesc(C.Structure):
+    """struct migan_sepconv_desc"""
+    _fields_ = [(n, C.c_void_p) for n in (
+        "x", "y", "skip", "conv1_weight", "conv1_bias", "conv2_weight", "noise_const", "noise_strength",
+        "fromrgb_weight", "fromrgb_bias", "torgb_weight", "torgb_bias", "img_prev", "img_out")] + [
+        (n, C.c_int) for n in ("batch", "cin", "cout", "res_in", "down", "up")]
+
+
+EXPORTS = (
+    "migan_create", "migan_destroy", "migan_num_weights", "migan_weight_info", "migan_set_weight",
+    "migan_commit", "migan_workspace_bytes", "migan_forward", "migan_num_launches", "migan_launch_info",
+    "migan_forward_timed", "migan_set_debug", "migan_debug_tensor", "migan_sepconv_forward",
+    "migan_last_error", "migan_backend", "migan_version",
+)
+
+
+class MiganLib:
+    """Typed view of one loaded libmigan_hip.so."""
+
+    def __init__(self, path: Optional[str] = None):
+        self.path = path or library_path()
+        if not os.path.exists(self.path):
+            raise MiganError(
+                f"{self.path} not found: the MI355X HIP extension is not built. "
+                f"Run `python -c 'import __graft_entry__ as g; g.build()'` (hipcc --offload-arch=gfx950). "
+                f"There is no CPU/PyTorch fallback for this path.")
+        try:
+            self.lib = C.CDLL(self.path)
+        except OSError as e:  # pragma: no cover - depends on the machine
+            raise MiganError(f"cannot load {self.path}: {e}") from e
+        L = self.lib
+        for name in EXPORTS:
+            if not hasattr(L, name):
+                raise MiganError(f"{self.path} does not export {name}")
+        vp, ci = C.c_void_p, C.c_int
+        L.migan_create.argtypes = [ci, ci, ci, C.POINTER(vp)]
+        L.migan_destroy.argtypes = [vp]
+        L.migan_num_weights.argtypes = [vp, C.POINTER(ci)]
+        L.migan_weight_info.argtypes = [vp, ci, C.POINTER(C.c_char_p), C.POINTER(C.c_int64), C.POINTER(ci), C.POINTER(ci)]
+        L.migan_set_weight.argtypes = [vp, C.c_char_p, vp, C.POINTER(C.c_int64), ci]
+        L.migan_commit.argtypes = [vp, vp]
+        L.migan_workspace_bytes.argtypes = [vp, ci, C.POINTER(C.c_size_t)]
+        L.migan_forward.argtypes = [vp, vp, vp, ci, vp, C.c_size_t, vp]
+        L.migan_num_launches.argtypes = [vp, C.POINTER(ci)]
+        L.migan_launch_info.argtypes = [vp, ci, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.POINTER(C.c_double),
+                                        C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(ci)]
+        L.migan_forward_timed.argtypes = [vp, vp, vp, ci, vp, C.c_size_t, vp, C.POINTER(C.c_float), ci]
+        L.migan_set_debug.argtypes = [vp, ci]
+        L.migan_debug_tensor.argtypes = [vp, ci, C.c_char_p, C.POINTER(C.c_size_t), C.POINTER(C.c_int64)]
+        L.migan_sepconv_forward.argtypes = [C.POINTER(SepConvDesc), vp]
+        L.migan_last_error.restype = C.c_char_p
+        L.migan_backend.restype = C.c_char_p
+        for name in EXPORTS:
+            if name not in ("migan_last_error", "migan_backend"):
+                getattr(L, name).restype = ci
+
+    # -- error mapping: EINVAL -> ValueError-like, like the reference's constructor / load_state_dict
+    def check(self, rc: int) -> None:
+        if rc == MIGAN_OK:
+            return
+        msg = (self.lib.migan_last_error() or b"").decode()
+        if rc == MIGAN_EINVAL:
+            err: Exception = ValueError(msg)
+        elif rc == MIGAN_EUNSUPPORTED:
+            err = NotImplementedError(msg)
+        else:
+            err = MiganError(msg, rc)
+        raise err
+
+    def backend(self) -> str:
+        return self.lib.migan_backend().decode()
+
+    def sepconv_forward(self, stream: int = 0, **kw) -> None:
+        d = SepConvDesc()
+        for f, _ in SepConvDesc._fields_:
+            setattr(d, f, kw.pop(f, None if f not in ("batch", "cin", "cout", "res_in", "down", "up") else 0))
+        if kw:
+            raise TypeError(f"unknown sepconv fields: {sorted(kw)}")
+        d.down = d.down or 1
+        d.up = d.up or 1
+        self.check(self.lib.migan_sepconv_forward(C.byref(d), C.c_void_p(stream)))
+
+
+class MiganHandle:
+    """RAII wrapper of ``migan_handle*`` (one Generator(resolution) instance)."""
+
+    def __init__(self, lib: MiganLib, resolution: int, device: int = 0):
+        self.lib = lib
+        self._h = C.c_void_p()
+        lib.check(lib.lib.migan_create(int(resolution), 0, int(device), C.byref(self._h)))
+        self.resolution = int(resolution)
+
+    def close(self) -> None:
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self.lib.lib.migan_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def weights(self) -> List[Tuple[str, Tuple[int, ...], bool]]:
+        n = C.c_int()
+        self.lib.check(self.lib.lib.migan_num_weights(self._h, C.byref(n)))
+        out = []
+        for i in range(n.value):
+            name = C.c_char_p()
+            shape = (C.c_int64 * 4)()
+            nd, isb = C.c_int(), C.c_int()
+            self.lib.check(self.lib.lib.migan_weight_info(self._h, i, C.byref(name), shape, C.byref(nd), C.byref(isb)))
+            out.append((name.value.decode(), tuple(int(shape[k]) for k in range(nd.value)), bool(isb.value)))
+        return out
+
+    def set_weight(self, name: str, ptr: int, shape: Sequence[int]) -> None:
+        arr = (C.c_int64 * max(1, len(shape)))(*[int(s) for s in shape])
+        self.lib.check(self.lib.lib.migan_set_weight(self._h, name.encode(), C.c_void_p(ptr), arr, len(shape)))
+
+    def commit(self, stream: int = 0) -> None:
+        self.lib.check(self.lib.lib.migan_commit(self._h, C.c_void_p(stream)))
+
+    def workspace_bytes(self, batch: int) -> int:
+        n = C.c_size_t()
+        self.lib.check(self.lib.lib.migan_workspace_bytes(self._h, int(batch), C.byref(n)))
+        return int(n.value)
+
+    def forward(self, x_ptr: int, y_ptr: int, batch: int, ws_ptr: int, ws_bytes: int, stream: int = 0) -> None:
+        self.lib.check(self.lib.lib.migan_forward(self._h, C.c_void_p(x_ptr), C.c_void_p(y_ptr), int(batch),
+                                                  C.c_void_p(ws_ptr), C.c_size_t(ws_bytes), C.c_void_p(stream)))
+
+    def forward_timed(self, x_ptr: int, y_ptr: int, batch: int, ws_ptr: int, ws_bytes: int, stream: int = 0) -> List[float]:
+        n = len(self.launches())
+        ms = (C.c_float * n)()
+        self.lib.check(self.lib.lib.migan_forward_timed(self._h, C.c_void_p(x_ptr), C.c_void_p(y_ptr), int(batch),
+                                                        C.c_void_p(ws_ptr), C.c_size_t(ws_bytes), C.c_void_p(stream), ms, n))
+        return [float(v) for v in ms]
+
+    def launches(self) -> List[Dict]:
+        n = C.c_int()
+        self.lib.check(self.lib.lib.migan_num_launches(self._h, C.byref(n)))
+        out = []
+        for i in range(n.value):
+            layer, kern = C.c_char_p(), C.c_char_p()
+            fl, mf, by = C.c_double(), C.c_double(), C.c_double()
+            wg = C.c_int()
+            self.lib.check(self.lib.lib.migan_launch_info(self._h, i, C.byref(layer), C.byref(kern), C.byref(fl),
+                                                          C.byref(mf), C.byref(by), C.byref(wg)))
+            out.append(dict(layer=layer.value.decode(), kernel=kern.value.decode(), flops=fl.value,
+                            mfma_flops=mf.value, bytes=by.value, workgroups_batch1=wg.value))
+        return out
+
+    def set_debug(self, keep: bool) -> None:
+        self.lib.check(self.lib.lib.migan_set_debug(self._h, 1 if keep else 0))
+
+    def debug_tensor(self, batch: int, layer: str) -> Tuple[int, Tuple[int, ...]]:
+        off = C.c_size_t()
+        shape = (C.c_int64 * 4)()
+        self.lib.check(self.lib.lib.migan_debug_tensor(self._h, int(batch), layer.encode(), C.byref(off), shape))
+        return int(off.value), tuple(int(s) for s in shape)
+
+
+_LIB: Optional[MiganLib] = None
+
+
+def load_library(path: Optional[str] = None) -> MiganLib:
+    """Process-wide libmigan_hip.so (raises MiganError when it is not built)."""
+    global _LIB
+    if path is not None:
+        return MiganLib(path)
+    if _LIB is None:
+        _LIB = MiganLib()
+    return _LIB

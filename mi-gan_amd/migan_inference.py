@@ -1,2 +1,206 @@
-class Generator:  # placeholder
-    pass
+"""Drop-in for ``lib.model_zoo.migan_inference`` of Picsart-AI-Research/MI-GAN.
+
+``Generator(resolution)`` has the reference's constructor, sub-module tree /
+``state_dict`` schema (so ``model.load_state_dict(torch.load(path))`` from
+scripts/demo.py:110 works unchanged) and ``forward(x)`` contract
+(x: [N,4,R,R] = cat([mask-0.5, img*mask]) -> [N,3,R,R]; reference :355-369),
+but ``forward`` is a single call into the MI355X HIP library through the C ABI
+(include/migan_hip.h).  PyTorch is used for device memory and streams only.
+
+There is no CPU or pure-PyTorch path here: a CPU tensor, a missing
+libmigan_hip.so or a missing GPU raises.  Not supported (reference "out of
+contract" list): autograd, torch.jit.trace / ONNX export.
+
+Inject as ``sys.modules['lib.model_zoo.migan_inference']`` to run the reference
+scripts unmodified.
+"""
+from __future__ import annotations
+
+import math
+from typing import List, Optional, Tuple
+
+import torch
+import torch.nn as nn
+
+from . import schema
+from .hipbind import MiganError, MiganHandle, MiganLib, load_library
+
+# reference class of each node of the module tree, for repr() only
+_NODE_KIND = {
+    "synthesis": "Synthesis", "encoder": "Encoder", "conv1": "SeparableConv2d", "conv2": "SeparableConv2d",
+    "fromrgb": "Conv2d", "torgb": "Conv2d", "downsample": "Downsample2d", "upsample": "Upsample2d", "filter": "Conv2d",
+}
+
+
+class _Node(nn.Module):
+    """Parameter container mirroring one reference sub-module (names only; the
+    arithmetic of the whole tree happens in Generator.forward on the GPU)."""
+
+    def __init__(self, kind: str = "Module"):
+        super().__init__()
+        self._kind = kind
+
+    def _get_name(self):
+        return self._kind
+
+    def forward(self, *args, **kwargs):
+        raise NotImplementedError(
+            f"{self._kind}: only Generator.forward is implemented on the MI355X HIP path; "
+            "sub-modules hold the reference-named parameters")
+
+
+def _init_tensor(e: schema.Entry) -> torch.Tensor:
+    """Constructor-time values, same distributions as the reference's layers."""
+    shp = e.shape
+    if e.role in ("dw_w", "pw_w", "rgb_w"):
+        w = torch.empty(shp)
+        nn.init.kaiming_uniform_(w, a=math.sqrt(5))           # nn.Conv2d default, reference :122-136
+        return w
+    if e.role in ("dw_b", "rgb_b"):
+        fan_in = {"dw_b": 9}.get(e.role)
+        if fan_in is None:
+            fan_in = 4 if "fromrgb" in e.name else schema.channels(int(e.name.split(".")[1][1:]))
+        bound = 1.0 / math.sqrt(fan_in)
+        return torch.empty(shp).uniform_(-bound, bound)
+    if e.role == "noise_strength":
+        return torch.zeros(())                                 # reference :150
+    if e.role == "noise_const":
+        return torch.randn(shp)                                # reference :149
+    if e.role == "fir_down":
+        return torch.tensor(schema.fir_kernel_2d(1.0)).repeat(shp[0], 1, 1, 1)    # reference :71-72
+    if e.role == "fir_up":
+        return torch.tensor(schema.fir_kernel_2d(4.0)).repeat(shp[0], 1, 1, 1)    # reference :95-96
+    if e.role == "filter_const":
+        w = torch.tensor([[1.0, 0.0], [0.0, 0.0]])
+        return w.repeat(1, 1, shp[2] // 2, shp[3] // 2)        # reference :83-85
+    raise AssertionError(e.role)
+
+
+class Generator(nn.Module):
+    """MI-GAN inference generator (reference migan_inference.py:355-369) on MI355X."""
+
+    def __init__(self, resolution: int = 256):
+        super().__init__()
+        schema.check_resolution(resolution)                    # ValueError like reference :215-216
+        if resolution > schema.MAX_RESOLUTION:
+            raise NotImplementedError(
+                f"resolution {resolution}: feature width {schema.channels(resolution)} is below the 64-channel "
+                "MFMA column tile; supported resolutions are 8..512")
+        self.resolution = resolution
+        self._names: List[str] = []
+        for e in schema.entries(resolution):
+            node: nn.Module = self
+            parts = e.name.split(".")
+            for p in parts[:-1]:
+                if not hasattr(node, p):
+                    kind = _NODE_KIND.get(p, "EncoderBlock" if parts[0] == "encoder" else "SynthesisBlock")
+                    node.add_module(p, _Node(kind))
+                node = getattr(node, p)
+            t = _init_tensor(e)
+            if e.kind == "param":
+                node.register_parameter(parts[-1], nn.Parameter(t))
+            else:
+                node.register_buffer(parts[-1], t)
+            self._names.append(e.name)
+        # engine state (never part of state_dict)
+        self._lib: Optional[MiganLib] = None
+        self._handle: Optional[MiganHandle] = None
+        self._handle_device: Optional[int] = None
+        self._bound: Optional[Tuple[int, ...]] = None
+        self._dirty = True
+        self._ws: Optional[torch.Tensor] = None
+        self.register_load_state_dict_post_hook(lambda module, incompatible: module._invalidate())
+
+    # ------------------------------------------------------------------ plumbing
+    def _invalidate(self) -> None:
+        self._dirty = True
+
+    def _apply(self, fn, *args, **kwargs):
+        out = super()._apply(fn, *args, **kwargs)
+        self._invalidate()
+        return out
+
+    def _tensors(self) -> List[torch.Tensor]:
+        sd = dict(self.named_parameters())
+        sd.update(dict(self.named_buffers()))
+        return [sd[n] for n in self._names]
+
+    def _require_device(self, x: torch.Tensor) -> int:
+        if not x.is_cuda:
+            raise RuntimeError(
+                "mi-gan_amd Generator.forward needs a tensor on an MI355X (HIP) device; there is no CPU path. "
+                "Move the model and input with .to('cuda').")
+        return x.device.index if x.device.index is not None else torch.cuda.current_device()
+
+    def _stream(self, x: torch.Tensor) -> int:
+        return int(torch.cuda.current_stream(x.device).cuda_stream)
+
+    def _engine(self, x: torch.Tensor) -> MiganHandle:
+        dev = self._require_device(x)
+        if self._lib is None:
+            self._lib = load_library()                         # raises MiganError when not built
+        if self._handle is None or self._handle_device != dev:
+            if self._handle is not None:
+                self._handle.close()
+            self._handle = MiganHandle(self._lib, self.resolution, dev)
+            self._handle_device = dev
+            self._bound = None
+        tensors = self._tensors()
+        ptrs = tuple(t.data_ptr() for t in tensors)
+        if self._dirty or ptrs != self._bound:
+            for name, t in zip(self._names, tensors):
+                if t.device != x.device:
+                    raise RuntimeError(
+                        f"Expected all tensors to be on the same device, but {name} is on {t.device} and the input on {x.device}")
+                if t.dtype != torch.float32 or not t.is_contiguous():
+                    raise RuntimeError(f"{name}: parameters must be contiguous float32 (got {t.dtype})")
+                self._handle.set_weight(name, t.data_ptr(), tuple(t.shape))
+            self._handle.commit(self._stream(x))
+            self._bound = ptrs
+            self._dirty = False
+        return self._handle
+
+    def _workspace(self, h: MiganHandle, batch: int, device: torch.device) -> torch.Tensor:
+        need = h.workspace_bytes(batch)
+        if self._ws is None or self._ws.device != device or self._ws.numel() < need:
+            self._ws = None
+            self._ws = torch.empty(need, dtype=torch.uint8, device=device)
+        return self._ws
+
+    def _check_input(self, x: torch.Tensor) -> torch.Tensor:
+        r = self.resolution
+        if x.dim() != 4 or x.shape[1] != 4 or x.shape[2] != r or x.shape[3] != r:
+            raise RuntimeError(f"expected input of shape [N, 4, {r}, {r}] (mask-0.5, img*mask), got {list(x.shape)}")
+        if x.dtype != torch.float32:
+            raise RuntimeError(f"Input type ({x.dtype}) and weight type (torch.float32) should be the same")
+        if x.shape[0] == 0:
+            raise RuntimeError("empty batch")
+        return x.contiguous()
+
+    # ------------------------------------------------------------------ API
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        """Args: x: 4 channel rgb+mask [N,4,R,R]; returns img [N,3,R,R] (reference :362-369)."""
+        x = self._check_input(x)
+        h = self._engine(x)
+        n = x.shape[0]
+        ws = self._workspace(h, n, x.device)
+        y = torch.empty((n, 3, self.resolution, self.resolution), dtype=torch.float32, device=x.device)
+        h.forward(x.data_ptr(), y.data_ptr(), n, ws.data_ptr(), ws.numel(), self._stream(x))
+        return y
+
+    def forward_timed(self, x: torch.Tensor):
+        """forward() with a hipEvent pair around every kernel launch: (y, [ms per launch])."""
+        x = self._check_input(x)
+        h = self._engine(x)
+        n = x.shape[0]
+        ws = self._workspace(h, n, x.device)
+        y = torch.empty((n, 3, self.resolution, self.resolution), dtype=torch.float32, device=x.device)
+        ms = h.forward_timed(x.data_ptr(), y.data_ptr(), n, ws.data_ptr(), ws.numel(), self._stream(x))
+        return y, ms
+
+    def launch_info(self):
+        """Per-launch layer / kernel names and algorithmic flops and bytes per image."""
+        if self._lib is None:
+            self._lib = load_library()
+        h = self._handle or MiganHandle(self._lib, self.resolution, 0)
+        return h.launches()

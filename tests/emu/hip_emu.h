@@ -1,0 +1,205 @@
+// TEST INFRASTRUCTURE ONLY -- never part of the product, never loaded by the package.
+//
+// A minimal SIMT emulator that lets the CPU test-suite execute the *same kernel source*
+// (mi-gan_amd/csrc/migan_kernels.hpp) and the same host plan / C ABI (migan_host.hpp) without a GPU,
+// to check tile indexing, LDS carving, barrier placement and the MFMA fragment mapping.
+//
+// Model: one workgroup = 256 lanes, each lane a user-level fiber (hand-rolled x86-64 context switch)
+// on ONE OS thread; lanes run to the next collective (__syncthreads, MFMA, shuffle) and then yield
+// round-robin.  Lane 0 therefore runs arbitrarily far ahead of lane 255 between barriers, which is
+// the most adversarial legal schedule: a missing barrier shows up as a wrong result.  LDS is filled
+// with NaNs before every block (reads of never-written LDS poison the output) and has a canary
+// behind it.  Blocks are distributed over OS threads.
+//
+// MFMA semantics follow /opt/skills/guides/cdna_hip_programming.md section 3:
+//   v_mfma_f32_32x32x2_f32: lane l supplies A[i=l&31][k=l>>5], B[k=l>>5][j=l&31];
+//   D[i][j] = fma(A[i][1],B[1][j], fma(A[i][0],B[0][j], C[i][j])), lane holds column j=l&31,
+//   rows i = (r&3) + 8*(r>>2) + 4*(l>>5) for r = 0..15.
+#pragma once
+
+#include <atomic>
+#include <chrono>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+namespace hipemu {
+
+struct Dim3 {
+  unsigned x = 1, y = 1, z = 1;
+};
+
+struct Lane {
+  Dim3 tid;
+  void* sp = nullptr;
+  bool done = false;
+};
+
+constexpr int kMaxLanes = 256;
+constexpr int kMaxWaves = kMaxLanes / 64;
+constexpr size_t kStackBytes = 96 * 1024;
+
+struct Block {
+  Dim3 bid, bdim, gdim;
+  float* smem = nullptr;
+  int nlanes = 0, cur = 0, alive = 0;
+  Lane lanes[kMaxLanes];
+  void* sched_sp = nullptr;
+  int blk_arrived = 0;
+  unsigned blk_gen = 0;
+  int wave_arrived[kMaxWaves] = {0};
+  unsigned wave_gen[kMaxWaves] = {0};
+  int wave_alive[kMaxWaves] = {0};
+  float xa[kMaxWaves][64], xb[kMaxWaves][64];
+  void (*invoke)(const void*) = nullptr;
+  const void* arg = nullptr;
+  char* stacks = nullptr;
+};
+
+extern thread_local Block* tl_blk;
+
+extern "C" void hipemu_switch(void** save_sp, void* load_sp);
+
+inline void switch_to(int from, int to) {
+  Block* b = tl_blk;
+  b->cur = to;
+  hipemu_switch(&b->lanes[from].sp, b->lanes[to].sp);
+}
+
+// round-robin to the next live lane; returns immediately if alone
+inline void yield_next() {
+  Block* b = tl_blk;
+  const int me = b->cur, n = b->nlanes;
+  int nx = me;
+  do {
+    nx = (nx + 1 == n) ? 0 : nx + 1;
+  } while (b->lanes[nx].done && nx != me);
+  if (nx != me) switch_to(me, nx);
+}
+
+inline void block_barrier() {
+  Block* b = tl_blk;
+  const unsigned g = b->blk_gen;
+  if (++b->blk_arrived >= b->alive) {
+    b->blk_arrived = 0;
+    b->blk_gen = g + 1;
+  } else {
+    while (b->blk_gen == g) yield_next();
+  }
+}
+
+inline void wave_barrier() {
+  Block* b = tl_blk;
+  const int w = b->cur >> 6;
+  const unsigned g = b->wave_gen[w];
+  if (++b->wave_arrived[w] >= b->wave_alive[w]) {
+    b->wave_arrived[w] = 0;
+    b->wave_gen[w] = g + 1;
+  } else {
+    while (b->wave_gen[w] == g) yield_next();
+  }
+}
+
+void run_grid(void (*invoke)(const void*), const void* arg, unsigned grid, unsigned block, size_t lds_bytes);
+
+}  // namespace hipemu
+
+// ---- the HIP surface the kernels use --------------------------------------------------------------
+#define threadIdx (hipemu::tl_blk->lanes[hipemu::tl_blk->cur].tid)
+#define blockIdx (hipemu::tl_blk->bid)
+#define blockDim (hipemu::tl_blk->bdim)
+#define gridDim (hipemu::tl_blk->gdim)
+
+#define MIGAN_DEVICE
+#define MIGAN_INLINE inline
+#define MIGAN_GLOBAL
+#define MIGAN_LAUNCH_BOUNDS(a, b)
+#define MIGAN_DYN_SMEM(name) float* name = hipemu::tl_blk->smem
+#define MIGAN_FMUL_RN(a, b) ((float)((a) * (b)))
+
+inline void __syncthreads() { hipemu::block_barrier(); }
+
+inline float __shfl_xor(float v, int mask) {
+  hipemu::Block* b = hipemu::tl_blk;
+  const int w = b->cur >> 6, l = b->cur & 63;
+  b->xa[w][l] = v;
+  hipemu::wave_barrier();
+  const float r = b->xa[w][l ^ mask];
+  hipemu::wave_barrier();
+  return r;
+}
+
+typedef float emu_f16v __attribute__((ext_vector_type(16)));
+inline emu_f16v hipemu_mfma_f32_32x32x2(float a, float bv, emu_f16v c) {
+  hipemu::Block* b = hipemu::tl_blk;
+  const int w = b->cur >> 6, l = b->cur & 63;
+  b->xa[w][l] = a;
+  b->xb[w][l] = bv;
+  hipemu::wave_barrier();
+  const int j = l & 31, hh = l >> 5;
+  for (int r = 0; r < 16; ++r) {
+    const int i = (r & 3) + 8 * (r >> 2) + 4 * hh;
+    c[r] = std::fmaf(b->xa[w][i + 32], b->xb[w][j + 32], std::fmaf(b->xa[w][i], b->xb[w][j], c[r]));
+  }
+  hipemu::wave_barrier();
+  return c;
+}
+#define MIGAN_MFMA_F32_32X32X2(a, b, c) hipemu_mfma_f32_32x32x2((a), (b), (c))
+
+// ---- the runtime surface the host code uses ----------------------------------------------------------
+namespace rt {
+typedef void* stream_t;
+struct event_t {
+  std::chrono::steady_clock::time_point t;
+  std::chrono::steady_clock::time_point* p = nullptr;
+};
+
+inline const char* backend_name() { return "emu:cpu-fibers (test only)"; }
+inline std::string error_string(int rc) { return "emulator error " + std::to_string(rc); }
+inline int set_device(int) { return 0; }
+inline int allow_dynamic_lds(const void*, size_t) { return 0; }
+
+template <class Args>
+struct Thunk {
+  void (*kernel)(const Args);
+  const Args* args;
+  static void call(const void* self) {
+    const Thunk* t = static_cast<const Thunk*>(self);
+    t->kernel(*t->args);
+  }
+};
+
+template <class Args>
+inline int launch(void (*kernel)(const Args), const Args& a, unsigned grid, unsigned block, size_t lds, stream_t) {
+  if (block != 256 || lds > 160 * 1024) return 1;
+  Thunk<Args> t{kernel, &a};
+  hipemu::run_grid(&Thunk<Args>::call, &t, grid, block, lds);
+  return 0;
+}
+inline int memcpy_d2h(void* dst, const void* src, size_t bytes, stream_t) {
+  std::memcpy(dst, src, bytes);
+  return 0;
+}
+inline int stream_sync(stream_t) { return 0; }
+inline int event_create(event_t* e) {
+  e->p = new std::chrono::steady_clock::time_point();
+  return 0;
+}
+inline int event_destroy(event_t e) {
+  delete e.p;
+  return 0;
+}
+inline int event_record(event_t e, stream_t) {
+  *e.p = std::chrono::steady_clock::now();
+  return 0;
+}
+inline int event_elapsed(float* ms, event_t a, event_t b) {
+  *ms = std::chrono::duration<float, std::milli>(*b.p - *a.p).count();
+  return 0;
+}
+}  // namespace rt

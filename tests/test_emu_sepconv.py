@@ -1,0 +1,144 @@
+"""Operator-level parity of the product kernel source (executed by the CPU fiber emulator,
+tests/emu) against the numpy oracle, through the C ABI entry migan_sepconv_forward.
+Covers every kernel mode, the small-resolution multi-image tiles, ragged batches, ragged UP
+tiles, noise, skip, fused fromrgb and fused ToRGB."""
+import numpy as np
+import pytest
+
+from oracle import migan_oracle as orc
+from tests.emu_util import aligned, emu_lib, nchw, nhwc, ptr
+
+
+@pytest.fixture(scope="module")
+def lib():
+    return emu_lib()
+
+
+def _weights(pkg, cin, cout, seed, res_out, noise):
+    s = pkg.synth
+    sd = {
+        "m.conv1.weight": (s.normal((cin, 1, 3, 3), seed, "w1") * 0.4).astype(np.float32),
+        "m.conv1.bias": (s.normal((cin,), seed, "b1") * 0.5).astype(np.float32),
+        "m.conv2.weight": (s.normal((cout, cin, 1, 1), seed, "w2") / np.sqrt(cin)).astype(np.float32),
+    }
+    if noise:
+        sd["m.noise_const"] = s.normal((res_out, res_out), seed, "nc").astype(np.float32)
+        sd["m.noise_strength"] = np.asarray(0.37, dtype=np.float32)
+    return sd
+
+
+def _run(lib, pkg, *, cin, cout, res_in, batch, down=1, up=1, noise=False, skip=False, seed=1):
+    res_out = res_in // 2 if down == 2 else (res_in * 2 if up == 2 else res_in)
+    sd = _weights(pkg, cin, cout, seed, res_out, noise)
+    osd = dict(sd)
+    if down == 2:
+        osd["m.downsample.filter.weight"] = np.broadcast_to(orc.fir_taps(1.0), (cin, 1, 4, 4)).astype(np.float32)
+    if up == 2:
+        osd["m.upsample.filter.weight"] = np.broadcast_to(orc.fir_taps(4.0), (cout, 1, 4, 4)).astype(np.float32)
+    x = (pkg.synth.normal((batch, cin, res_in, res_in), seed, "x") * 1.5).astype(np.float32)
+    want = orc.separable_conv(x.copy(), osd, "m")
+    sk = None
+    if skip:
+        sk = pkg.synth.normal((batch, cout, res_out, res_out), seed, "skip").astype(np.float32)
+        want = want + sk
+    xh = aligned(nhwc(x))
+    y = aligned(np.full((batch, res_out, res_out, cout), np.nan, dtype=np.float32))
+    skh = aligned(nhwc(sk)) if skip else None
+    w1, b1, w2 = aligned(sd["m.conv1.weight"]), aligned(sd["m.conv1.bias"]), aligned(sd["m.conv2.weight"])
+    nc = aligned(sd["m.noise_const"]) if noise else None
+    ns = aligned(sd["m.noise_strength"].reshape(1)) if noise else None
+    lib.sepconv_forward(x=ptr(xh), y=ptr(y), skip=ptr(skh), conv1_weight=ptr(w1), conv1_bias=ptr(b1),
+                        conv2_weight=ptr(w2), noise_const=ptr(nc), noise_strength=ptr(ns),
+                        batch=batch, cin=cin, cout=cout, res_in=res_in, down=down, up=up)
+    got = nchw(y)
+    assert np.isfinite(got).all(), "kernel left NaNs (unwritten output or read of unwritten LDS)"
+    tol = 2e-5 * max(1.0, float(np.abs(want).max()))
+    np.testing.assert_allclose(got, want, rtol=0, atol=tol)
+
+
+@pytest.mark.parametrize("cin,cout,res,batch,noise,skip", [
+    (64, 64, 16, 1, False, False),     # NT=64, one n-chunk, 2 tiles
+    (32, 128, 16, 2, True, True),      # NT=128, single K chunk
+    (64, 256, 32, 1, True, False),     # two n-chunks, 8 tiles (XCD remap over 16 workgroups)
+    (64, 64, 8, 3, False, True),       # 2 images per tile, ragged batch
+    (64, 128, 4, 3, True, False),      # 8 images per tile, ragged batch
+])
+def test_plain(lib, pkg, cin, cout, res, batch, noise, skip):
+    _run(lib, pkg, cin=cin, cout=cout, res_in=res, batch=batch, noise=noise, skip=skip)
+
+
+@pytest.mark.parametrize("cin,cout,res_in,batch", [
+    (32, 64, 32, 1),      # out 16: 4x16 tiles
+    (64, 128, 64, 1),     # out 32: 16 tiles, NT=128, 4 K chunks
+    (32, 64, 16, 2),      # out 8: 8x8 tile
+    (48 + 16, 128, 8, 5), # out 4: 4 images per tile, ragged batch
+])
+def test_down(lib, pkg, cin, cout, res_in, batch):
+    _run(lib, pkg, cin=cin, cout=cout, res_in=res_in, batch=batch, down=2)
+
+
+@pytest.mark.parametrize("cin,cout,res_in,batch,noise,skip", [
+    (64, 64, 16, 1, True, True),      # out 32: 3x2 ragged tiles
+    (32, 128, 32, 1, False, False),   # out 64: 6x3 tiles
+    (64, 64, 8, 2, True, False),      # out 16: 2x1 tiles
+    (32, 128, 4, 3, True, True),      # out 8: 2 images per tile, ragged batch
+])
+def test_up(lib, pkg, cin, cout, res_in, batch, noise, skip):
+    _run(lib, pkg, cin=cin, cout=cout, res_in=res_in, batch=batch, up=2, noise=noise, skip=skip)
+
+
+def test_fromrgb_fused(lib, pkg):
+    cin = cout = 64
+    res, batch = 16, 2
+    sd = _weights(pkg, cin, cout, 7, res, False)
+    fw = (pkg.synth.normal((cin, 4, 1, 1), 7, "fw") * 0.7).astype(np.float32)
+    fb = (pkg.synth.normal((cin,), 7, "fb") * 0.3).astype(np.float32)
+    img = pkg.synth.make_input(batch, res, seed=7)
+    h = orc.lrelu_agc(orc.pointwise(img, fw, fb))                     # reference :194-195
+    want = orc.separable_conv(h, sd, "m")
+    x = aligned(img)                                                   # NCHW network input
+    y = aligned(np.full((batch, res, res, cout), np.nan, dtype=np.float32))
+    arrs = [aligned(a) for a in (sd["m.conv1.weight"], sd["m.conv1.bias"], sd["m.conv2.weight"], fw, fb)]
+    lib.sepconv_forward(x=ptr(x), y=ptr(y), conv1_weight=ptr(arrs[0]), conv1_bias=ptr(arrs[1]), conv2_weight=ptr(arrs[2]),
+                        fromrgb_weight=ptr(arrs[3]), fromrgb_bias=ptr(arrs[4]),
+                        batch=batch, cin=cin, cout=cout, res_in=res)
+    np.testing.assert_allclose(nchw(y), want, rtol=0, atol=2e-5 * max(1.0, float(np.abs(want).max())))
+
+
+@pytest.mark.parametrize("with_prev,cout", [(False, 64), (True, 64), (True, 128)])
+def test_torgb_fused(lib, pkg, with_prev, cout):
+    cin = cout
+    res, batch = 16, 2
+    sd = _weights(pkg, cin, cout, 9, res, True)
+    tw = (pkg.synth.normal((3, cout, 1, 1), 9, "tw") / np.sqrt(cout)).astype(np.float32)
+    tb = (pkg.synth.normal((3,), 9, "tb") * 0.3).astype(np.float32)
+    x = (pkg.synth.normal((batch, cin, res, res), 9, "x")).astype(np.float32)
+    prev = pkg.synth.normal((batch, 3, res // 2, res // 2), 9, "prev").astype(np.float32) if with_prev else None
+    feat = orc.separable_conv(x.copy(), sd, "m")
+    want_img = orc.pointwise(feat, tw, tb)
+    if with_prev:
+        want_img = orc.upsample2d(prev) + want_img                    # reference :308-313
+    xh = aligned(nhwc(x))
+    y = aligned(np.full((batch, res, res, cout), np.nan, dtype=np.float32))
+    img_out = aligned(np.full((batch, 3, res, res), np.nan, dtype=np.float32))
+    arrs = [aligned(a) for a in (sd["m.conv1.weight"], sd["m.conv1.bias"], sd["m.conv2.weight"], sd["m.noise_const"],
+                                 sd["m.noise_strength"].reshape(1), tw, tb)]
+    pv = aligned(prev) if with_prev else None
+    lib.sepconv_forward(x=ptr(xh), y=ptr(y), conv1_weight=ptr(arrs[0]), conv1_bias=ptr(arrs[1]), conv2_weight=ptr(arrs[2]),
+                        noise_const=ptr(arrs[3]), noise_strength=ptr(arrs[4]), torgb_weight=ptr(arrs[5]), torgb_bias=ptr(arrs[6]),
+                        img_prev=ptr(pv), img_out=ptr(img_out), batch=batch, cin=cin, cout=cout, res_in=res)
+    np.testing.assert_allclose(nchw(y), feat, rtol=0, atol=2e-5 * max(1.0, float(np.abs(feat).max())))
+    np.testing.assert_allclose(img_out, want_img, rtol=0, atol=2e-5 * max(1.0, float(np.abs(want_img).max())))
+
+
+def test_bad_arguments_are_rejected(lib):
+    a = np.zeros(64, dtype=np.float32)
+    with pytest.raises(ValueError):
+        lib.sepconv_forward(x=ptr(a), y=ptr(a), conv1_weight=ptr(a), conv1_bias=ptr(a), conv2_weight=ptr(a),
+                            batch=1, cin=48, cout=64, res_in=16)          # cin not a multiple of 32
+    with pytest.raises(ValueError):
+        lib.sepconv_forward(x=ptr(a), y=ptr(a), conv1_weight=ptr(a), conv1_bias=ptr(a), conv2_weight=ptr(a),
+                            batch=1, cin=64, cout=64, res_in=12)          # not a power of two
+    with pytest.raises(ValueError):
+        lib.sepconv_forward(x=None, y=ptr(a), conv1_weight=ptr(a), conv1_bias=ptr(a), conv2_weight=ptr(a),
+                            batch=1, cin=64, cout=64, res_in=16)          # null tensor
