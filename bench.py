@@ -46,6 +46,8 @@ def parse():
     ap.add_argument("--batch", type=int, default=32, help="images per GPU per step")
     ap.add_argument("--cpu-images", type=int, default=4, help="sample size of the CPU baseline (0 = skip)")
     ap.add_argument("--no-gather", action="store_true", help="N>1: skip the output all-gather")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (0 = all logical cores)")
+    ap.add_argument("--dump-layers", type=str, default="", help="write per-launch hipEvent durations to this JSON file")
     return ap.parse_args()
 
 
@@ -162,6 +164,10 @@ def main():
                 if i >= 3:
                     rounds.append(ms)
         roof = roofline_from_launches(launches, rounds, B)
+        if args.dump_layers:
+            med = np.median(np.asarray(rounds), axis=0)
+            with open(args.dump_layers, "w") as f:
+                json.dump([dict(L, ms=float(t)) for L, t in zip(launches, med)], f, indent=1)
 
         # ---- CPU baseline + parity on the same inputs (rank 0, N = 1 protocol) ---------------------
         cpu = None
@@ -170,7 +176,7 @@ def main():
             from oracle import migan_torch_cpu as torc
             n = min(args.cpu_images, B)
             xs = x_np[:n]
-            torch.set_num_threads(os.cpu_count() or 1)
+            torch.set_num_threads(args.cpu_threads or (os.cpu_count() or 1))
             ref = torc.generator(xs, sd, R)                    # warm-up + parity reference
             times = []
             for _ in range(2):

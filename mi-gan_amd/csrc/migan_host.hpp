@@ -6,9 +6,11 @@
 // Synthesis :318-352, SeparableConv2d :106-170).
 #pragma once
 
+#include <algorithm>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <stdexcept>
 #include <string>
@@ -44,10 +46,11 @@ inline void rt_check(int rc, const char* what) {
 struct Geo {
   int mode = MODE_NORMAL, MT = 128, NT = 128, KC = 32;
   bool fromrgb = false;
+  int NI = 6, MINW = 2;            // prefetch items per thread, workgroups per CU the kernel is built for
   int lgGH = 3, lgGW = 4, lgIMGS = 0;
   int sy = 8, sx = 16, off = 0, lgRS = 1;
   int tiles_x = 1, tiles_y = 1, nchunks = 1;
-  int off_a = 0, off_b = 0, off_v = 0, off_rgb = 0;
+  int off_a = 0, off_b = 0, off_v = 0, off_rgb = 0, off_w = 0, b_stride = 0;
   size_t lds_bytes = 0;
   int npix_in = 0;
 };
@@ -59,7 +62,22 @@ inline int ilog2(int v) {
 }
 inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
-inline Geo choose_geo(int mode, int cin, int cout, int res_in, bool fromrgb) {
+// Tuning knobs read once from the environment (experiments only; defaults are the shipped choice).
+struct Tuning {
+  int nt64_wgs_per_cu = 3;     // MIGAN_NT64_WGS: workgroups per CU targeted by the 64-column kernels (2 or 3)
+  int force_single_b = 0;      // MIGAN_SINGLE_B=1: never double-buffer the 1x1 weight tile
+};
+inline Tuning& tuning() {
+  static Tuning t = [] {
+    Tuning v;
+    if (const char* e = std::getenv("MIGAN_NT64_WGS")) v.nt64_wgs_per_cu = (std::atoi(e) == 2) ? 2 : 3;
+    if (const char* e = std::getenv("MIGAN_SINGLE_B")) v.force_single_b = std::atoi(e) != 0;
+    return v;
+  }();
+  return t;
+}
+
+inline Geo choose_geo(int mode, int cin, int cout, int res_in, bool fromrgb, bool fused_rgb = true) {
   Geo g;
   g.mode = mode;
   g.fromrgb = fromrgb;
@@ -67,7 +85,6 @@ inline Geo choose_geo(int mode, int cin, int cout, int res_in, bool fromrgb) {
               "channel counts must be multiples of 32 (in) / 64 (out)");
   MIGAN_CHECK(res_in >= 4 && (res_in & (res_in - 1)) == 0, MIGAN_EINVAL, "resolution must be a power of two >= 4");
   g.NT = (cout % 128 == 0) ? 128 : 64;
-  g.nchunks = cout / g.NT;
   int GH, GW, IMGS;
   if (mode == MODE_NORMAL) {
     g.MT = 128; g.KC = 32;
@@ -81,8 +98,9 @@ inline Geo choose_geo(int mode, int cin, int cout, int res_in, bool fromrgb) {
     MIGAN_CHECK(!fromrgb, MIGAN_EINVAL, "fromrgb is only fused into plain layers");
     const int ro = res_in / 2;
     g.MT = 64; g.KC = 16;
+    if (cout % 256 == 0) g.NT = 256;             // fewer recomputations of the depthwise stage per pixel
     if (ro >= 16) { GH = 4; GW = 16; IMGS = 1; }
-    else if (ro == 8) { GH = 8; GW = 8; IMGS = 1; }
+    else if (ro == 8) { GH = 4; GW = 8; IMGS = 2; }
     else { GH = 4; GW = 4; IMGS = 4; }
     g.sy = GH; g.sx = GW; g.off = 0;
     g.tiles_y = ro / GH; g.tiles_x = ro / GW;
@@ -94,28 +112,40 @@ inline Geo choose_geo(int mode, int cin, int cout, int res_in, bool fromrgb) {
     g.sy = GH - 2; g.sx = GW - 2; g.off = 1;     // 1-pixel halo of GEMM outputs is recomputed per tile
     g.tiles_y = cdiv(res_in, g.sy); g.tiles_x = cdiv(res_in, g.sx);
   }
+  g.nchunks = cout / g.NT;
   g.lgGH = ilog2(GH); g.lgGW = ilog2(GW); g.lgIMGS = ilog2(IMGS);
   MIGAN_CHECK(IMGS * GH * GW == g.MT, MIGAN_EINVAL, "internal: tile geometry does not fill the GEMM tile");
   const int QC = g.KC / 4;
   int rs = 1;
   if (mode != MODE_DOWN) {
-    rs = kThreads / (IMGS * GW * QC);
-    if (rs < 1) rs = 1;
-    if (rs > GH) rs = GH;
+    rs = GH / 4;                                   // depthwise strips are 4 output rows tall
+    MIGAN_CHECK(rs >= 1 && IMGS * GW * QC * rs >= 1, MIGAN_EINVAL, "internal: strip geometry");
+  } else {
+    MIGAN_CHECK(GH == 4, MIGAN_EINVAL, "internal: DOWN tiles are 4 GEMM rows tall");
   }
   g.lgRS = ilog2(rs);
   const int IGH = (mode == MODE_DOWN) ? 2 * GH + 4 : GH + 2;
   const int IGW = (mode == MODE_DOWN) ? 2 * GW + 4 : GW + 2;
   g.npix_in = IMGS * IGH * IGW;
-  MIGAN_CHECK(g.npix_in * QC <= kInItemsMax * kThreads, MIGAN_EINVAL, "internal: input tile too large");
+  const int items = cdiv(g.npix_in * QC, kThreads);
+  if (mode == MODE_DOWN) g.NI = items <= 7 ? 7 : 9;
+  else g.NI = items <= 6 ? 6 : 9;
+  MIGAN_CHECK(items <= g.NI, MIGAN_EINVAL, "internal: input tile too large");
+  g.MINW = (g.NT == 64) ? tuning().nt64_wgs_per_cu : 2;
   const int AS = g.KC + 4, GS = g.NT + 4;
   int o = g.npix_in * g.KC;
   g.off_a = o; o += g.MT * AS;
-  g.off_b = o; o += g.NT * AS;
   g.off_v = o; if (mode == MODE_DOWN) o += IMGS * GH * (2 * GW + 2) * g.KC;
   g.off_rgb = o; if (fromrgb) o += g.npix_in * 4;
-  const int gs = g.MT * GS;
-  g.lds_bytes = (size_t)(o > gs ? o : gs) * sizeof(float);
+  g.off_w = o; o += g.KC * 10 + (fromrgb ? g.KC * 5 : 0);
+  g.off_b = o;
+  const int bsz = g.NT * AS;
+  int gs = g.MT * GS + (fused_rgb ? g.MT * 4 : 0);
+  const size_t limit = (size_t)(160 * 1024 / g.MINW);
+  const size_t dbl = (size_t)std::max(o + 2 * bsz, gs) * sizeof(float);
+  const size_t sgl = (size_t)std::max(o + bsz, gs) * sizeof(float);
+  if (dbl <= limit && !tuning().force_single_b) { g.b_stride = bsz; g.lds_bytes = dbl; }   // double-buffered 1x1 weights: 2 barriers per K chunk
+  else { g.b_stride = 0; g.lds_bytes = sgl; }
   MIGAN_CHECK(g.lds_bytes <= 160 * 1024, MIGAN_EINVAL, "internal: LDS tile exceeds 160 KiB");
   return g;
 }
@@ -125,27 +155,42 @@ typedef void (*SepKernelFn)(const SepArgs);
 struct KernelEntry {
   int mode, MT, NT, KC;
   bool fromrgb;
+  int NI, MINW;
   SepKernelFn fn;
   const char* name;
 };
 
+#define MIGAN_KERNEL(MODE, MT, NT, KC, RGB, NI, MINW)                                   \
+  {MODE, MT, NT, KC, RGB, NI, MINW, sepconv_kernel<MODE, MT, NT, KC, RGB, NI, MINW>,    \
+   "migan::sepconv_kernel<" #MODE ", " #MT ", " #NT ", " #KC ", " #RGB ", " #NI ", " #MINW ">"}
+
 inline const std::vector<KernelEntry>& kernel_table() {
   static const std::vector<KernelEntry> t = {
-      {MODE_NORMAL, 128, 128, 32, false, sepconv_kernel<MODE_NORMAL, 128, 128, 32, false>, "migan::sepconv_kernel<0, 128, 128, 32, false>"},
-      {MODE_NORMAL, 128, 64, 32, false, sepconv_kernel<MODE_NORMAL, 128, 64, 32, false>, "migan::sepconv_kernel<0, 128, 64, 32, false>"},
-      {MODE_NORMAL, 128, 128, 32, true, sepconv_kernel<MODE_NORMAL, 128, 128, 32, true>, "migan::sepconv_kernel<0, 128, 128, 32, true>"},
-      {MODE_NORMAL, 128, 64, 32, true, sepconv_kernel<MODE_NORMAL, 128, 64, 32, true>, "migan::sepconv_kernel<0, 128, 64, 32, true>"},
-      {MODE_DOWN, 64, 128, 16, false, sepconv_kernel<MODE_DOWN, 64, 128, 16, false>, "migan::sepconv_kernel<1, 64, 128, 16, false>"},
-      {MODE_DOWN, 64, 64, 16, false, sepconv_kernel<MODE_DOWN, 64, 64, 16, false>, "migan::sepconv_kernel<1, 64, 64, 16, false>"},
-      {MODE_UP, 128, 128, 32, false, sepconv_kernel<MODE_UP, 128, 128, 32, false>, "migan::sepconv_kernel<2, 128, 128, 32, false>"},
-      {MODE_UP, 128, 64, 32, false, sepconv_kernel<MODE_UP, 128, 64, 32, false>, "migan::sepconv_kernel<2, 128, 64, 32, false>"},
+      // plain layers (MODE 0)
+      MIGAN_KERNEL(0, 128, 128, 32, false, 6, 2), MIGAN_KERNEL(0, 128, 128, 32, false, 9, 2),
+      MIGAN_KERNEL(0, 128, 64, 32, false, 6, 3),  MIGAN_KERNEL(0, 128, 64, 32, false, 9, 3),
+      MIGAN_KERNEL(0, 128, 64, 32, false, 6, 2),  MIGAN_KERNEL(0, 128, 64, 32, false, 9, 2),
+      MIGAN_KERNEL(0, 128, 128, 32, true, 6, 2),  MIGAN_KERNEL(0, 128, 128, 32, true, 9, 2),
+      MIGAN_KERNEL(0, 128, 64, 32, true, 6, 3),   MIGAN_KERNEL(0, 128, 64, 32, true, 9, 3),
+      MIGAN_KERNEL(0, 128, 64, 32, true, 6, 2),   MIGAN_KERNEL(0, 128, 64, 32, true, 9, 2),
+      // FIR-down layers (MODE 1)
+      MIGAN_KERNEL(1, 64, 256, 16, false, 7, 2),  MIGAN_KERNEL(1, 64, 256, 16, false, 9, 2),
+      MIGAN_KERNEL(1, 64, 128, 16, false, 7, 2),  MIGAN_KERNEL(1, 64, 128, 16, false, 9, 2),
+      MIGAN_KERNEL(1, 64, 64, 16, false, 7, 3),   MIGAN_KERNEL(1, 64, 64, 16, false, 9, 3),
+      MIGAN_KERNEL(1, 64, 64, 16, false, 7, 2),   MIGAN_KERNEL(1, 64, 64, 16, false, 9, 2),
+      // FIR-up layers (MODE 2)
+      MIGAN_KERNEL(2, 128, 128, 32, false, 6, 2), MIGAN_KERNEL(2, 128, 128, 32, false, 9, 2),
+      MIGAN_KERNEL(2, 128, 64, 32, false, 6, 3),  MIGAN_KERNEL(2, 128, 64, 32, false, 9, 3),
+      MIGAN_KERNEL(2, 128, 64, 32, false, 6, 2),  MIGAN_KERNEL(2, 128, 64, 32, false, 9, 2),
   };
   return t;
 }
 
 inline const KernelEntry& pick_kernel(const Geo& g) {
   for (const auto& e : kernel_table())
-    if (e.mode == g.mode && e.MT == g.MT && e.NT == g.NT && e.KC == g.KC && e.fromrgb == g.fromrgb) return e;
+    if (e.mode == g.mode && e.MT == g.MT && e.NT == g.NT && e.KC == g.KC && e.fromrgb == g.fromrgb && e.NI == g.NI &&
+        e.MINW == g.MINW)
+      return e;
   throw Error(MIGAN_EINVAL, "internal: no kernel instantiation for this geometry");
 }
 
@@ -153,15 +198,35 @@ inline const KernelEntry& pick_kernel(const Geo& g) {
 inline void prepare_kernels() {
   static bool done = false;
   if (done) return;
-  for (const auto& e : kernel_table()) rt_check(rt::allow_dynamic_lds((const void*)e.fn, 80 * 1024), "hipFuncSetAttribute");
+  for (const auto& e : kernel_table()) rt_check(rt::allow_dynamic_lds((const void*)e.fn, 96 * 1024), "hipFuncSetAttribute");
   done = true;
 }
+
+#ifdef MIGAN_PHASE_PROF
+inline unsigned long long* prof_buffer() {
+  static unsigned long long* buf = nullptr;
+  if (!buf) rt_check(rt::prof_alloc(&buf, 16), "prof alloc");
+  return buf;
+}
+#else
+inline unsigned long long* prof_buffer() { return nullptr; }
+#endif
+
+#ifdef MIGAN_PHASE_PROF
+struct ProfRow { unsigned long long v[16]; };
+inline std::vector<ProfRow>& prof_layers() {
+  static std::vector<ProfRow> rows;
+  return rows;
+}
+#endif
 
 inline void fill_geo(SepArgs& a, const Geo& g) {
   a.lgGH = g.lgGH; a.lgGW = g.lgGW; a.lgIMGS = g.lgIMGS;
   a.tiles_x = g.tiles_x; a.tiles_y = g.tiles_y; a.nchunks = g.nchunks;
   a.sy = g.sy; a.sx = g.sx; a.off = g.off; a.lgRS = g.lgRS;
-  a.off_a = g.off_a; a.off_b = g.off_b; a.off_v = g.off_v; a.off_rgb = g.off_rgb;
+  a.off_a = g.off_a; a.off_b = g.off_b; a.off_v = g.off_v; a.off_rgb = g.off_rgb; a.off_w = g.off_w;
+  a.b_stride = g.b_stride;
+  a.prof = prof_buffer();
 }
 
 inline unsigned grid_of(const Geo& g, int batch) {
@@ -487,6 +552,12 @@ inline void migan_handle::forward(const float* x, float* y, int batch, void* ws,
       launch_sepconv(L.g, a, stream);
     }
     if (timed) rt_check(rt::event_record(events[2 * li + 1], stream), "hipEventRecord");
+#ifdef MIGAN_PHASE_PROF
+    if (timed) {
+      prof_layers().resize(launches.size());
+      rt_check(rt::prof_read(prof_buffer(), prof_layers()[li].v, 16, true), "prof read");
+    }
+#endif
   }
   if (timed) {
     rt_check(rt::stream_sync(stream), "hipStreamSynchronize");
@@ -713,6 +784,22 @@ int migan_sepconv_forward(const migan_sepconv_desc* d, void* stream) {
   launch_sepconv(g, a, (rt::stream_t)stream);
   MIGAN_API_END
 }
+
+#ifdef MIGAN_PHASE_PROF
+// debug builds only: cumulative cycles of thread 0 per phase [prologue, S1, S2, MFMA, acc->LDS, epilogue, -, -, #workgroups]
+int migan_prof_read(unsigned long long out[16], int reset) {
+  MIGAN_API_BEGIN
+  migan::rt_check(rt::prof_read(migan::prof_buffer(), out, 16, reset != 0), "prof read");
+  MIGAN_API_END
+}
+// phase counters of launch `index` of the last migan_forward_timed
+int migan_prof_layer(int index, unsigned long long out[16]) {
+  MIGAN_API_BEGIN
+  MIGAN_CHECK(index >= 0 && index < (int)migan::prof_layers().size(), MIGAN_EINVAL, "no such launch");
+  for (int i = 0; i < 16; ++i) out[i] = migan::prof_layers()[index].v[i];
+  MIGAN_API_END
+}
+#endif
 
 const char* migan_last_error(void) { return migan::last_error_ref().c_str(); }
 const char* migan_backend(void) { return rt::backend_name(); }

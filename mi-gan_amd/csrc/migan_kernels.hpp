@@ -2,8 +2,8 @@
 //
 // One fused kernel per SeparableConv2d (reference lib/model_zoo/migan_inference.py:154-170):
 //
-//   HBM (NHWC fp32) --coalesced float4--> LDS input tile (+halo, zero padded)
-//     -> depthwise 3x3 + bias            (VALU, LDS-resident, column strips with rotating accumulators)
+//   HBM (NHWC fp32) --coalesced float4, register-prefetched one K chunk ahead--> LDS input tile
+//     -> depthwise 3x3 + bias            (VALU on LDS data; column strips with rotating accumulators)
 //     -> lrelu*sqrt2, clamp              (reference :20-28)
 //     -> [4x4 FIR, stride 2]             (reference Downsample2d :58-76; separable, vertical pass fused in the strip)
 //     -> 1x1 conv as an fp32 MFMA GEMM   (v_mfma_f32_32x32x2_f32, exact f32; M = tile pixels, K = Cin chunk, N = Cout tile)
@@ -12,7 +12,13 @@
 //     -> [+ noise_const*noise_strength]  (reference :165-167)
 //     -> lrelu*sqrt2, clamp -> [+ skip]  (reference :272 / :305)
 //     -> [ToRGB 1x1 + bias + upsampled previous image, wave-shuffle channel reduction] (reference :308-313)
-//     -> HBM (NHWC fp32), float4 stores, 256..512 B contiguous per pixel
+//     -> HBM (NHWC fp32), float4 stores, 256..1024 B contiguous per pixel
+//
+// K loop software pipeline (per workgroup, 4 wave64):
+//     regs <- global(chunk c+1)   issued right after the barrier that publishes chunk c, so HBM/L2
+//                                 latency runs under the depthwise stage and the MFMAs of chunk c
+//     LDS  <- regs(chunk c)       input tile, 1x1 weight tile (double buffered when it fits: 2 barriers
+//                                 per chunk instead of 3), depthwise weights
 //
 // Everything in the encoder/decoder runs through `sepconv_kernel`; `torgb_kernel` is the un-fused
 // ToRGB for layers whose Cout is split over several workgroups.
@@ -29,7 +35,6 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 typedef float f16v __attribute__((ext_vector_type(16)));
 
 constexpr int kThreads = 256;          // 4 wave64 per workgroup, one per SIMD
-constexpr int kInItemsMax = 9;         // float4 input-tile items per thread per K chunk (host checks)
 
 enum : int { MODE_NORMAL = 0, MODE_DOWN = 1, MODE_UP = 2 };
 
@@ -52,13 +57,15 @@ struct SepArgs {
   const float* trgb_b;         // [3]
   const float* img_prev;       // planar [B][3][HO/2][WO/2] or null
   float* img_out;              // planar [B][3][HO][WO]
+  unsigned long long* prof;    // phase-cycle accumulators (MIGAN_PHASE_PROF builds only), else null
   int B, H, W, CI, CO, HO, WO;
   // GEMM pixel grid of one workgroup: IMGS images x GH x GW (all powers of two), MT = IMGS*GH*GW rows
   int lgGH, lgGW, lgIMGS;
   int tiles_x, tiles_y, nchunks;   // workgroup grid: tiles_x * tiles_y * ceil(B/IMGS) * nchunks
   int sy, sx, off;                 // tile pitch in GEMM-resolution pixels; off = 1 for MODE_UP (recomputed halo)
   int lgRS;                        // log2(row segments per column) of the depthwise stage (NORMAL/UP)
-  int off_a, off_b, off_v, off_rgb;// LDS carve, in floats
+  int off_a, off_b, off_v, off_rgb, off_w;   // LDS carve, in floats
+  int b_stride;                    // floats between the two 1x1-weight buffers (0 = single buffered)
 };
 
 struct RgbArgs {
@@ -74,11 +81,12 @@ struct RgbArgs {
 // small device helpers
 
 // lrelu_agc(alpha=0.2, gain=sqrt(2), clamp=256), reference :20-28: leaky_relu, fp32 multiply by
-// float(np.sqrt(2)), clamp.  Same operation order as the reference so results round identically.
+// float(np.sqrt(2)), clamp.  max(v, 0.2v) == (v > 0 ? v : 0.2v) for every finite v; the two
+// multiplies stay separate so results round exactly like the reference's three passes.
 MIGAN_DEVICE MIGAN_INLINE float act1(float v) {
-  float t = v > 0.0f ? v : v * 0.2f;
+  float t = fmaxf(v, v * 0.2f);
   t = t * 1.41421356237309515f;
-  return fminf(fmaxf(t, -256.0f), 256.0f);
+  return MIGAN_CLAMP(t, -256.0f, 256.0f);
 }
 MIGAN_DEVICE MIGAN_INLINE f4 act4(f4 v) { return f4{act1(v.x), act1(v.y), act1(v.z), act1(v.w)}; }
 
@@ -94,42 +102,47 @@ MIGAN_DEVICE MIGAN_INLINE int xcd_remap(int bid, int nblk) {
   return base + idx;
 }
 
-// 2x polyphase FIR weights of Upsample2d per axis (reference :95-103, taps [1,3,3,1]/4 on a
-// zero-inserted signal): out[2i] = g[i-1]/4 + 3g[i]/4 ; out[2i+1] = 3g[i]/4 + g[i+1]/4.
+// 2x polyphase FIR of Upsample2d at one output pixel of a planar image (reference :95-103, taps
+// [1,3,3,1]/4 per axis on a zero-inserted signal): out[2i] = g[i-1]/4 + 3g[i]/4,
+// out[2i+1] = 3g[i]/4 + g[i+1]/4, zeros outside.
 MIGAN_DEVICE MIGAN_INLINE float up_prev3(const float* plane, int hp, int wp, int oy, int ox) {
   const int iy = oy >> 1, ix = ox >> 1;
   const int y0 = (oy & 1) ? iy : iy - 1, x0 = (ox & 1) ? ix : ix - 1;   // first of the two taps
   const float wy0 = (oy & 1) ? 0.75f : 0.25f, wx0 = (ox & 1) ? 0.75f : 0.25f;
-  float acc = 0.0f;
-#pragma unroll
-  for (int a = 0; a < 2; ++a) {
-    const int yy = y0 + a;
-    const float wy = a == 0 ? wy0 : 1.0f - wy0;
-    if (yy < 0 || yy >= hp) continue;
-    float row = 0.0f;
-#pragma unroll
-    for (int c = 0; c < 2; ++c) {
-      const int xx = x0 + c;
-      const float wx = c == 0 ? wx0 : 1.0f - wx0;
-      if (xx >= 0 && xx < wp) row += wx * plane[(size_t)yy * wp + xx];
-    }
-    acc += wy * row;
-  }
-  return acc;
+  const int y1 = y0 + 1, x1 = x0 + 1;
+  const bool vy0 = y0 >= 0, vy1 = y1 < hp, vx0 = x0 >= 0, vx1 = x1 < wp;
+  const int cy0 = vy0 ? y0 : 0, cy1 = vy1 ? y1 : hp - 1, cx0 = vx0 ? x0 : 0, cx1 = vx1 ? x1 : wp - 1;
+  const float p00 = plane[(size_t)cy0 * wp + cx0], p01 = plane[(size_t)cy0 * wp + cx1];
+  const float p10 = plane[(size_t)cy1 * wp + cx0], p11 = plane[(size_t)cy1 * wp + cx1];
+  const float r0 = (vx0 ? wx0 * p00 : 0.0f) + (vx1 ? (1.0f - wx0) * p01 : 0.0f);
+  const float r1 = (vx0 ? wx0 * p10 : 0.0f) + (vx1 ? (1.0f - wx0) * p11 : 0.0f);
+  return (vy0 ? wy0 * r0 : 0.0f) + (vy1 ? (1.0f - wy0) * r1 : 0.0f);
 }
+
+#ifdef MIGAN_PHASE_PROF
+#define PROF_BEGIN() long long prof_t = (long long)MIGAN_CLOCK(); long long prof_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define PROF_MARK(i) do { const long long n_ = (long long)MIGAN_CLOCK(); prof_acc[i] += n_ - prof_t; prof_t = n_; } while (0)
+#define PROF_END() do { if (p.prof && tid == 0) { for (int i_ = 0; i_ < 8; ++i_) MIGAN_ATOMIC_ADD_U64(p.prof + i_, (unsigned long long)prof_acc[i_]); MIGAN_ATOMIC_ADD_U64(p.prof + 8, 1ull); } } while (0)
+#else
+#define PROF_BEGIN() do {} while (0)
+#define PROF_MARK(i) do {} while (0)
+#define PROF_END() do {} while (0)
+#endif
 
 // ------------------------------------------------------------------------------------------------
 // fused SeparableConv2d
 //
 //   MODE   : NORMAL (down=1, up=1) | DOWN (FIR stride 2 before the 1x1) | UP (FIR x2 after the 1x1)
 //   MT     : GEMM rows (pixels) per workgroup, 128 or 64
-//   NT     : GEMM columns (output channels) per workgroup, 128 or 64
+//   NT     : GEMM columns (output channels) per workgroup, 64 / 128 / 256
 //   KC     : input-channel chunk staged per K step, 32 or 16
 //   FROMRGB: input tile is act(fromrgb(network input)) computed on the fly (encoder first block)
+//   NI     : float4 input-tile items per thread per K chunk (prefetch registers)
+//   MINW   : launch bound, minimum waves per SIMD (= workgroups per CU)
 //
 // Waves are laid out 2x2 over the MT x NT tile; each wave owns (MT/2)x(NT/2) as 32x32 MFMA tiles.
-template <int MODE, int MT, int NT, int KC, bool FROMRGB>
-MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, 2) sepconv_kernel(const SepArgs p) {
+template <int MODE, int MT, int NT, int KC, bool FROMRGB, int NI, int MINW>
+MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, MINW) sepconv_kernel(const SepArgs p) {
   MIGAN_DYN_SMEM(smem);
 
   constexpr int QC = KC / 4;                       // float4 groups per pixel in a K chunk
@@ -138,16 +151,31 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, 2) sepconv_kernel(const SepArgs p) {
   constexpr int AS = KC + 4;                       // A/B row pitch (floats): odd number of 16-B slots -> conflict-free b128
   constexpr int GS = NT + 4;                       // result tile row pitch
   constexpr int QN = NT / 4;
-  constexpr int LG_QN = (QN == 32) ? 5 : 4;
-  static_assert(QN == 32 || QN == 16, "NT must be 128 or 64");
+  constexpr int LG_QN = (QN == 64) ? 6 : ((QN == 32) ? 5 : 4);
+  static_assert(QN == 64 || QN == 32 || QN == 16, "NT must be 256, 128 or 64");
   constexpr int WROWS = MT / 2, WCOLS = NT / 2;    // per-wave tile
   constexpr int MTI = WROWS / 32, NTI = WCOLS / 32;
   static_assert(MTI >= 1 && NTI >= 1, "wave tile must be at least 32x32");
+  constexpr int NB = NT * QC / kThreads;           // float4 items of the 1x1 weight tile per thread
+  static_assert(NB >= 1 && NB * kThreads == NT * QC, "weight tile must split evenly over the threads");
+  constexpr int NW4 = KC * 10 / 4;                 // float4s of depthwise weights (9 taps) + bias per chunk
+  constexpr int NF4 = FROMRGB ? KC * 5 / 4 : 0;    // float4s of fromrgb weights (4 per channel) + bias
+  constexpr int SEGH = 4;                          // output rows per depthwise strip (NORMAL / UP)
+  constexpr int DGH = 4;                           // GEMM-grid rows of a DOWN tile
+
+  const float* __restrict__ gx_ = p.x;
+  float* __restrict__ gy_ = p.y;
+  const float* __restrict__ gskip = p.skip;
+  const float* __restrict__ gwdw = p.wdw;
+  const float* __restrict__ gbdw = p.bdw;
+  const float* __restrict__ gwpw = p.wpw;
+  const float* __restrict__ gnoise = p.noise;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int l31 = lane & 31, half = lane >> 5;
+  PROF_BEGIN();
 
   const int GH = 1 << p.lgGH, GW = 1 << p.lgGW, IMGS = 1 << p.lgIMGS;
 
@@ -164,10 +192,12 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, 2) sepconv_kernel(const SepArgs p) {
   // ---- LDS carve --------------------------------------------------------------------------
   float* in_s = smem;                       // [npix_in][KC]
   float* a_s = smem + p.off_a;              // [MT][AS]
-  float* b_s = smem + p.off_b;              // [NT][AS]
+  float* b_s = smem + p.off_b;              // [NT][AS] x (1 or 2 buffers)
   float* v_s = smem + p.off_v;              // DOWN: [IMGS][GH][2GW+2][KC]
   float* rgb_s = smem + p.off_rgb;          // FROMRGB: [npix_in][4]
+  float* w_s = smem + p.off_w;              // [KC*9] depthwise taps, [KC] bias, (FROMRGB: [KC*4] + [KC])
   float* g_s = smem;                        // after the K loop: [MT][GS], aliases the buffers above
+  float* racc_s = smem + MT * GS;           // fused ToRGB partial sums [MT][4]
 
   // input-tile geometry (input-resolution coordinates)
   const int IGH = (MODE == MODE_DOWN) ? 2 * GH + 4 : GH + 2;
@@ -177,29 +207,39 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, 2) sepconv_kernel(const SepArgs p) {
   const int npix_in = IMGS * IGH * IGW;
   const int nitems_in = npix_in * QC;
 
-  // per-thread global offsets of its input items (constant across K chunks):
-  //   >= 0 : element offset of the float4 inside image group b0 (before adding the chunk's k0)
-  //   -1   : outside the image / batch -> zero fill (conv zero padding, reference :126)
-  //   -2   : no such item
-  int goff[kInItemsMax];
+  // per-thread descriptors of its input items (constant across K chunks).  Item i = tid + j*256 is
+  // float4 number i of the LDS tile ([pixel][KC/4]); goff = element offset of its source inside
+  // image group b0 (0 when the pixel is padding: loaded anyway, zeroed on the way to LDS, which is
+  // the conv zero padding of reference :126); bit j of `vmask` = real pixel, of `emask` = item exists.
+  int goff[NI];
+  unsigned vmask = 0, emask = 0;
 #pragma unroll
-  for (int j = 0; j < kInItemsMax; ++j) {
+  for (int j = 0; j < NI; ++j) {
     const int i = tid + j * kThreads;
-    int g = -2;
+    int g = 0;
     if (i < nitems_in) {
+      emask |= 1u << j;
       const int c4 = i & (QC - 1);
       const int pix = i >> LG_QC;
       const int ix = pix % IGW;
       const int r = pix / IGW;
       const int iy = r % IGH, img = r / IGH;
       const int yy = iy0 + iy, xx = ix0 + ix;
-      g = -1;
-      if (yy >= 0 && yy < p.H && xx >= 0 && xx < p.W && (b0 + img) < p.B)
+      if (yy >= 0 && yy < p.H && xx >= 0 && xx < p.W && (b0 + img) < p.B) {
+        vmask |= 1u << j;
         g = FROMRGB ? 0 : ((img * p.H + yy) * p.W + xx) * p.CI + c4 * 4;
+      }
     }
     goff[j] = g;
   }
-  const float* xb = p.x + (size_t)b0 * p.H * p.W * (FROMRGB ? 4 : p.CI);
+  const float* __restrict__ xb = gx_ + (size_t)b0 * p.H * p.W * (FROMRGB ? 4 : p.CI);
+  // 1x1 weight tile items: n = i / QC rows of conv2.weight, 4 consecutive input channels
+  int boff[NB];
+#pragma unroll
+  for (int j = 0; j < NB; ++j) {
+    const int i = tid + j * kThreads;
+    boff[j] = (n0 + (i >> LG_QC)) * p.CI + (i & (QC - 1)) * 4;
+  }
 
   if constexpr (FROMRGB) {
     // raw 4-channel network input (NCHW) of the halo tile, loaded once
@@ -226,44 +266,79 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, 2) sepconv_kernel(const SepArgs p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
+  // prefetch registers: one K chunk of the input tile, of the 1x1 weights and of the small weights
+  f4 rin[NI], rb[NB], rw;
+  auto issue_loads = [&](int k0) {
+    if constexpr (!FROMRGB) {
+#pragma unroll
+      for (int j = 0; j < NI; ++j) rin[j] = ld4(xb + goff[j] + k0);
+    }
+#pragma unroll
+    for (int j = 0; j < NB; ++j) rb[j] = ld4(gwpw + boff[j] + k0);
+    // depthwise taps of channels [k0,k0+KC) are KC*9 contiguous floats of conv1.weight, then the bias
+    const float* src = gwdw + (size_t)k0 * 9 + tid * 4;
+    if (tid >= KC * 9 / 4) src = gbdw + k0 + (tid - KC * 9 / 4) * 4;
+    if constexpr (FROMRGB) {
+      if (tid >= NW4) src = p.frgb_w + (size_t)k0 * 4 + (tid - NW4) * 4;
+      if (tid >= NW4 + KC) src = p.frgb_b + k0 + (tid - NW4 - KC) * 4;
+    }
+    if (tid < NW4 + NF4) rw = ld4(src);
+  };
+
+  PROF_MARK(0);
   // ======================================= K loop ==========================================
   const int nkc = p.CI / KC;
+  issue_loads(0);
+  if constexpr (FROMRGB) __syncthreads();           // rgb_s visible to the tile builder below
   for (int c = 0; c < nkc; ++c) {
     const int k0 = c * KC;
-    __syncthreads();   // previous chunk's MFMA reads of a_s/b_s (and rgb_s writes) are complete
+    float* bcur = b_s + (c & 1) * p.b_stride;
+    if (p.b_stride == 0) __syncthreads();           // single weight buffer: wait for the MFMAs of chunk c-1
 
-    // ---- S1: input tile chunk -> LDS, pointwise-weight chunk -> LDS ------------------------
+    // ---- S1: prefetched chunk -> LDS -----------------------------------------------------------
+    if (tid < NW4 + NF4) st4(w_s + tid * 4, rw);
 #pragma unroll
-    for (int j = 0; j < kInItemsMax; ++j) {
-      if (goff[j] != -2) {
-        const int i = tid + j * kThreads;
-        const int c4 = i & (QC - 1);
-        const int pix = i >> LG_QC;
-        f4 v = {0.f, 0.f, 0.f, 0.f};
-        if (goff[j] >= 0) {
-          if constexpr (FROMRGB) {
-            // x = act(fromrgb(img)) (reference :194-195), 4 -> CI pointwise with bias
+    for (int j = 0; j < NB; ++j) {
+      const int i = tid + j * kThreads;
+      st4(bcur + (i >> LG_QC) * AS + (i & (QC - 1)) * 4, rb[j]);
+    }
+    if constexpr (FROMRGB) {
+      __syncthreads();                              // w_s (fromrgb weights of this chunk) visible
+      // x = act(fromrgb(img)) (reference :194-195), 4 -> CI pointwise with bias, per halo pixel
+#pragma unroll
+      for (int j = 0; j < NI; ++j) {
+        if (emask & (1u << j)) {
+          const int i = tid + j * kThreads;
+          const int c4 = i & (QC - 1);
+          const int pix = i >> LG_QC;
+          f4 v = {0.f, 0.f, 0.f, 0.f};
+          if (vmask & (1u << j)) {
             const f4 raw = ld4(rgb_s + pix * 4);
-            const float* wr = p.frgb_w + (size_t)(k0 + c4 * 4) * 4;
+            const float* wr = w_s + KC * 10 + c4 * 16;
             const f4 w0 = ld4(wr), w1 = ld4(wr + 4), w2 = ld4(wr + 8), w3 = ld4(wr + 12);
-            const f4 bb = ld4(p.frgb_b + k0 + c4 * 4);
+            const f4 bb = ld4(w_s + KC * 14 + c4 * 4);
             v.x = bb.x + (w0.x * raw.x + w0.y * raw.y + w0.z * raw.z + w0.w * raw.w);
             v.y = bb.y + (w1.x * raw.x + w1.y * raw.y + w1.z * raw.z + w1.w * raw.w);
             v.z = bb.z + (w2.x * raw.x + w2.y * raw.y + w2.z * raw.z + w2.w * raw.w);
             v.w = bb.w + (w3.x * raw.x + w3.y * raw.y + w3.z * raw.z + w3.w * raw.w);
             v = act4(v);
-          } else {
-            v = ld4(xb + goff[j] + k0);
           }
+          st4(in_s + i * 4, v);
         }
-        st4(in_s + pix * KC + c4 * 4, v);
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < NI; ++j) {
+        if (emask & (1u << j)) {
+          f4 v = rin[j];
+          if (!(vmask & (1u << j))) v = f4{0.f, 0.f, 0.f, 0.f};
+          st4(in_s + (tid + j * kThreads) * 4, v);
+        }
       }
     }
-    for (int i = tid; i < NT * QC; i += kThreads) {
-      const int c4 = i & (QC - 1), n = i >> LG_QC;
-      st4(b_s + n * AS + c4 * 4, ld4(p.wpw + (size_t)(n0 + n) * p.CI + k0 + c4 * 4));
-    }
     __syncthreads();
+    PROF_MARK(1);
+    if (c + 1 < nkc) issue_loads(k0 + KC);          // in flight during the depthwise stage and the MFMAs
 
     // ---- S2: depthwise 3x3 + bias + act (+ FIR down) -> A operand in LDS --------------------
     // One thread walks a column of the tile for 4 channels.  Every input row it reads (3 float4
@@ -271,7 +346,6 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, 2) sepconv_kernel(const SepArgs p) {
     // tap row of), so each LDS value is read once per column and no register window is kept.
     if constexpr (MODE != MODE_DOWN) {
       const int RS = 1 << p.lgRS;
-      const int SEGH = GH >> p.lgRS;
       const int ncols = (IMGS * GW * QC) << p.lgRS;
       for (int it = tid; it < ncols; it += kThreads) {
         const int c4 = it & (QC - 1);
@@ -280,33 +354,28 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, 2) sepconv_kernel(const SepArgs p) {
         const int seg = r & (RS - 1);
         const int img = r >> p.lgRS;
         const int r0 = seg * SEGH;
-        // 4 channels x 9 taps are 36 contiguous floats in conv1.weight [C][1][3][3]
+        // 4 channels x 9 taps are 36 contiguous floats of conv1.weight [C][1][3][3]
         float wf[36];
-        {
-          const float* wp = p.wdw + (size_t)(k0 + c4 * 4) * 9;
 #pragma unroll
-          for (int q = 0; q < 9; ++q) {
-            const f4 tq = ld4(wp + 4 * q);
-            wf[4 * q + 0] = tq.x; wf[4 * q + 1] = tq.y; wf[4 * q + 2] = tq.z; wf[4 * q + 3] = tq.w;
-          }
+        for (int q = 0; q < 9; ++q) {
+          const f4 tq = ld4(w_s + c4 * 36 + 4 * q);
+          wf[4 * q + 0] = tq.x; wf[4 * q + 1] = tq.y; wf[4 * q + 2] = tq.z; wf[4 * q + 3] = tq.w;
         }
         f4 w[9];
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) w[tap] = f4{wf[tap], wf[9 + tap], wf[18 + tap], wf[27 + tap]};
-        const f4 bias = ld4(p.bdw + k0 + c4 * 4);
+        const f4 bias = ld4(w_s + KC * 9 + c4 * 4);
         f4 s2 = bias, s1 = bias, s0 = bias;   // outputs (row-2, row-1, row) of the current input row
         const float* ip = in_s + ((img * IGH + r0) * IGW + gx) * KC + c4 * 4;
+        const int mbase = (img << (p.lgGH + p.lgGW)) + (r0 << p.lgGW) + gx;
+#pragma unroll 2
         for (int rr = 0; rr < SEGH + 2; ++rr) {
           const f4 L = ld4(ip), M = ld4(ip + KC), R = ld4(ip + 2 * KC);
           ip += IGW * KC;
           s2 += w[6] * L + w[7] * M + w[8] * R;
           s1 += w[3] * L + w[4] * M + w[5] * R;
           s0 += w[0] * L + w[1] * M + w[2] * R;
-          if (rr >= 2) {
-            const int g = r0 + rr - 2;
-            const int m = (img << (p.lgGH + p.lgGW)) + (g << p.lgGW) + gx;
-            st4(a_s + m * AS + c4 * 4, act4(s2));
-          }
+          if (rr >= 2) st4(a_s + (mbase + ((rr - 2) << p.lgGW)) * AS + c4 * 4, act4(s2));
           s2 = s1; s1 = s0; s0 = bias;
         }
       }
@@ -323,23 +392,21 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, 2) sepconv_kernel(const SepArgs p) {
         const int xim = 2 * gx0 - 1 + dx;
         const bool colin = xim >= 0 && xim < p.W;
         float wf[36];
-        {
-          const float* wp = p.wdw + (size_t)(k0 + c4 * 4) * 9;
 #pragma unroll
-          for (int q = 0; q < 9; ++q) {
-            const f4 tq = ld4(wp + 4 * q);
-            wf[4 * q + 0] = tq.x; wf[4 * q + 1] = tq.y; wf[4 * q + 2] = tq.z; wf[4 * q + 3] = tq.w;
-          }
+        for (int q = 0; q < 9; ++q) {
+          const f4 tq = ld4(w_s + c4 * 36 + 4 * q);
+          wf[4 * q + 0] = tq.x; wf[4 * q + 1] = tq.y; wf[4 * q + 2] = tq.z; wf[4 * q + 3] = tq.w;
         }
         f4 w[9];
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) w[tap] = f4{wf[tap], wf[9 + tap], wf[18 + tap], wf[27 + tap]};
-        const f4 bias = ld4(p.bdw + k0 + c4 * 4);
+        const f4 bias = ld4(w_s + KC * 9 + c4 * 4);
         f4 s2 = bias, s1 = bias, s0 = bias;
         f4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = {0.f, 0.f, 0.f, 0.f};
         const float* ip = in_s + ((img * IGH) * IGW + dx) * KC + c4 * 4;
         const int yim0 = 2 * gy0 - 1;
-        for (int I = 0; I < 2 * GH + 4; ++I) {
+#pragma unroll 2
+        for (int I = 0; I < 2 * DGH + 4; ++I) {
           const f4 L = ld4(ip), M = ld4(ip + KC), R = ld4(ip + 2 * KC);
           ip += IGW * KC;
           s2 += w[6] * L + w[7] * M + w[8] * R;
@@ -376,6 +443,7 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, 2) sepconv_kernel(const SepArgs p) {
       }
     }
     __syncthreads();
+    PROF_MARK(2);
 
     // ---- S3: acc += A[MT x KC] * W^T[KC x NT] on the matrix cores ---------------------------
     // v_mfma_f32_32x32x2_f32: lane l supplies A[i=l&31][k=l>>5] and B[k=l>>5][j=l&31].  Each lane
@@ -383,7 +451,7 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, 2) sepconv_kernel(const SepArgs p) {
     // same for A and B, so any assignment of k to (half,t) sums the full K.
     {
       const float* ap = a_s + (wm * WROWS + l31) * AS + 4 * half;
-      const float* bp = b_s + (wn * WCOLS + l31) * AS + 4 * half;
+      const float* bp = bcur + (wn * WCOLS + l31) * AS + 4 * half;
 #pragma unroll
       for (int kk = 0; kk < KC / 8; ++kk) {
         f4 av[MTI], bv[NTI];
@@ -400,6 +468,7 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, 2) sepconv_kernel(const SepArgs p) {
               acc[i][j] = MIGAN_MFMA_F32_32X32X2(av[i][tt], bv[j][tt], acc[i][j]);
       }
     }
+    PROF_MARK(3);
   }
 
   // ======================================= epilogue ========================================
@@ -426,49 +495,80 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, 2) sepconv_kernel(const SepArgs p) {
         g_s[row * GS + col] = v;
       }
   __syncthreads();
+  PROF_MARK(4);
 
-  const bool has_noise = p.noise != nullptr;
+  const bool has_noise = gnoise != nullptr;
   const float ns = has_noise ? p.noise_strength[0] : 0.0f;
+  constexpr int ITEMS = MT * QN / kThreads;          // epilogue items per thread
+  constexpr int UB = 4;                              // items whose global loads are issued together
+  static_assert(ITEMS % UB == 0, "epilogue batches must divide the per-thread items");
 
   if constexpr (MODE != MODE_UP) {
     const bool do_rgb = p.trgb_w != nullptr;
-    for (int it = tid; it < MT * QN; it += kThreads) {
-      const int c4 = it & (QN - 1);
-      const int m = it >> LG_QN;
-      const int gx = m & (GW - 1);
-      const int gy = (m >> p.lgGW) & (GH - 1);
-      const int img = m >> (p.lgGW + p.lgGH);
-      const int oy = gy0 + gy, ox = gx0 + gx, b = b0 + img;
-      const bool ok = b < p.B;
-      f4 v = ld4(g_s + m * GS + c4 * 4);
-      if (has_noise) {
-        const float nz = MIGAN_FMUL_RN(p.noise[(size_t)oy * p.WO + ox], ns);   // product rounded first, reference :166
-        v += nz;
-      }
-      v = act4(v);
-      const size_t o = (((size_t)b * p.HO + oy) * p.WO + ox) * p.CO + n0 + c4 * 4;
-      if (ok) {
-        f4 out = v;
-        if (p.skip) out += ld4(p.skip + o);
-        st4(p.y + o, out);
-      }
-      if (do_rgb) {
-        // ToRGB: 3 dot products over the CO channels of this pixel; the QN lanes holding one pixel
-        // are contiguous in the wave -> butterfly reduction with wave shuffles.
-        const f4 w0 = ld4(p.trgb_w + n0 + c4 * 4);
-        const f4 w1 = ld4(p.trgb_w + p.CO + n0 + c4 * 4);
-        const f4 w2 = ld4(p.trgb_w + 2 * p.CO + n0 + c4 * 4);
-        float r0 = v.x * w0.x + v.y * w0.y + v.z * w0.z + v.w * w0.w;
-        float r1 = v.x * w1.x + v.y * w1.y + v.z * w1.z + v.w * w1.w;
-        float r2 = v.x * w2.x + v.y * w2.y + v.z * w2.z + v.w * w2.w;
+    f4 tw0 = {0.f, 0.f, 0.f, 0.f}, tw1 = tw0, tw2 = tw0;
+    const int c4 = tid & (QN - 1);                   // the same for every item of this thread
+    if (do_rgb) {
+      tw0 = ld4(p.trgb_w + n0 + c4 * 4);
+      tw1 = ld4(p.trgb_w + p.CO + n0 + c4 * 4);
+      tw2 = ld4(p.trgb_w + 2 * p.CO + n0 + c4 * 4);
+    }
 #pragma unroll
-        for (int s = QN / 2; s >= 1; s >>= 1) {
-          r0 += __shfl_xor(r0, s);
-          r1 += __shfl_xor(r1, s);
-          r2 += __shfl_xor(r2, s);
+    for (int it0 = 0; it0 < ITEMS; it0 += UB) {
+      f4 val[UB], sk[UB];
+      float nz[UB];
+      size_t oaddr[UB];
+      bool ok[UB];
+      int mm[UB];
+#pragma unroll
+      for (int u = 0; u < UB; ++u) {
+        const int it = tid + (it0 + u) * kThreads;
+        const int m = it >> LG_QN;
+        const int gx = m & (GW - 1);
+        const int gy = (m >> p.lgGW) & (GH - 1);
+        const int img = m >> (p.lgGW + p.lgGH);
+        const int oy = gy0 + gy, ox = gx0 + gx, b = b0 + img;
+        mm[u] = m;
+        ok[u] = b < p.B;
+        oaddr[u] = (((size_t)(ok[u] ? b : b0) * p.HO + oy) * p.WO + ox) * p.CO + n0 + c4 * 4;
+        val[u] = ld4(g_s + m * GS + c4 * 4);
+        nz[u] = has_noise ? gnoise[(size_t)oy * p.WO + ox] : 0.0f;
+        sk[u] = gskip ? ld4(gskip + oaddr[u]) : f4{0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+      for (int u = 0; u < UB; ++u) {
+        f4 v = val[u];
+        if (has_noise) v += MIGAN_FMUL_RN(nz[u], ns);                 // product rounded first, reference :166
+        v = act4(v);
+        if (ok[u]) st4(gy_ + oaddr[u], v + sk[u]);
+        if (do_rgb) {
+          // ToRGB: 3 dot products over the CO channels of this pixel; the QN lanes holding one pixel
+          // are contiguous in the wave -> butterfly reduction with wave shuffles.
+          float r0 = v.x * tw0.x + v.y * tw0.y + v.z * tw0.z + v.w * tw0.w;
+          float r1 = v.x * tw1.x + v.y * tw1.y + v.z * tw1.z + v.w * tw1.w;
+          float r2 = v.x * tw2.x + v.y * tw2.y + v.z * tw2.z + v.w * tw2.w;
+#pragma unroll
+          for (int s = (QN > 32 ? 32 : QN / 2); s >= 1; s >>= 1) {
+            r0 += __shfl_xor(r0, s);
+            r1 += __shfl_xor(r1, s);
+            r2 += __shfl_xor(r2, s);
+          }
+          if (c4 == 0) st4(racc_s + mm[u] * 4, f4{r0, r1, r2, 0.0f});
         }
-        if (c4 == 0 && ok) {
-          const float rgb[3] = {r0 + p.trgb_b[0], r1 + p.trgb_b[1], r2 + p.trgb_b[2]};
+      }
+    }
+    if (do_rgb) {
+      // second pass, one thread per pixel: bias + 2x-upsampled previous image (reference :308-313),
+      // planar store (consecutive threads -> consecutive x)
+      __syncthreads();
+      if (tid < MT) {
+        const int m = tid;
+        const int gx = m & (GW - 1);
+        const int gy = (m >> p.lgGW) & (GH - 1);
+        const int img = m >> (p.lgGW + p.lgGH);
+        const int oy = gy0 + gy, ox = gx0 + gx, b = b0 + img;
+        if (b < p.B) {
+          const f4 r = ld4(racc_s + m * 4);
+          const float rgb[3] = {r.x + p.trgb_b[0], r.y + p.trgb_b[1], r.z + p.trgb_b[2]};
           const size_t plane = (size_t)p.HO * p.WO;
 #pragma unroll
           for (int ch = 0; ch < 3; ++ch) {
@@ -483,8 +583,10 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, 2) sepconv_kernel(const SepArgs p) {
   } else {
     // UP: each item owns one interior low-resolution pixel x 4 channels and produces its 2x2
     // output pixels from the 3x3 neighbourhood in g_s (separable polyphase taps 1/4, 3/4).
-    for (int it = tid; it < MT * QN; it += kThreads) {
-      const int c4 = it & (QN - 1);
+    const int c4 = tid & (QN - 1);
+#pragma unroll 2
+    for (int it0 = 0; it0 < ITEMS; ++it0) {
+      const int it = tid + it0 * kThreads;
       const int m = it >> LG_QN;
       const int gx = m & (GW - 1);
       const int gy = (m >> p.lgGW) & (GH - 1);
@@ -492,6 +594,19 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, 2) sepconv_kernel(const SepArgs p) {
       const int ly = gy0 + gy, lx = gx0 + gx, b = b0 + img;
       if (gy < 1 || gy > GH - 2 || gx < 1 || gx > GW - 2) continue;     // recomputed halo rows
       if (ly >= p.H || lx >= p.W || b >= p.B) continue;                  // ragged tile edge
+      // issue the global loads of the 2x2 outputs first
+      size_t oaddr[2][2];
+      f4 sk[2][2];
+      float nz[2][2];
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int bb = 0; bb < 2; ++bb) {
+          const int oy = 2 * ly + a, ox = 2 * lx + bb;
+          oaddr[a][bb] = (((size_t)b * p.HO + oy) * p.WO + ox) * p.CO + n0 + c4 * 4;
+          nz[a][bb] = has_noise ? gnoise[(size_t)oy * p.WO + ox] : 0.0f;
+          sk[a][bb] = gskip ? ld4(gskip + oaddr[a][bb]) : f4{0.f, 0.f, 0.f, 0.f};
+        }
       f4 e[3], o[3];
 #pragma unroll
       for (int dy = 0; dy < 3; ++dy) {
@@ -509,19 +624,15 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, 2) sepconv_kernel(const SepArgs p) {
       for (int a = 0; a < 2; ++a)
 #pragma unroll
         for (int bb = 0; bb < 2; ++bb) {
-          const int oy = 2 * ly + a, ox = 2 * lx + bb;
           f4 v = out[a][bb];
-          if (has_noise) {
-            const float nz = MIGAN_FMUL_RN(p.noise[(size_t)oy * p.WO + ox], ns);
-            v += nz;
-          }
+          if (has_noise) v += MIGAN_FMUL_RN(nz[a][bb], ns);
           v = act4(v);
-          const size_t off = (((size_t)b * p.HO + oy) * p.WO + ox) * p.CO + n0 + c4 * 4;
-          if (p.skip) v += ld4(p.skip + off);
-          st4(p.y + off, v);
+          st4(gy_ + oaddr[a][bb], v + sk[a][bb]);
         }
     }
   }
+  PROF_MARK(5);
+  PROF_END();
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -13,6 +13,9 @@
 // v_mfma_f32_32x32x2_f32: exact-f32 matrix FMA (D = A[32x2] * B[2x32] + C), 64 cycles per SIMD
 #define MIGAN_MFMA_F32_32X32X2(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 #define MIGAN_FMUL_RN(a, b) __fmul_rn((a), (b))
+#define MIGAN_CLAMP(v, lo, hi) __builtin_amdgcn_fmed3f((v), (lo), (hi))     // v_med3_f32
+#define MIGAN_CLOCK() __builtin_readcyclecounter()
+#define MIGAN_ATOMIC_ADD_U64(p, v) atomicAdd((p), (v))
 
 namespace rt {
 typedef hipStream_t stream_t;
@@ -33,6 +36,18 @@ inline int memcpy_d2h(void* dst, const void* src, size_t bytes, stream_t s) {
   hipError_t e = hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, s);
   if (e != hipSuccess) return (int)e;
   return (int)hipStreamSynchronize(s);
+}
+inline int prof_alloc(unsigned long long** p, int n) {
+  hipError_t e = hipMalloc((void**)p, n * sizeof(unsigned long long));
+  if (e != hipSuccess) return (int)e;
+  return (int)hipMemset(*p, 0, n * sizeof(unsigned long long));
+}
+inline int prof_read(unsigned long long* dev, unsigned long long* out, int n, bool reset) {
+  hipError_t e = hipDeviceSynchronize();
+  if (e != hipSuccess) return (int)e;
+  e = hipMemcpy(out, dev, n * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+  if (e != hipSuccess) return (int)e;
+  return reset ? (int)hipMemset(dev, 0, n * sizeof(unsigned long long)) : 0;
 }
 inline int stream_sync(stream_t s) { return (int)hipStreamSynchronize(s); }
 inline int event_create(event_t* e) { return (int)hipEventCreate(e); }

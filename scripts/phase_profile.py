@@ -1,0 +1,40 @@
+#!/usr/bin/env python3
+"""Per-layer phase breakdown (debug build libmigan_hip_prof.so, -DMIGAN_PHASE_PROF): cycles spent by
+thread 0 of every workgroup in [prologue, S1 LDS fill (+barrier waits), S2 depthwise, S3 MFMA,
+accumulators->LDS, epilogue], averaged per workgroup, next to the hipEvent duration of the launch.
+    MIGAN_HIP_LIBRARY=mi-gan_amd/csrc/libmigan_hip_prof.so python scripts/phase_profile.py [res] [batch]
+"""
+import ctypes as C
+import importlib
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import torch
+
+pkg = importlib.import_module("mi-gan_amd")
+R = int(sys.argv[1]) if len(sys.argv) > 1 else 512
+B = int(sys.argv[2]) if len(sys.argv) > 2 else 32
+model = pkg.Generator(R)
+model.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in pkg.synth.make_state_dict(R, seed=0).items()})
+model = model.to("cuda").eval()
+x = torch.from_numpy(pkg.synth.make_input(B, R, seed=1)).to("cuda")
+with torch.no_grad():
+    for _ in range(2):
+        model(x)
+    _, ms = model.forward_timed(x)
+    _, ms = model.forward_timed(x)
+lib = model._lib.lib
+lib.migan_prof_layer.argtypes = [C.c_int, C.POINTER(C.c_ulonglong)]
+launches = model.launch_info()
+names = ["prolog", "S1fill", "S2dw", "S3mfma", "acc2lds", "epilog"]
+print(f"{'layer':26s} {'ms':>8s} {'WGs':>7s} " + " ".join(f"{n:>8s}" for n in names) + "   total cyc/WG")
+for i, (L, t) in enumerate(zip(launches, ms)):
+    out = (C.c_ulonglong * 16)()
+    if lib.migan_prof_layer(i, out) != 0:
+        continue
+    n = max(1, out[8])
+    cyc = [out[k] / n for k in range(6)]
+    print(f"{L['layer']:26s} {t:8.3f} {out[8]:7d} " + " ".join(f"{c:8.0f}" for c in cyc) + f"   {sum(cyc):9.0f}")
