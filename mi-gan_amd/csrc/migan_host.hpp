@@ -64,13 +64,13 @@ inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
 // Tuning knobs read once from the environment (experiments only; defaults are the shipped choice).
 struct Tuning {
-  int nt64_wgs_per_cu = 3;     // MIGAN_NT64_WGS: workgroups per CU targeted by the 64-column kernels (2 or 3)
+  int nt64_wgs_per_cu = 2;     // MIGAN_NT64_WGS: workgroups per CU targeted by the 64-column kernels (2 or 3)
   int force_single_b = 0;      // MIGAN_SINGLE_B=1: never double-buffer the 1x1 weight tile
 };
 inline Tuning& tuning() {
   static Tuning t = [] {
     Tuning v;
-    if (const char* e = std::getenv("MIGAN_NT64_WGS")) v.nt64_wgs_per_cu = (std::atoi(e) == 2) ? 2 : 3;
+    if (const char* e = std::getenv("MIGAN_NT64_WGS")) v.nt64_wgs_per_cu = (std::atoi(e) == 3) ? 3 : 2;
     if (const char* e = std::getenv("MIGAN_SINGLE_B")) v.force_single_b = std::atoi(e) != 0;
     return v;
   }();

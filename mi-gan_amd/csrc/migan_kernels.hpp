@@ -88,7 +88,13 @@ MIGAN_DEVICE MIGAN_INLINE float act1(float v) {
   t = t * 1.41421356237309515f;
   return MIGAN_CLAMP(t, -256.0f, 256.0f);
 }
-MIGAN_DEVICE MIGAN_INLINE f4 act4(f4 v) { return f4{act1(v.x), act1(v.y), act1(v.z), act1(v.w)}; }
+MIGAN_DEVICE MIGAN_INLINE f4 act4(f4 v) {
+  // vector form so the two multiplies become v_pk_mul_f32 (2 instead of 4 VALU issues each)
+  f4 t = __builtin_elementwise_max(v, v * 0.2f);
+  t = t * 1.41421356237309515f;
+  return f4{MIGAN_CLAMP(t.x, -256.0f, 256.0f), MIGAN_CLAMP(t.y, -256.0f, 256.0f), MIGAN_CLAMP(t.z, -256.0f, 256.0f),
+            MIGAN_CLAMP(t.w, -256.0f, 256.0f)};
+}
 
 MIGAN_DEVICE MIGAN_INLINE f4 ld4(const float* p) { return *reinterpret_cast<const f4*>(p); }
 MIGAN_DEVICE MIGAN_INLINE void st4(float* p, f4 v) { *reinterpret_cast<f4*>(p) = v; }
@@ -177,7 +183,15 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, MINW) sepconv_kernel(const SepArgs p)
   const int l31 = lane & 31, half = lane >> 5;
   PROF_BEGIN();
 
-  const int GH = 1 << p.lgGH, GW = 1 << p.lgGW, IMGS = 1 << p.lgIMGS;
+  // Main tiles (every layer at >= 16x16 output) have compile-time geometry so the index math below
+  // folds to shifts and multiply-highs; the NI == 9 instantiations serve the small-resolution layers
+  // (several images per tile) with run-time geometry.
+  constexpr bool MAINGEO = (NI != 9);
+  const int lgGH = MAINGEO ? (MODE == MODE_DOWN ? 2 : 3) : p.lgGH;
+  const int lgGW = MAINGEO ? 4 : p.lgGW;
+  const int lgIMGS = MAINGEO ? 0 : p.lgIMGS;
+  const int lgRS = MAINGEO ? 1 : p.lgRS;
+  const int GH = 1 << lgGH, GW = 1 << lgGW, IMGS = 1 << lgIMGS;
 
   // ---- which tile am I -------------------------------------------------------------------
   int t = xcd_remap((int)blockIdx.x, (int)gridDim.x);
@@ -186,7 +200,7 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, MINW) sepconv_kernel(const SepArgs p)
   const int ty = t % p.tiles_y;
   const int bgrp = t / p.tiles_y;
   const int n0 = nch * NT;
-  const int b0 = bgrp << p.lgIMGS;
+  const int b0 = bgrp << lgIMGS;
   const int gy0 = ty * p.sy - p.off, gx0 = tx * p.sx - p.off;   // GEMM grid origin (GEMM-resolution image coords)
 
   // ---- LDS carve --------------------------------------------------------------------------
@@ -211,12 +225,12 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, MINW) sepconv_kernel(const SepArgs p)
   // float4 number i of the LDS tile ([pixel][KC/4]); goff = element offset of its source inside
   // image group b0 (0 when the pixel is padding: loaded anyway, zeroed on the way to LDS, which is
   // the conv zero padding of reference :126); bit j of `vmask` = real pixel, of `emask` = item exists.
-  int goff[NI];
+  unsigned goff[NI];
   unsigned vmask = 0, emask = 0;
 #pragma unroll
   for (int j = 0; j < NI; ++j) {
     const int i = tid + j * kThreads;
-    int g = 0;
+    unsigned g = 0;
     if (i < nitems_in) {
       emask |= 1u << j;
       const int c4 = i & (QC - 1);
@@ -227,18 +241,18 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, MINW) sepconv_kernel(const SepArgs p)
       const int yy = iy0 + iy, xx = ix0 + ix;
       if (yy >= 0 && yy < p.H && xx >= 0 && xx < p.W && (b0 + img) < p.B) {
         vmask |= 1u << j;
-        g = FROMRGB ? 0 : ((img * p.H + yy) * p.W + xx) * p.CI + c4 * 4;
+        g = FROMRGB ? 0u : (unsigned)(((img * p.H + yy) * p.W + xx) * p.CI + c4 * 4);
       }
     }
     goff[j] = g;
   }
   const float* __restrict__ xb = gx_ + (size_t)b0 * p.H * p.W * (FROMRGB ? 4 : p.CI);
   // 1x1 weight tile items: n = i / QC rows of conv2.weight, 4 consecutive input channels
-  int boff[NB];
+  unsigned boff[NB];
 #pragma unroll
   for (int j = 0; j < NB; ++j) {
     const int i = tid + j * kThreads;
-    boff[j] = (n0 + (i >> LG_QC)) * p.CI + (i & (QC - 1)) * 4;
+    boff[j] = (unsigned)((n0 + (i >> LG_QC)) * p.CI + (i & (QC - 1)) * 4);
   }
 
   if constexpr (FROMRGB) {
@@ -268,22 +282,27 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, MINW) sepconv_kernel(const SepArgs p)
 
   // prefetch registers: one K chunk of the input tile, of the 1x1 weights and of the small weights
   f4 rin[NI], rb[NB], rw;
+  // every global access below is (wave-uniform base pointer, held in SGPRs) + (32-bit lane offset):
+  // no 64-bit VALU address arithmetic in the K loop.
   auto issue_loads = [&](int k0) {
     if constexpr (!FROMRGB) {
+      const float* __restrict__ xk = xb + k0;
 #pragma unroll
-      for (int j = 0; j < NI; ++j) rin[j] = ld4(xb + goff[j] + k0);
+      for (int j = 0; j < NI; ++j) rin[j] = ld4(xk + goff[j]);
     }
+    const float* __restrict__ wk = gwpw + k0;
 #pragma unroll
-    for (int j = 0; j < NB; ++j) rb[j] = ld4(gwpw + boff[j] + k0);
+    for (int j = 0; j < NB; ++j) rb[j] = ld4(wk + boff[j]);
     // depthwise taps of channels [k0,k0+KC) are KC*9 contiguous floats of conv1.weight, then the bias
-    const float* src = gwdw + (size_t)k0 * 9 + tid * 4;
-    if (tid >= KC * 9 / 4) src = gbdw + k0 + (tid - KC * 9 / 4) * 4;
+    if (tid < KC * 9 / 4) rw = ld4(gwdw + (size_t)k0 * 9 + (unsigned)(tid * 4));
+    else if (tid < NW4) rw = ld4(gbdw + k0 + (unsigned)((tid - KC * 9 / 4) * 4));
     if constexpr (FROMRGB) {
-      if (tid >= NW4) src = p.frgb_w + (size_t)k0 * 4 + (tid - NW4) * 4;
-      if (tid >= NW4 + KC) src = p.frgb_b + k0 + (tid - NW4 - KC) * 4;
+      if (tid >= NW4 && tid < NW4 + KC) rw = ld4(p.frgb_w + (size_t)k0 * 4 + (unsigned)((tid - NW4) * 4));
+      else if (tid >= NW4 + KC && tid < NW4 + NF4) rw = ld4(p.frgb_b + k0 + (unsigned)((tid - NW4 - KC) * 4));
     }
-    if (tid < NW4 + NF4) rw = ld4(src);
   };
+  // interior tiles (no padding anywhere in the wave's items) skip the zero-fill selects
+  const bool wave_all_valid = __all(vmask == emask);
 
   PROF_MARK(0);
   // ======================================= K loop ==========================================
@@ -296,7 +315,16 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, MINW) sepconv_kernel(const SepArgs p)
     if (p.b_stride == 0) __syncthreads();           // single weight buffer: wait for the MFMAs of chunk c-1
 
     // ---- S1: prefetched chunk -> LDS -----------------------------------------------------------
-    if (tid < NW4 + NF4) st4(w_s + tid * 4, rw);
+    // depthwise taps go to LDS tap-major ([9][KC]) so the strip below reads one float4 per tap
+    if (tid < KC * 9 / 4) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int f = tid * 4 + e;                   // flat index into [KC][9]
+        w_s[(f % 9) * KC + f / 9] = rw[e];
+      }
+    } else if (tid < NW4 + NF4) {
+      st4(w_s + tid * 4, rw);
+    }
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
       const int i = tid + j * kThreads;
@@ -327,12 +355,18 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, MINW) sepconv_kernel(const SepArgs p)
         }
       }
     } else {
+      if (wave_all_valid) {
 #pragma unroll
-      for (int j = 0; j < NI; ++j) {
-        if (emask & (1u << j)) {
-          f4 v = rin[j];
-          if (!(vmask & (1u << j))) v = f4{0.f, 0.f, 0.f, 0.f};
-          st4(in_s + (tid + j * kThreads) * 4, v);
+        for (int j = 0; j < NI; ++j)
+          if (emask & (1u << j)) st4(in_s + (tid + j * kThreads) * 4, rin[j]);
+      } else {
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+          if (emask & (1u << j)) {
+            f4 v = rin[j];
+            if (!(vmask & (1u << j))) v = f4{0.f, 0.f, 0.f, 0.f};
+            st4(in_s + (tid + j * kThreads) * 4, v);
+          }
         }
       }
     }
@@ -345,38 +379,39 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, MINW) sepconv_kernel(const SepArgs p)
     // from LDS) is scattered into three running sums (the outputs it is the bottom / middle / top
     // tap row of), so each LDS value is read once per column and no register window is kept.
     if constexpr (MODE != MODE_DOWN) {
-      const int RS = 1 << p.lgRS;
-      const int ncols = (IMGS * GW * QC) << p.lgRS;
+      const int RS = 1 << lgRS;
+      const int ncols = (IMGS * GW * QC) << lgRS;
       for (int it = tid; it < ncols; it += kThreads) {
         const int c4 = it & (QC - 1);
         int r = it >> LG_QC;
-        const int gx = r & (GW - 1); r >>= p.lgGW;
+        const int gx = r & (GW - 1); r >>= lgGW;
         const int seg = r & (RS - 1);
-        const int img = r >> p.lgRS;
+        const int img = r >> lgRS;
         const int r0 = seg * SEGH;
-        // 4 channels x 9 taps are 36 contiguous floats of conv1.weight [C][1][3][3]
-        float wf[36];
-#pragma unroll
-        for (int q = 0; q < 9; ++q) {
-          const f4 tq = ld4(w_s + c4 * 36 + 4 * q);
-          wf[4 * q + 0] = tq.x; wf[4 * q + 1] = tq.y; wf[4 * q + 2] = tq.z; wf[4 * q + 3] = tq.w;
-        }
         f4 w[9];
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap) w[tap] = f4{wf[tap], wf[9 + tap], wf[18 + tap], wf[27 + tap]};
+        for (int tap = 0; tap < 9; ++tap) w[tap] = ld4(w_s + tap * KC + c4 * 4);
         const f4 bias = ld4(w_s + KC * 9 + c4 * 4);
-        f4 s2 = bias, s1 = bias, s0 = bias;   // outputs (row-2, row-1, row) of the current input row
+        // sliding 3x3 register window down the strip: 3 LDS reads and 9 float4 FMAs per output
         const float* ip = in_s + ((img * IGH + r0) * IGW + gx) * KC + c4 * 4;
-        const int mbase = (img << (p.lgGH + p.lgGW)) + (r0 << p.lgGW) + gx;
-#pragma unroll 2
-        for (int rr = 0; rr < SEGH + 2; ++rr) {
-          const f4 L = ld4(ip), M = ld4(ip + KC), R = ld4(ip + 2 * KC);
+        const int mbase = (img << (lgGH + lgGW)) + (r0 << lgGW) + gx;
+        f4 win[3][3];
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) {
+          win[rr][0] = ld4(ip); win[rr][1] = ld4(ip + KC); win[rr][2] = ld4(ip + 2 * KC);
           ip += IGW * KC;
-          s2 += w[6] * L + w[7] * M + w[8] * R;
-          s1 += w[3] * L + w[4] * M + w[5] * R;
-          s0 += w[0] * L + w[1] * M + w[2] * R;
-          if (rr >= 2) st4(a_s + (mbase + ((rr - 2) << p.lgGW)) * AS + c4 * 4, act4(s2));
-          s2 = s1; s1 = s0; s0 = bias;
+        }
+#pragma unroll
+        for (int o = 0; o < SEGH; ++o) {
+          const int nr = (o + 2) % 3;
+          win[nr][0] = ld4(ip); win[nr][1] = ld4(ip + KC); win[nr][2] = ld4(ip + 2 * KC);
+          ip += IGW * KC;
+          f4 sacc = bias;
+#pragma unroll
+          for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) sacc += w[ky * 3 + kx] * win[(o + ky) % 3][kx];
+          st4(a_s + (mbase + (o << lgGW)) * AS + c4 * 4, act4(sacc));
         }
       }
     } else {
@@ -391,15 +426,9 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, MINW) sepconv_kernel(const SepArgs p)
         const int dx = r % DW, img = r / DW;
         const int xim = 2 * gx0 - 1 + dx;
         const bool colin = xim >= 0 && xim < p.W;
-        float wf[36];
-#pragma unroll
-        for (int q = 0; q < 9; ++q) {
-          const f4 tq = ld4(w_s + c4 * 36 + 4 * q);
-          wf[4 * q + 0] = tq.x; wf[4 * q + 1] = tq.y; wf[4 * q + 2] = tq.z; wf[4 * q + 3] = tq.w;
-        }
         f4 w[9];
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap) w[tap] = f4{wf[tap], wf[9 + tap], wf[18 + tap], wf[27 + tap]};
+        for (int tap = 0; tap < 9; ++tap) w[tap] = ld4(w_s + tap * KC + c4 * 4);
         const f4 bias = ld4(w_s + KC * 9 + c4 * 4);
         f4 s2 = bias, s1 = bias, s0 = bias;
         f4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = {0.f, 0.f, 0.f, 0.f};
@@ -424,7 +453,7 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, MINW) sepconv_kernel(const SepArgs p)
               v1 += 0.375f * d;
               v0 += 0.125f * d;
               const int oy = (dy >> 1) - 1;
-              if (oy >= 0) st4(v_s + (((img << p.lgGH) + oy) * DW + dx) * KC + c4 * 4, v0);
+              if (oy >= 0) st4(v_s + (((img << lgGH) + oy) * DW + dx) * KC + c4 * 4, v0);
               v0 = v1;
             }
           }
@@ -436,7 +465,7 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, MINW) sepconv_kernel(const SepArgs p)
         const int c4 = it & (QC - 1);
         const int m = it >> LG_QC;
         const int ox = m & (GW - 1);
-        const int rr = m >> p.lgGW;                 // img*GH + oy
+        const int rr = m >> lgGW;                 // img*GH + oy
         const float* vp = v_s + (rr * DW + 2 * ox) * KC + c4 * 4;
         const f4 a = 0.125f * ld4(vp) + 0.375f * ld4(vp + KC) + 0.375f * ld4(vp + 2 * KC) + 0.125f * ld4(vp + 3 * KC);
         st4(a_s + m * AS + c4 * 4, a);
@@ -488,7 +517,7 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, MINW) sepconv_kernel(const SepArgs p)
           // halo pixels outside the low-resolution image contribute zeros to the upsampling FIR
           // (reference pads with zeros :101), not the conv of a zero-padded input
           const int gx = row & (GW - 1);
-          const int gy = (row >> p.lgGW) & (GH - 1);
+          const int gy = (row >> lgGW) & (GH - 1);
           const int ly = gy0 + gy, lx = gx0 + gx;
           if (ly < 0 || ly >= p.H || lx < 0 || lx >= p.W) v = 0.0f;
         }
@@ -502,44 +531,60 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, MINW) sepconv_kernel(const SepArgs p)
   constexpr int ITEMS = MT * QN / kThreads;          // epilogue items per thread
   constexpr int UB = 4;                              // items whose global loads are issued together
   static_assert(ITEMS % UB == 0, "epilogue batches must divide the per-thread items");
+  // Items of a thread are GEMM rows m0 + k*STEP (k = 0..ITEMS-1), always the same 4 channels.  With
+  // the main geometry the pixel offset of item k is a compile-time function of k, so every global
+  // address is (uniform pointer advanced per item in SGPRs) + (one 32-bit lane offset computed once).
+  constexpr int STEP = kThreads >> LG_QN;
+  const int c4 = tid & (QN - 1);
+  const int m0 = tid >> LG_QN;
+  const int gxt = m0 & (GW - 1), gyt = (m0 >> lgGW) & (GH - 1);
+  const size_t img_elems = (size_t)p.HO * p.WO * p.CO;
+  float* __restrict__ yb = gy_ + (size_t)b0 * img_elems;
+  const float* __restrict__ sb = gskip ? gskip + (size_t)b0 * img_elems : nullptr;
 
   if constexpr (MODE != MODE_UP) {
     const bool do_rgb = p.trgb_w != nullptr;
     f4 tw0 = {0.f, 0.f, 0.f, 0.f}, tw1 = tw0, tw2 = tw0;
-    const int c4 = tid & (QN - 1);                   // the same for every item of this thread
     if (do_rgb) {
       tw0 = ld4(p.trgb_w + n0 + c4 * 4);
       tw1 = ld4(p.trgb_w + p.CO + n0 + c4 * 4);
       tw2 = ld4(p.trgb_w + 2 * p.CO + n0 + c4 * 4);
     }
+    const unsigned pix_t = (unsigned)((gy0 + gyt) * p.WO + gx0 + gxt);   // first pixel of this thread
+    const unsigned off_t = pix_t * (unsigned)p.CO + (unsigned)(n0 + c4 * 4);
 #pragma unroll
     for (int it0 = 0; it0 < ITEMS; it0 += UB) {
       f4 val[UB], sk[UB];
       float nz[UB];
-      size_t oaddr[UB];
+      unsigned loff[UB];     // lane part of the element offset
+      int upix[UB];          // uniform part, in pixels
       bool ok[UB];
-      int mm[UB];
 #pragma unroll
       for (int u = 0; u < UB; ++u) {
-        const int it = tid + (it0 + u) * kThreads;
-        const int m = it >> LG_QN;
-        const int gx = m & (GW - 1);
-        const int gy = (m >> p.lgGW) & (GH - 1);
-        const int img = m >> (p.lgGW + p.lgGH);
-        const int oy = gy0 + gy, ox = gx0 + gx, b = b0 + img;
-        mm[u] = m;
-        ok[u] = b < p.B;
-        oaddr[u] = (((size_t)(ok[u] ? b : b0) * p.HO + oy) * p.WO + ox) * p.CO + n0 + c4 * 4;
+        const int dm = (it0 + u) * STEP;
+        const int m = m0 + dm;
         val[u] = ld4(g_s + m * GS + c4 * 4);
-        nz[u] = has_noise ? gnoise[(size_t)oy * p.WO + ox] : 0.0f;
-        sk[u] = gskip ? ld4(gskip + oaddr[u]) : f4{0.f, 0.f, 0.f, 0.f};
+        if constexpr (MAINGEO) {
+          upix[u] = (dm >> lgGW) * p.WO + (dm & (GW - 1));
+          loff[u] = off_t;
+          ok[u] = true;
+          nz[u] = has_noise ? (gnoise + upix[u])[pix_t] : 0.0f;
+        } else {
+          const int gx = m & (GW - 1), gy = (m >> lgGW) & (GH - 1), img = m >> (lgGW + lgGH);
+          ok[u] = (b0 + img) < p.B;
+          const unsigned pix = (unsigned)((gy0 + gy) * p.WO + gx0 + gx);
+          upix[u] = 0;
+          loff[u] = (unsigned)(ok[u] ? img : 0) * (unsigned)img_elems + pix * (unsigned)p.CO + (unsigned)(n0 + c4 * 4);
+          nz[u] = has_noise ? gnoise[pix] : 0.0f;
+        }
+        sk[u] = sb ? ld4(sb + (size_t)upix[u] * p.CO + loff[u]) : f4{0.f, 0.f, 0.f, 0.f};
       }
 #pragma unroll
       for (int u = 0; u < UB; ++u) {
         f4 v = val[u];
         if (has_noise) v += MIGAN_FMUL_RN(nz[u], ns);                 // product rounded first, reference :166
         v = act4(v);
-        if (ok[u]) st4(gy_ + oaddr[u], v + sk[u]);
+        if (ok[u]) st4(yb + (size_t)upix[u] * p.CO + loff[u], sb ? v + sk[u] : v);
         if (do_rgb) {
           // ToRGB: 3 dot products over the CO channels of this pixel; the QN lanes holding one pixel
           // are contiguous in the wave -> butterfly reduction with wave shuffles.
@@ -552,7 +597,7 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, MINW) sepconv_kernel(const SepArgs p)
             r1 += __shfl_xor(r1, s);
             r2 += __shfl_xor(r2, s);
           }
-          if (c4 == 0) st4(racc_s + mm[u] * 4, f4{r0, r1, r2, 0.0f});
+          if (c4 == 0) st4(racc_s + (m0 + (it0 + u) * STEP) * 4, f4{r0, r1, r2, 0.0f});
         }
       }
     }
@@ -563,8 +608,8 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, MINW) sepconv_kernel(const SepArgs p)
       if (tid < MT) {
         const int m = tid;
         const int gx = m & (GW - 1);
-        const int gy = (m >> p.lgGW) & (GH - 1);
-        const int img = m >> (p.lgGW + p.lgGH);
+        const int gy = (m >> lgGW) & (GH - 1);
+        const int img = m >> (lgGW + lgGH);
         const int oy = gy0 + gy, ox = gx0 + gx, b = b0 + img;
         if (b < p.B) {
           const f4 r = ld4(racc_s + m * 4);
@@ -583,29 +628,46 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, MINW) sepconv_kernel(const SepArgs p)
   } else {
     // UP: each item owns one interior low-resolution pixel x 4 channels and produces its 2x2
     // output pixels from the 3x3 neighbourhood in g_s (separable polyphase taps 1/4, 3/4).
-    const int c4 = tid & (QN - 1);
-#pragma unroll 2
-    for (int it0 = 0; it0 < ITEMS; ++it0) {
-      const int it = tid + it0 * kThreads;
-      const int m = it >> LG_QN;
-      const int gx = m & (GW - 1);
-      const int gy = (m >> p.lgGW) & (GH - 1);
-      const int img = m >> (p.lgGW + p.lgGH);
+    // lane part of the output address: output pixel (2*(gy0+gyt), 2*(gx0+gxt)) of this thread's first item
+    // (signed: the first item of a thread may be a halo pixel above/left of the image)
+    const int opix_t = 2 * (gy0 + gyt) * p.WO + 2 * (gx0 + gxt);
+    const int ooff_t = opix_t * p.CO + n0 + c4 * 4;
+#pragma unroll
+    for (int k = 0; k < ITEMS; ++k) {
+      const int dm = k * STEP;
+      const int m = m0 + dm;
+      int gx, gy, img;
+      if constexpr (MAINGEO) {
+        gy = dm >> lgGW;                     // compile-time: halo rows of the GEMM grid drop out statically
+        gx = gxt + (dm & (GW - 1));
+        img = 0;
+        if (gy < 1 || gy > GH - 2) continue;
+      } else {
+        gx = m & (GW - 1); gy = (m >> lgGW) & (GH - 1); img = m >> (lgGW + lgGH);
+        if (gy < 1 || gy > GH - 2) continue;
+      }
       const int ly = gy0 + gy, lx = gx0 + gx, b = b0 + img;
-      if (gy < 1 || gy > GH - 2 || gx < 1 || gx > GW - 2) continue;     // recomputed halo rows
-      if (ly >= p.H || lx >= p.W || b >= p.B) continue;                  // ragged tile edge
-      // issue the global loads of the 2x2 outputs first
-      size_t oaddr[2][2];
+      if (gx < 1 || gx > GW - 2 || ly >= p.H || lx >= p.W || b >= p.B) continue;     // halo columns, ragged edge
+      // uniform part (pixels) and lane part (elements) of the four output addresses
+      int upix, loff, lpix;
+      if constexpr (MAINGEO) {
+        upix = 2 * (dm >> lgGW) * p.WO + 2 * (dm & (GW - 1));
+        loff = ooff_t;
+        lpix = opix_t;
+      } else {
+        upix = 0;
+        lpix = (2 * ly) * p.WO + 2 * lx;
+        loff = img * (int)img_elems + lpix * p.CO + n0 + c4 * 4;
+      }
       f4 sk[2][2];
       float nz[2][2];
 #pragma unroll
       for (int a = 0; a < 2; ++a)
 #pragma unroll
         for (int bb = 0; bb < 2; ++bb) {
-          const int oy = 2 * ly + a, ox = 2 * lx + bb;
-          oaddr[a][bb] = (((size_t)b * p.HO + oy) * p.WO + ox) * p.CO + n0 + c4 * 4;
-          nz[a][bb] = has_noise ? gnoise[(size_t)oy * p.WO + ox] : 0.0f;
-          sk[a][bb] = gskip ? ld4(gskip + oaddr[a][bb]) : f4{0.f, 0.f, 0.f, 0.f};
+          const int dp = upix + a * p.WO + bb;                      // uniform
+          nz[a][bb] = has_noise ? gnoise[(unsigned)(lpix + dp)] : 0.0f;
+          sk[a][bb] = sb ? ld4(sb + (unsigned)(loff + dp * p.CO)) : f4{0.f, 0.f, 0.f, 0.f};
         }
       f4 e[3], o[3];
 #pragma unroll
@@ -627,7 +689,7 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, MINW) sepconv_kernel(const SepArgs p)
           f4 v = out[a][bb];
           if (has_noise) v += MIGAN_FMUL_RN(nz[a][bb], ns);
           v = act4(v);
-          st4(gy_ + oaddr[a][bb], v + sk[a][bb]);
+          st4(yb + (unsigned)(loff + (upix + a * p.WO + bb) * p.CO), sb ? v + sk[a][bb] : v);
         }
     }
   }

@@ -137,6 +137,18 @@ inline float __shfl_xor(float v, int mask) {
   return r;
 }
 
+inline bool __all(bool pred) {
+  hipemu::Block* b = hipemu::tl_blk;
+  const int w = b->cur >> 6, l = b->cur & 63;
+  b->xa[w][l] = pred ? 1.0f : 0.0f;
+  hipemu::wave_barrier();
+  bool r = true;
+  for (int i = 0; i < 64; ++i)
+    if (!b->lanes[(w << 6) + i].done && b->xa[w][i] == 0.0f) r = false;
+  hipemu::wave_barrier();
+  return r;
+}
+
 typedef float emu_f16v __attribute__((ext_vector_type(16)));
 inline emu_f16v hipemu_mfma_f32_32x32x2(float a, float bv, emu_f16v c) {
   hipemu::Block* b = hipemu::tl_blk;
