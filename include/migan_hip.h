@@ -114,6 +114,8 @@ typedef struct migan_sepconv_desc {
   int batch, cin, cout, res_in;
   int down;                   /* 1 or 2 (Downsample2d, reference :58-76) */
   int up;                     /* 1 or 2 (Upsample2d, reference :79-103) */
+  void* scratch;              /* down == 2 only: batch*(res_in/2)^2*cin floats (output of the depthwise+FIR kernel) */
+  size_t scratch_bytes;
 } migan_sepconv_desc;
 int migan_sepconv_forward(const migan_sepconv_desc* d, void* stream);
 

@@ -27,7 +27,7 @@ def hipcc() -> str:
 
 
 def command(extra: List[str] = ()) -> List[str]:
-    return [hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared",
+    return [hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared", "-fno-honor-nans",
             os.path.join(CSRC, "migan_hip.hip"), "-o", OUT, *extra]
 
 

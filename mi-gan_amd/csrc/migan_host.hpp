@@ -47,6 +47,9 @@ struct Geo {
   int mode = MODE_NORMAL, MT = 128, NT = 128, KC = 32;
   bool fromrgb = false;
   int NI = 6, MINW = 2;            // prefetch items per thread, workgroups per CU the kernel is built for
+  bool maing = true;               // compile-time tile geometry (8x16 pixels, one image)
+  bool persist = false;            // kernel variant whose workgroups walk several tiles
+  int a_stride = 0;
   int lgGH = 3, lgGW = 4, lgIMGS = 0;
   int sy = 8, sx = 16, off = 0, lgRS = 1;
   int tiles_x = 1, tiles_y = 1, nchunks = 1;
@@ -66,12 +69,16 @@ inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 struct Tuning {
   int nt64_wgs_per_cu = 2;     // MIGAN_NT64_WGS: workgroups per CU targeted by the 64-column kernels (2 or 3)
   int force_single_b = 0;      // MIGAN_SINGLE_B=1: never double-buffer the 1x1 weight tile
+  int persist_min = 8192;      // MIGAN_PERSIST_MIN: launches with at least this many tiles run persistent workgroups
+  int persist_grid = 512;      // MIGAN_PERSIST_GRID: ... that many (2 per CU on MI355X), each walking its share of tiles
 };
 inline Tuning& tuning() {
   static Tuning t = [] {
     Tuning v;
     if (const char* e = std::getenv("MIGAN_NT64_WGS")) v.nt64_wgs_per_cu = (std::atoi(e) == 3) ? 3 : 2;
     if (const char* e = std::getenv("MIGAN_SINGLE_B")) v.force_single_b = std::atoi(e) != 0;
+    if (const char* e = std::getenv("MIGAN_PERSIST_MIN")) v.persist_min = std::max(1, std::atoi(e));
+    if (const char* e = std::getenv("MIGAN_PERSIST_GRID")) v.persist_grid = std::max(8, std::atoi(e) / 8 * 8);   // multiple of 8: one share per XCD
     return v;
   }();
   return t;
@@ -93,17 +100,15 @@ inline Geo choose_geo(int mode, int cin, int cout, int res_in, bool fromrgb, boo
     else { GH = 4; GW = 4; IMGS = 8; }
     g.sy = GH; g.sx = GW; g.off = 0;
     g.tiles_y = res_in / GH; g.tiles_x = res_in / GW;
-  } else if (mode == MODE_DOWN) {
-    MIGAN_CHECK(res_in >= 8, MIGAN_EINVAL, "down layer needs res_in >= 8");
+  } else if (mode == MODE_PW) {
+    // pointwise GEMM at res_in (second half of a down=2 layer; its input is dwfir_kernel's output)
     MIGAN_CHECK(!fromrgb, MIGAN_EINVAL, "fromrgb is only fused into plain layers");
-    const int ro = res_in / 2;
-    g.MT = 64; g.KC = 16;
-    if (cout % 256 == 0) g.NT = 256;             // fewer recomputations of the depthwise stage per pixel
-    if (ro >= 16) { GH = 4; GW = 16; IMGS = 1; }
-    else if (ro == 8) { GH = 4; GW = 8; IMGS = 2; }
-    else { GH = 4; GW = 4; IMGS = 4; }
+    g.MT = 128; g.KC = 32;
+    if (res_in >= 16) { GH = 8; GW = 16; IMGS = 1; }
+    else if (res_in == 8) { GH = 8; GW = 8; IMGS = 2; }
+    else { GH = 4; GW = 4; IMGS = 8; }
     g.sy = GH; g.sx = GW; g.off = 0;
-    g.tiles_y = ro / GH; g.tiles_x = ro / GW;
+    g.tiles_y = res_in / GH; g.tiles_x = res_in / GW;
   } else {
     MIGAN_CHECK(!fromrgb, MIGAN_EINVAL, "fromrgb is only fused into plain layers");
     g.MT = 128; g.KC = 32;
@@ -116,36 +121,38 @@ inline Geo choose_geo(int mode, int cin, int cout, int res_in, bool fromrgb, boo
   g.lgGH = ilog2(GH); g.lgGW = ilog2(GW); g.lgIMGS = ilog2(IMGS);
   MIGAN_CHECK(IMGS * GH * GW == g.MT, MIGAN_EINVAL, "internal: tile geometry does not fill the GEMM tile");
   const int QC = g.KC / 4;
-  int rs = 1;
-  if (mode != MODE_DOWN) {
-    rs = GH / 4;                                   // depthwise strips are 4 output rows tall
-    MIGAN_CHECK(rs >= 1 && IMGS * GW * QC * rs >= 1, MIGAN_EINVAL, "internal: strip geometry");
-  } else {
-    MIGAN_CHECK(GH == 4, MIGAN_EINVAL, "internal: DOWN tiles are 4 GEMM rows tall");
-  }
+  const int rs = GH / 4 > 0 ? GH / 4 : 1;        // depthwise strips are 4 output rows tall
   g.lgRS = ilog2(rs);
-  const int IGH = (mode == MODE_DOWN) ? 2 * GH + 4 : GH + 2;
-  const int IGW = (mode == MODE_DOWN) ? 2 * GW + 4 : GW + 2;
-  g.npix_in = IMGS * IGH * IGW;
+  const int halo = (mode == MODE_PW) ? 0 : 1;
+  g.npix_in = IMGS * (GH + 2 * halo) * (GW + 2 * halo);
   const int items = cdiv(g.npix_in * QC, kThreads);
-  if (mode == MODE_DOWN) g.NI = items <= 7 ? 7 : 9;
-  else g.NI = items <= 6 ? 6 : 9;
+  g.maing = (IMGS == 1 && GH == 8 && GW == 16);
+  if (mode == MODE_PW) g.NI = 4;
+  else g.NI = g.maing ? 6 : 9;
   MIGAN_CHECK(items <= g.NI, MIGAN_EINVAL, "internal: input tile too large");
   g.MINW = (g.NT == 64) ? tuning().nt64_wgs_per_cu : 2;
   const int AS = g.KC + 4, GS = g.NT + 4;
-  int o = g.npix_in * g.KC;
-  g.off_a = o; o += g.MT * AS;
-  g.off_v = o; if (mode == MODE_DOWN) o += IMGS * GH * (2 * GW + 2) * g.KC;
-  g.off_rgb = o; if (fromrgb) o += g.npix_in * 4;
-  g.off_w = o; o += g.KC * 10 + (fromrgb ? g.KC * 5 : 0);
-  g.off_b = o;
-  const int bsz = g.NT * AS;
-  int gs = g.MT * GS + (fused_rgb ? g.MT * 4 : 0);
+  const int asz = g.MT * AS, bsz = g.NT * AS;
+  const int gs = g.MT * GS + (fused_rgb ? g.MT * 4 : 0);
   const size_t limit = (size_t)(160 * 1024 / g.MINW);
-  const size_t dbl = (size_t)std::max(o + 2 * bsz, gs) * sizeof(float);
-  const size_t sgl = (size_t)std::max(o + bsz, gs) * sizeof(float);
-  if (dbl <= limit && !tuning().force_single_b) { g.b_stride = bsz; g.lds_bytes = dbl; }   // double-buffered 1x1 weights: 2 barriers per K chunk
-  else { g.b_stride = 0; g.lds_bytes = sgl; }
+  if (mode == MODE_PW) {
+    // A and B operands double buffered: one barrier per K chunk
+    g.off_a = 0; g.off_v = g.off_rgb = g.off_w = 0;
+    const size_t dbl = (size_t)std::max(2 * asz + 2 * bsz, gs) * sizeof(float);
+    if (dbl <= limit && !tuning().force_single_b) { g.a_stride = asz; g.off_b = 2 * asz; g.b_stride = bsz; g.lds_bytes = dbl; }
+    else { g.a_stride = 0; g.off_b = asz; g.b_stride = 0; g.lds_bytes = (size_t)std::max(asz + bsz, gs) * sizeof(float); }
+  } else {
+    int o = g.npix_in * g.KC;
+    g.off_a = o; o += asz;
+    g.off_v = o;
+    g.off_rgb = o; if (fromrgb) o += g.npix_in * 4;
+    g.off_w = o; o += g.KC * 10 + (fromrgb ? g.KC * 5 : 0);
+    g.off_b = o;
+    const size_t dbl = (size_t)std::max(o + 2 * bsz, gs) * sizeof(float);
+    const size_t sgl = (size_t)std::max(o + bsz, gs) * sizeof(float);
+    if (dbl <= limit && !tuning().force_single_b) { g.b_stride = bsz; g.lds_bytes = dbl; }   // double-buffered 1x1 weights: 2 barriers per K chunk
+    else { g.b_stride = 0; g.lds_bytes = sgl; }
+  }
   MIGAN_CHECK(g.lds_bytes <= 160 * 1024, MIGAN_EINVAL, "internal: LDS tile exceeds 160 KiB");
   return g;
 }
@@ -156,32 +163,32 @@ struct KernelEntry {
   int mode, MT, NT, KC;
   bool fromrgb;
   int NI, MINW;
+  bool maing, persist;
   SepKernelFn fn;
   const char* name;
 };
 
-#define MIGAN_KERNEL(MODE, MT, NT, KC, RGB, NI, MINW)                                   \
-  {MODE, MT, NT, KC, RGB, NI, MINW, sepconv_kernel<MODE, MT, NT, KC, RGB, NI, MINW>,    \
-   "migan::sepconv_kernel<" #MODE ", " #MT ", " #NT ", " #KC ", " #RGB ", " #NI ", " #MINW ">"}
+#define MIGAN_KERNEL(MODE, MT, NT, KC, RGB, NI, MINW, MAING, PERSIST)                                               \
+  {MODE, MT, NT, KC, RGB, NI, MINW, MAING, PERSIST, sepconv_kernel<MODE, MT, NT, KC, RGB, NI, MINW, MAING, PERSIST>, \
+   "migan::sepconv_kernel<" #MODE ", " #MT ", " #NT ", " #KC ", " #RGB ", " #NI ", " #MINW ", " #MAING ", " #PERSIST ">"}
 
 inline const std::vector<KernelEntry>& kernel_table() {
   static const std::vector<KernelEntry> t = {
-      // plain layers (MODE 0)
-      MIGAN_KERNEL(0, 128, 128, 32, false, 6, 2), MIGAN_KERNEL(0, 128, 128, 32, false, 9, 2),
-      MIGAN_KERNEL(0, 128, 64, 32, false, 6, 3),  MIGAN_KERNEL(0, 128, 64, 32, false, 9, 3),
-      MIGAN_KERNEL(0, 128, 64, 32, false, 6, 2),  MIGAN_KERNEL(0, 128, 64, 32, false, 9, 2),
-      MIGAN_KERNEL(0, 128, 128, 32, true, 6, 2),  MIGAN_KERNEL(0, 128, 128, 32, true, 9, 2),
-      MIGAN_KERNEL(0, 128, 64, 32, true, 6, 3),   MIGAN_KERNEL(0, 128, 64, 32, true, 9, 3),
-      MIGAN_KERNEL(0, 128, 64, 32, true, 6, 2),   MIGAN_KERNEL(0, 128, 64, 32, true, 9, 2),
-      // FIR-down layers (MODE 1)
-      MIGAN_KERNEL(1, 64, 256, 16, false, 7, 2),  MIGAN_KERNEL(1, 64, 256, 16, false, 9, 2),
-      MIGAN_KERNEL(1, 64, 128, 16, false, 7, 2),  MIGAN_KERNEL(1, 64, 128, 16, false, 9, 2),
-      MIGAN_KERNEL(1, 64, 64, 16, false, 7, 3),   MIGAN_KERNEL(1, 64, 64, 16, false, 9, 3),
-      MIGAN_KERNEL(1, 64, 64, 16, false, 7, 2),   MIGAN_KERNEL(1, 64, 64, 16, false, 9, 2),
+      // plain layers (MODE 0): main 8x16 tiles (NI 6) and small-resolution multi-image tiles (NI 9)
+      MIGAN_KERNEL(0, 128, 128, 32, false, 6, 2, true, false), MIGAN_KERNEL(0, 128, 128, 32, false, 9, 2, false, false),
+      MIGAN_KERNEL(0, 128, 64, 32, false, 6, 2, true, false),  MIGAN_KERNEL(0, 128, 64, 32, false, 9, 2, false, false),
+      MIGAN_KERNEL(0, 128, 64, 32, false, 6, 2, true, true),
+      MIGAN_KERNEL(0, 128, 128, 32, true, 6, 2, true, false),  MIGAN_KERNEL(0, 128, 128, 32, true, 9, 2, false, false),
+      MIGAN_KERNEL(0, 128, 64, 32, true, 6, 2, true, false),   MIGAN_KERNEL(0, 128, 64, 32, true, 9, 2, false, false),
+      MIGAN_KERNEL(0, 128, 64, 32, true, 6, 2, true, true),
       // FIR-up layers (MODE 2)
-      MIGAN_KERNEL(2, 128, 128, 32, false, 6, 2), MIGAN_KERNEL(2, 128, 128, 32, false, 9, 2),
-      MIGAN_KERNEL(2, 128, 64, 32, false, 6, 3),  MIGAN_KERNEL(2, 128, 64, 32, false, 9, 3),
-      MIGAN_KERNEL(2, 128, 64, 32, false, 6, 2),  MIGAN_KERNEL(2, 128, 64, 32, false, 9, 2),
+      MIGAN_KERNEL(2, 128, 128, 32, false, 6, 2, true, false), MIGAN_KERNEL(2, 128, 128, 32, false, 9, 2, false, false),
+      MIGAN_KERNEL(2, 128, 64, 32, false, 6, 2, true, false),  MIGAN_KERNEL(2, 128, 64, 32, false, 9, 2, false, false),
+      MIGAN_KERNEL(2, 128, 64, 32, false, 6, 2, true, true),
+      // pointwise GEMM (MODE 3): second half of FIR-down layers
+      MIGAN_KERNEL(3, 128, 128, 32, false, 4, 2, true, false), MIGAN_KERNEL(3, 128, 128, 32, false, 4, 2, false, false),
+      MIGAN_KERNEL(3, 128, 128, 32, false, 4, 2, true, true),
+      MIGAN_KERNEL(3, 128, 64, 32, false, 4, 2, true, false),  MIGAN_KERNEL(3, 128, 64, 32, false, 4, 2, false, false),
   };
   return t;
 }
@@ -189,16 +196,55 @@ inline const std::vector<KernelEntry>& kernel_table() {
 inline const KernelEntry& pick_kernel(const Geo& g) {
   for (const auto& e : kernel_table())
     if (e.mode == g.mode && e.MT == g.MT && e.NT == g.NT && e.KC == g.KC && e.fromrgb == g.fromrgb && e.NI == g.NI &&
-        e.MINW == g.MINW)
+        e.MINW == g.MINW && e.maing == g.maing && e.persist == g.persist)
       return e;
   throw Error(MIGAN_EINVAL, "internal: no kernel instantiation for this geometry");
 }
+
+// persistent variants exist where they fit the register budget without spilling
+inline bool has_persistent_variant(const Geo& g) {
+  return g.maing && g.MINW == 2 && ((g.NT == 64 && g.mode != MODE_PW) || (g.mode == MODE_PW && g.NT == 128));
+}
+
+// ---- depthwise + FIR-down kernel (first half of down=2 layers) ----
+struct DwGeo {
+  int lgGH = 2, lgGW = 4, lgIMGS = 0, tiles_x = 1, tiles_y = 1, nkg = 1, kpw = 1, NI = 7;
+  bool maing = true;
+  int off_d = 0, off_w = 0;
+  size_t lds_bytes = 0;
+};
+inline DwGeo choose_dwfir_geo(int c, int res_in) {
+  DwGeo g;
+  MIGAN_CHECK(c % 16 == 0 && res_in >= 8 && (res_in & (res_in - 1)) == 0, MIGAN_EINVAL, "dwfir: bad shape");
+  const int ro = res_in / 2;
+  int GH = 4, GW, IMGS;
+  if (ro >= 16) { GW = 16; IMGS = 1; }
+  else if (ro == 8) { GW = 8; IMGS = 2; }
+  else { GW = 4; IMGS = 4; }
+  g.lgGH = 2; g.lgGW = ilog2(GW); g.lgIMGS = ilog2(IMGS);
+  g.tiles_y = ro / GH; g.tiles_x = ro / GW;
+  g.kpw = (c / 16) % 4 == 0 ? 4 : ((c / 16) % 2 == 0 ? 2 : 1);   // chunks walked per workgroup (software pipelined)
+  g.nkg = (c / 16) / g.kpw;
+  g.maing = (IMGS == 1 && GW == 16);
+  const int npix = IMGS * (2 * GH + 4) * (2 * GW + 4);
+  const int items = cdiv(npix * 4, kThreads);
+  g.NI = g.maing ? 7 : 9;
+  MIGAN_CHECK(items <= g.NI, MIGAN_EINVAL, "internal: dwfir input tile too large");
+  g.off_d = npix * 16;
+  g.off_w = g.off_d + IMGS * (2 * GH + 2) * (2 * GW + 2) * 16;
+  g.lds_bytes = (size_t)(g.off_w + 160) * sizeof(float);
+  return g;
+}
+inline unsigned dwfir_grid(const DwGeo& g, int batch) { return (unsigned)(g.tiles_x * g.tiles_y * cdiv(batch, 1 << g.lgIMGS) * g.nkg); }
+inline const char* dwfir_name(const DwGeo& g) { return g.maing ? "migan::dwfir_kernel<7, true>" : "migan::dwfir_kernel<9, false>"; }
 
 // Raise the dynamic-LDS limit of every instantiation once per process (tiles use up to ~74 KiB).
 inline void prepare_kernels() {
   static bool done = false;
   if (done) return;
   for (const auto& e : kernel_table()) rt_check(rt::allow_dynamic_lds((const void*)e.fn, 96 * 1024), "hipFuncSetAttribute");
+  rt_check(rt::allow_dynamic_lds((const void*)dwfir_kernel<7, true>, 96 * 1024), "hipFuncSetAttribute");
+  rt_check(rt::allow_dynamic_lds((const void*)dwfir_kernel<9, false>, 96 * 1024), "hipFuncSetAttribute");
   done = true;
 }
 
@@ -226,17 +272,39 @@ inline void fill_geo(SepArgs& a, const Geo& g) {
   a.sy = g.sy; a.sx = g.sx; a.off = g.off; a.lgRS = g.lgRS;
   a.off_a = g.off_a; a.off_b = g.off_b; a.off_v = g.off_v; a.off_rgb = g.off_rgb; a.off_w = g.off_w;
   a.b_stride = g.b_stride;
+  a.a_stride = g.a_stride;
   a.prof = prof_buffer();
 }
 
-inline unsigned grid_of(const Geo& g, int batch) {
+inline unsigned tiles_of(const Geo& g, int batch) {
   return (unsigned)(g.tiles_x * g.tiles_y * cdiv(batch, 1 << g.lgIMGS) * g.nchunks);
 }
+// Large launches run a fixed grid of persistent workgroups (2 per CU) that walk the tiles and prefetch
+// their next tile during the current epilogue; small ones keep one tile per workgroup.
+inline bool use_persistent(const Geo& g, int batch, bool fused_rgb) {
+  const int total = (int)tiles_of(g, batch);
+  // measured on MI355X (profiles/): +2..7 % on the 512x512 layers, -7 % when the ToRGB tail is fused
+  return has_persistent_variant(g) && !fused_rgb && total >= tuning().persist_min && total > tuning().persist_grid;
+}
+inline unsigned grid_of(const Geo& g, int batch, bool fused_rgb = false) {
+  return use_persistent(g, batch, fused_rgb) ? (unsigned)tuning().persist_grid : tiles_of(g, batch);
+}
 
-inline void launch_sepconv(const Geo& g, const SepArgs& a, rt::stream_t stream) {
+inline void launch_sepconv(Geo g, const SepArgs& a, rt::stream_t stream) {
   prepare_kernels();
+  const bool fused_rgb = a.trgb_w != nullptr;
+  g.persist = use_persistent(g, a.B, fused_rgb);
   const KernelEntry& k = pick_kernel(g);
-  rt_check(rt::launch(k.fn, a, grid_of(g, a.B), kThreads, g.lds_bytes, stream), k.name);
+  rt_check(rt::launch(k.fn, a, grid_of(g, a.B, fused_rgb), kThreads, g.lds_bytes, stream), k.name);
+}
+
+inline void launch_dwfir(const DwGeo& g, DwFirArgs a, rt::stream_t stream) {
+  prepare_kernels();
+  a.lgGH = g.lgGH; a.lgGW = g.lgGW; a.lgIMGS = g.lgIMGS;
+  a.tiles_x = g.tiles_x; a.tiles_y = g.tiles_y; a.nkg = g.nkg; a.kpw = g.kpw;
+  a.off_d = g.off_d; a.off_w = g.off_w;
+  if (g.maing) rt_check(rt::launch(dwfir_kernel<7, true>, a, dwfir_grid(g, a.B), kThreads, g.lds_bytes, stream), dwfir_name(g));
+  else rt_check(rt::launch(dwfir_kernel<9, false>, a, dwfir_grid(g, a.B), kThreads, g.lds_bytes, stream), dwfir_name(g));
 }
 
 inline void launch_torgb(const RgbArgs& a, rt::stream_t stream) {
@@ -277,8 +345,11 @@ enum : int { BUF_NONE = -1, BUF_X = -2, BUF_Y = -3 };
 
 struct Launch {
   std::string layer, kernel;
+  mutable std::string kernel_last;   // kernel symbol actually launched by the last forward (persistent variant or not)
   bool is_rgb = false;
+  bool is_dwfir = false;
   Geo g;
+  DwGeo dg;
   int cin = 0, cout = 0, res_in = 0, res_out = 0;
   int in_buf = BUF_NONE, out_buf = BUF_NONE, skip_buf = BUF_NONE, imgprev_buf = BUF_NONE, imgout_buf = BUF_NONE;
   int w_dw = -1, b_dw = -1, w_pw = -1, w_noise = -1, w_ns = -1, w_frgb = -1, b_frgb = -1, w_trgb = -1, b_trgb = -1;
@@ -390,6 +461,9 @@ inline void migan_handle::build_plan() {
   }
   std::vector<int> feat(16, BUF_NONE);
   for (int res = R; res >= 4; res /= 2) feat[ilog2(res)] = add_buf("feat" + std::to_string(res), (size_t)res * res * channels_at(res));
+  size_t max_dwt = 16;
+  for (int res = R; res > 4; res /= 2) max_dwt = std::max(max_dwt, (size_t)(res / 2) * (res / 2) * channels_at(res));
+  const int DWT = add_buf("dwfir_tmp", max_dwt);
   int P0 = BUF_NONE, P1 = BUF_NONE, I0 = BUF_NONE, I1 = BUF_NONE;
   if (!debug) {
     P0 = add_buf("act0", max_act);
@@ -421,9 +495,10 @@ inline void migan_handle::build_plan() {
     const double pgemm = (mode == MODE_UP) ? pin : pout;
     L.mfma_flops = 2.0 * cin * cout * pgemm;
     L.flops = L.mfma_flops + 2.0 * 9 * cin * pin;
-    if (mode == MODE_DOWN) L.flops += 2.0 * 16 * cin * pout;
+    if (mode == MODE_PW) L.flops = L.mfma_flops;     // depthwise + FIR are accounted to the dwfir launch
     if (mode == MODE_UP) L.flops += 2.0 * 4 * cout * pout;
     L.bytes = 4.0 * ((fromrgb ? 4.0 : (double)cin) * pin + (double)cout * pout + (skip_buf != BUF_NONE ? (double)cout * pout : 0.0));
+    if (mode == MODE_PW) L.bytes = 4.0 * (double)cout * pout;   // algorithmic input read is accounted to the dwfir launch
     if (fromrgb) L.flops += 2.0 * 4 * cin * pin;
     L.wgs_batch1 = (int)grid_of(L.g, 1);
     launches.push_back(L);
@@ -445,8 +520,25 @@ inline void migan_handle::build_plan() {
     if (debug) debug_tensors.back().second = feat[ilog2(res)];
     if (res > 4) {
       const int cn = channels_at(res / 2);
+      // down=2 layer = depthwise+FIR kernel (writes the half-resolution cin-channel tensor) + pointwise GEMM
+      {
+        Launch L;
+        L.layer = b + ".conv2.dwfir";
+        L.is_dwfir = true;
+        L.dg = choose_dwfir_geo(c, res);
+        L.kernel = dwfir_name(L.dg);
+        L.cin = c; L.cout = c; L.res_in = res; L.res_out = res / 2;
+        L.in_buf = feat[ilog2(res)]; L.out_buf = DWT;
+        L.w_dw = slot_index(b + ".conv2.conv1.weight");
+        L.b_dw = slot_index(b + ".conv2.conv1.bias");
+        const double pin = (double)res * res, pout = pin / 4;
+        L.flops = 2.0 * 9 * c * pin + 2.0 * 16 * c * pout;
+        L.bytes = 4.0 * c * pin;
+        L.wgs_batch1 = (int)dwfir_grid(L.dg, 1);
+        launches.push_back(L);
+      }
       const int ob = out_for(b + ".conv2", res / 2, cn, P0);
-      add_sep(b + ".conv2", MODE_DOWN, c, cn, res, res / 2, false, false, feat[ilog2(res)], ob, BUF_NONE);
+      add_sep(b + ".conv2", MODE_PW, c, cn, res / 2, res / 2, false, false, DWT, ob, BUF_NONE);
       cur = ob;
     } else {
       const int ob = out_for(b + ".conv2", 4, c, P0);
@@ -533,7 +625,12 @@ inline void migan_handle::forward(const float* x, float* y, int batch, void* ws,
   for (size_t li = 0; li < launches.size(); ++li) {
     const Launch& L = launches[li];
     if (timed) rt_check(rt::event_record(events[2 * li], stream), "hipEventRecord");
-    if (L.is_rgb) {
+    if (L.is_dwfir) {
+      DwFirArgs a{};
+      a.x = bptr(L.in_buf); a.y = bptr(L.out_buf); a.wdw = wptr(L.w_dw); a.bdw = wptr(L.b_dw);
+      a.B = batch; a.H = L.res_in; a.W = L.res_in; a.C = L.cin;
+      launch_dwfir(L.dg, a, stream);
+    } else if (L.is_rgb) {
       RgbArgs a{};
       a.x = bptr(L.in_buf); a.w = wptr(L.w_trgb); a.b = wptr(L.b_trgb);
       a.img_prev = bptr(L.imgprev_buf); a.img_out = bptr(L.imgout_buf);
@@ -550,6 +647,9 @@ inline void migan_handle::forward(const float* x, float* y, int batch, void* ws,
       a.B = batch; a.H = L.res_in; a.W = L.res_in; a.CI = L.cin; a.CO = L.cout; a.HO = L.res_out; a.WO = L.res_out;
       fill_geo(a, L.g);
       launch_sepconv(L.g, a, stream);
+      Geo gl = L.g;
+      gl.persist = use_persistent(gl, batch, a.trgb_w != nullptr);
+      L.kernel_last = pick_kernel(gl).name;
     }
     if (timed) rt_check(rt::event_record(events[2 * li + 1], stream), "hipEventRecord");
 #ifdef MIGAN_PHASE_PROF
@@ -720,7 +820,7 @@ int migan_launch_info(const migan_handle* h, int index, const char** layer, cons
   MIGAN_CHECK(index >= 0 && index < (int)h->launches.size(), MIGAN_EINVAL, "launch index out of range");
   const migan::Launch& L = h->launches[index];
   if (layer) *layer = L.layer.c_str();
-  if (kernel) *kernel = L.kernel.c_str();
+  if (kernel) *kernel = L.kernel_last.empty() ? L.kernel.c_str() : L.kernel_last.c_str();
   if (flops) *flops = L.flops;
   if (mfma_flops) *mfma_flops = L.mfma_flops;
   if (bytes) *bytes = L.bytes;
@@ -748,7 +848,7 @@ int migan_debug_tensor(const migan_handle* h, int batch, const char* layer, size
     for (const auto& L : h->launches) {
       if (is_img) {
         if (L.imgout_buf == kv.second) { shape[0] = batch; shape[1] = 3; shape[2] = L.res_out; shape[3] = L.res_out; return MIGAN_OK; }
-      } else if (!L.is_rgb && L.layer == n) {
+      } else if (!L.is_rgb && !L.is_dwfir && L.layer == n) {
         shape[0] = batch; shape[1] = L.res_out; shape[2] = L.res_out; shape[3] = L.cout;
         return MIGAN_OK;
       }
@@ -766,20 +866,36 @@ int migan_sepconv_forward(const migan_sepconv_desc* d, void* stream) {
   MIGAN_CHECK((d->down == 1 || d->down == 2) && (d->up == 1 || d->up == 2) && !(d->down == 2 && d->up == 2), MIGAN_EINVAL,
               "down/up must be 1 or 2 and not both 2");
   MIGAN_CHECK(d->batch > 0, MIGAN_EINVAL, "empty batch");
-  const int mode = d->down == 2 ? MODE_DOWN : (d->up == 2 ? MODE_UP : MODE_NORMAL);
   const int res_out = d->down == 2 ? d->res_in / 2 : (d->up == 2 ? d->res_in * 2 : d->res_in);
-  const Geo g = choose_geo(mode, d->cin, d->cout, d->res_in, d->fromrgb_weight != nullptr);
+  MIGAN_CHECK(d->noise_const == nullptr || d->noise_strength != nullptr, MIGAN_EINVAL, "noise_const without noise_strength");
+  const float* gemm_in = (const float*)d->x;
+  int mode = d->up == 2 ? MODE_UP : MODE_NORMAL, gemm_res = d->res_in;
+  if (d->down == 2) {
+    // reference :155-161: depthwise+act+FIR at res_in (dwfir kernel), then the 1x1 at res_in/2
+    MIGAN_CHECK(d->fromrgb_weight == nullptr, MIGAN_EINVAL, "fromrgb is only fused into plain layers");
+    const size_t need = (size_t)d->batch * res_out * res_out * d->cin * sizeof(float);
+    MIGAN_CHECK(d->scratch != nullptr && d->scratch_bytes >= need, MIGAN_EINVAL,
+                "down=2 needs scratch of batch*(res_in/2)^2*cin floats");
+    const DwGeo dg = choose_dwfir_geo(d->cin, d->res_in);
+    DwFirArgs fa{};
+    fa.x = (const float*)d->x; fa.y = (float*)d->scratch; fa.wdw = (const float*)d->conv1_weight; fa.bdw = (const float*)d->conv1_bias;
+    fa.B = d->batch; fa.H = d->res_in; fa.W = d->res_in; fa.C = d->cin;
+    launch_dwfir(dg, fa, (rt::stream_t)stream);
+    gemm_in = (const float*)d->scratch;
+    mode = MODE_PW;
+    gemm_res = res_out;
+  }
+  const Geo g = choose_geo(mode, d->cin, d->cout, gemm_res, d->fromrgb_weight != nullptr);
   MIGAN_CHECK(d->torgb_weight == nullptr || (g.nchunks == 1 && mode != MODE_UP && d->img_out), MIGAN_EINVAL,
               "fused ToRGB needs cout <= 128, up == 1 and img_out");
-  MIGAN_CHECK(d->noise_const == nullptr || d->noise_strength != nullptr, MIGAN_EINVAL, "noise_const without noise_strength");
   SepArgs a{};
-  a.x = (const float*)d->x; a.y = (float*)d->y; a.skip = (const float*)d->skip;
+  a.x = gemm_in; a.y = (float*)d->y; a.skip = (const float*)d->skip;
   a.wdw = (const float*)d->conv1_weight; a.bdw = (const float*)d->conv1_bias; a.wpw = (const float*)d->conv2_weight;
   a.noise = (const float*)d->noise_const; a.noise_strength = (const float*)d->noise_strength;
   a.frgb_w = (const float*)d->fromrgb_weight; a.frgb_b = (const float*)d->fromrgb_bias;
   a.trgb_w = (const float*)d->torgb_weight; a.trgb_b = (const float*)d->torgb_bias;
   a.img_prev = (const float*)d->img_prev; a.img_out = (float*)d->img_out;
-  a.B = d->batch; a.H = d->res_in; a.W = d->res_in; a.CI = d->cin; a.CO = d->cout; a.HO = res_out; a.WO = res_out;
+  a.B = d->batch; a.H = gemm_res; a.W = gemm_res; a.CI = d->cin; a.CO = d->cout; a.HO = res_out; a.WO = res_out;
   fill_geo(a, g);
   launch_sepconv(g, a, (rt::stream_t)stream);
   MIGAN_API_END

@@ -36,7 +36,9 @@ typedef float f16v __attribute__((ext_vector_type(16)));
 
 constexpr int kThreads = 256;          // 4 wave64 per workgroup, one per SIMD
 
-enum : int { MODE_NORMAL = 0, MODE_DOWN = 1, MODE_UP = 2 };
+enum : int { MODE_NORMAL = 0, MODE_DOWN = 1, MODE_UP = 2, MODE_PW = 3 };
+struct TrueT { static constexpr bool value = true; };
+struct FalseT { static constexpr bool value = false; };
 
 struct SepArgs {
   // activations
@@ -66,6 +68,7 @@ struct SepArgs {
   int lgRS;                        // log2(row segments per column) of the depthwise stage (NORMAL/UP)
   int off_a, off_b, off_v, off_rgb, off_w;   // LDS carve, in floats
   int b_stride;                    // floats between the two 1x1-weight buffers (0 = single buffered)
+  int a_stride;                    // MODE_PW: floats between the two A-operand buffers
 };
 
 struct RgbArgs {
@@ -145,10 +148,13 @@ MIGAN_DEVICE MIGAN_INLINE float up_prev3(const float* plane, int hp, int wp, int
 //   FROMRGB: input tile is act(fromrgb(network input)) computed on the fly (encoder first block)
 //   NI     : float4 input-tile items per thread per K chunk (prefetch registers)
 //   MINW   : launch bound, minimum waves per SIMD (= workgroups per CU)
+//   MAING  : compile-time tile geometry (8x16 pixels, one image per tile)
+//   PERSIST: workgroups walk several tiles and prefetch the next tile during the epilogue
 //
 // Waves are laid out 2x2 over the MT x NT tile; each wave owns (MT/2)x(NT/2) as 32x32 MFMA tiles.
-template <int MODE, int MT, int NT, int KC, bool FROMRGB, int NI, int MINW>
+template <int MODE, int MT, int NT, int KC, bool FROMRGB, int NI, int MINW, bool MAING, bool PERSIST>
 MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, MINW) sepconv_kernel(const SepArgs p) {
+  static_assert(MODE != MODE_DOWN, "FIR-down layers run as dwfir_kernel + a MODE_PW pointwise GEMM");
   MIGAN_DYN_SMEM(smem);
 
   constexpr int QC = KC / 4;                       // float4 groups per pixel in a K chunk
@@ -167,7 +173,6 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, MINW) sepconv_kernel(const SepArgs p)
   constexpr int NW4 = KC * 10 / 4;                 // float4s of depthwise weights (9 taps) + bias per chunk
   constexpr int NF4 = FROMRGB ? KC * 5 / 4 : 0;    // float4s of fromrgb weights (4 per channel) + bias
   constexpr int SEGH = 4;                          // output rows per depthwise strip (NORMAL / UP)
-  constexpr int DGH = 4;                           // GEMM-grid rows of a DOWN tile
 
   const float* __restrict__ gx_ = p.x;
   float* __restrict__ gy_ = p.y;
@@ -186,137 +191,168 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, MINW) sepconv_kernel(const SepArgs p)
   // Main tiles (every layer at >= 16x16 output) have compile-time geometry so the index math below
   // folds to shifts and multiply-highs; the NI == 9 instantiations serve the small-resolution layers
   // (several images per tile) with run-time geometry.
-  constexpr bool MAINGEO = (NI != 9);
-  const int lgGH = MAINGEO ? (MODE == MODE_DOWN ? 2 : 3) : p.lgGH;
+  constexpr bool MAINGEO = MAING;
+  const int lgGH = MAINGEO ? 3 : p.lgGH;
   const int lgGW = MAINGEO ? 4 : p.lgGW;
   const int lgIMGS = MAINGEO ? 0 : p.lgIMGS;
   const int lgRS = MAINGEO ? 1 : p.lgRS;
   const int GH = 1 << lgGH, GW = 1 << lgGW, IMGS = 1 << lgIMGS;
 
-  // ---- which tile am I -------------------------------------------------------------------
-  int t = xcd_remap((int)blockIdx.x, (int)gridDim.x);
-  const int nch = t % p.nchunks; t /= p.nchunks;
-  const int tx = t % p.tiles_x;  t /= p.tiles_x;
-  const int ty = t % p.tiles_y;
-  const int bgrp = t / p.tiles_y;
-  const int n0 = nch * NT;
-  const int b0 = bgrp << lgIMGS;
-  const int gy0 = ty * p.sy - p.off, gx0 = tx * p.sx - p.off;   // GEMM grid origin (GEMM-resolution image coords)
+  // ---- persistent tile schedule -------------------------------------------------------------
+  // Logical tiles (n-chunk fastest, then x, y, image group) are split into 8 contiguous ranges, one
+  // per XCD (block b runs on XCD b%8, each XCD has a private L2: halo rows shared by neighbouring
+  // tiles and the Cout chunks of one tile then hit the same L2).  The workgroups of an XCD walk
+  // their range with a stride equal to their count, so at any moment an XCD works on consecutive
+  // tiles.  With gridDim == #tiles every workgroup does exactly one tile.
+  const int ntiles = p.tiles_x * p.tiles_y * p.nchunks * ((p.B + IMGS - 1) >> lgIMGS);
+  const int xcd = (int)blockIdx.x & 7;
+  const int tq = ntiles >> 3, tr = ntiles & 7;
+  const int tcnt = tq + (xcd < tr ? 1 : 0);                                  // tiles of this XCD
+  const int tbase = xcd < tr ? xcd * (tq + 1) : tr * (tq + 1) + (xcd - tr) * tq;
+  const int tstep = ((int)gridDim.x + 7 - xcd) >> 3;                         // workgroups on this XCD
+  int tl = (int)blockIdx.x >> 3;                                             // my first tile in the range
+  auto decode = [&](int t, int& n0_, int& b0_, int& gy0_, int& gx0_) {
+    const int nch = t % p.nchunks; t /= p.nchunks;
+    const int tx = t % p.tiles_x;  t /= p.tiles_x;
+    const int ty = t % p.tiles_y;
+    n0_ = nch * NT;
+    b0_ = (t / p.tiles_y) << lgIMGS;
+    gy0_ = ty * p.sy - p.off;                        // GEMM grid origin (GEMM-resolution image coords)
+    gx0_ = tx * p.sx - p.off;
+  };
+  int n0, b0, gy0, gx0;
+  decode(tbase + tl, n0, b0, gy0, gx0);
 
   // ---- LDS carve --------------------------------------------------------------------------
   float* in_s = smem;                       // [npix_in][KC]
   float* a_s = smem + p.off_a;              // [MT][AS]
   float* b_s = smem + p.off_b;              // [NT][AS] x (1 or 2 buffers)
-  float* v_s = smem + p.off_v;              // DOWN: [IMGS][GH][2GW+2][KC]
+  float* v_s = smem + p.off_v;              // DOWN: depthwise grid [IMGS][2GH+2][2GW+2][KC]
   float* rgb_s = smem + p.off_rgb;          // FROMRGB: [npix_in][4]
   float* w_s = smem + p.off_w;              // [KC*9] depthwise taps, [KC] bias, (FROMRGB: [KC*4] + [KC])
   float* g_s = smem;                        // after the K loop: [MT][GS], aliases the buffers above
   float* racc_s = smem + MT * GS;           // fused ToRGB partial sums [MT][4]
 
   // input-tile geometry (input-resolution coordinates)
-  const int IGH = (MODE == MODE_DOWN) ? 2 * GH + 4 : GH + 2;
-  const int IGW = (MODE == MODE_DOWN) ? 2 * GW + 4 : GW + 2;
-  const int iy0 = (MODE == MODE_DOWN) ? 2 * gy0 - 2 : gy0 - 1;
-  const int ix0 = (MODE == MODE_DOWN) ? 2 * gx0 - 2 : gx0 - 1;
+  constexpr int HALO = (MODE == MODE_PW) ? 0 : 1;
+  const int IGH = GH + 2 * HALO, IGW = GW + 2 * HALO;
   const int npix_in = IMGS * IGH * IGW;
   const int nitems_in = npix_in * QC;
 
-  // per-thread descriptors of its input items (constant across K chunks).  Item i = tid + j*256 is
-  // float4 number i of the LDS tile ([pixel][KC/4]); goff = element offset of its source inside
-  // image group b0 (0 when the pixel is padding: loaded anyway, zeroed on the way to LDS, which is
-  // the conv zero padding of reference :126); bit j of `vmask` = real pixel, of `emask` = item exists.
-  unsigned goff[NI];
-  unsigned vmask = 0, emask = 0;
+  // per-thread descriptors of its input items (constant across the K chunks of a tile).  Item
+  // i = tid + j*256 is float4 number i of the LDS tile ([pixel][KC/4]); goff = element offset of
+  // its source inside image group b0 (0 when the pixel is padding: loaded anyway, zeroed on the way
+  // to LDS, which is the conv zero padding of reference :126); bit j of `vmask` = real pixel, of
+  // `emask` = item exists.
+  unsigned emask = 0;
 #pragma unroll
-  for (int j = 0; j < NI; ++j) {
-    const int i = tid + j * kThreads;
-    unsigned g = 0;
-    if (i < nitems_in) {
-      emask |= 1u << j;
-      const int c4 = i & (QC - 1);
-      const int pix = i >> LG_QC;
-      const int ix = pix % IGW;
-      const int r = pix / IGW;
-      const int iy = r % IGH, img = r / IGH;
-      const int yy = iy0 + iy, xx = ix0 + ix;
-      if (yy >= 0 && yy < p.H && xx >= 0 && xx < p.W && (b0 + img) < p.B) {
-        vmask |= 1u << j;
-        g = FROMRGB ? 0u : (unsigned)(((img * p.H + yy) * p.W + xx) * p.CI + c4 * 4);
+  for (int j = 0; j < NI; ++j)
+    if (tid + j * kThreads < nitems_in) emask |= 1u << j;
+  auto make_items = [&](int b0_, int gy0_, int gx0_, unsigned (&goff_)[NI], unsigned& vmask_) {
+    vmask_ = 0;
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      const int i = tid + j * kThreads;
+      unsigned g = 0;
+      if (i < nitems_in) {
+        const int c4 = i & (QC - 1);
+        const int pix = i >> LG_QC;
+        const int ix = pix % IGW;
+        const int r = pix / IGW;
+        const int iy = r % IGH, img = r / IGH;
+        const int yy = gy0_ - HALO + iy, xx = gx0_ - HALO + ix;
+        if (yy >= 0 && yy < p.H && xx >= 0 && xx < p.W && (b0_ + img) < p.B) {
+          vmask_ |= 1u << j;
+          g = FROMRGB ? 0u : (unsigned)(((img * p.H + yy) * p.W + xx) * p.CI + c4 * 4);
+        }
       }
+      goff_[j] = g;
     }
-    goff[j] = g;
-  }
-  const float* __restrict__ xb = gx_ + (size_t)b0 * p.H * p.W * (FROMRGB ? 4 : p.CI);
+  };
   // 1x1 weight tile items: n = i / QC rows of conv2.weight, 4 consecutive input channels
-  unsigned boff[NB];
+  auto make_boff = [&](int n0_, unsigned (&boff_)[NB]) {
 #pragma unroll
-  for (int j = 0; j < NB; ++j) {
-    const int i = tid + j * kThreads;
-    boff[j] = (unsigned)((n0 + (i >> LG_QC)) * p.CI + (i & (QC - 1)) * 4);
-  }
-
-  if constexpr (FROMRGB) {
-    // raw 4-channel network input (NCHW) of the halo tile, loaded once
-    for (int pix = tid; pix < npix_in; pix += kThreads) {
+    for (int j = 0; j < NB; ++j) {
+      const int i = tid + j * kThreads;
+      boff_[j] = (unsigned)((n0_ + (i >> LG_QC)) * p.CI + (i & (QC - 1)) * 4);
+    }
+  };
+  // FROMRGB: raw 4-channel network input (NCHW) of this thread's halo pixel (npix_in <= 256)
+  auto load_raw = [&](int b0_, int gy0_, int gx0_) -> f4 {
+    f4 v = {0.f, 0.f, 0.f, 0.f};
+    const int pix = tid;
+    if (pix < npix_in) {
       const int ix = pix % IGW;
       const int r = pix / IGW;
       const int iy = r % IGH, img = r / IGH;
-      const int yy = iy0 + iy, xx = ix0 + ix;
-      f4 v = {0.f, 0.f, 0.f, 0.f};
-      if (yy >= 0 && yy < p.H && xx >= 0 && xx < p.W && (b0 + img) < p.B) {
-        const float* src = xb + ((size_t)img * 4 * p.H + yy) * p.W + xx;
+      const int yy = gy0_ - HALO + iy, xx = gx0_ - HALO + ix;
+      if (yy >= 0 && yy < p.H && xx >= 0 && xx < p.W && (b0_ + img) < p.B) {
+        const float* src = gx_ + ((size_t)(b0_ + img) * 4 * p.H + yy) * p.W + xx;
         const size_t plane = (size_t)p.H * p.W;
         v = f4{src[0], src[plane], src[2 * plane], src[3 * plane]};
       }
-      st4(rgb_s + pix * 4, v);
     }
-  }
+    return v;
+  };
+  unsigned goff[NI], vmask, boff[NB];
+  make_items(b0, gy0, gx0, goff, vmask);
+  make_boff(n0, boff);
 
   f16v acc[MTI][NTI];
+
+  // prefetch registers: one K chunk of the input tile, of the 1x1 weights and of the small weights
+  f4 rin[NI], rb[NB], rw, rraw;
+  // every global access below is (wave-uniform base pointer, held in SGPRs) + (32-bit lane offset):
+  // no 64-bit VALU address arithmetic in the K loop.
+  auto issue_loads = [&](int b0_, const unsigned (&goff_)[NI], const unsigned (&boff_)[NB], int k0) {
+    if constexpr (!FROMRGB) {
+      const float* __restrict__ xk = gx_ + (size_t)b0_ * p.H * p.W * p.CI + k0;
+#pragma unroll
+      for (int j = 0; j < NI; ++j) rin[j] = ld4(xk + goff_[j]);
+    }
+    const float* __restrict__ wk = gwpw + k0;
+#pragma unroll
+    for (int j = 0; j < NB; ++j) rb[j] = ld4(wk + boff_[j]);
+    // depthwise taps of channels [k0,k0+KC) are KC*9 contiguous floats of conv1.weight, then the bias
+    if constexpr (MODE != MODE_PW) {
+      if (tid < KC * 9 / 4) rw = ld4(gwdw + (size_t)k0 * 9 + (unsigned)(tid * 4));
+      else if (tid < NW4) rw = ld4(gbdw + k0 + (unsigned)((tid - KC * 9 / 4) * 4));
+    }
+    if constexpr (FROMRGB) {
+      if (tid >= NW4 && tid < NW4 + KC) rw = ld4(p.frgb_w + (size_t)k0 * 4 + (unsigned)((tid - NW4) * 4));
+      else if (tid >= NW4 + KC && tid < NW4 + NF4) rw = ld4(p.frgb_b + k0 + (unsigned)((tid - NW4 - KC) * 4));
+    }
+  };
+
+  PROF_MARK(0);
+  const int nkc = p.CI / KC;
+  issue_loads(b0, goff, boff, 0);
+  if constexpr (FROMRGB) rraw = load_raw(b0, gy0, gx0);
+
+  // =================================== tile loop ===========================================
+  for (;;) {
+  const bool has_next = PERSIST && (tl + tstep < tcnt);   // PERSIST = false: exactly one tile per workgroup
+  int n0n = 0, b0n = 0, gy0n = 0, gx0n = 0;
+  unsigned goffn[NI], vmaskn = 0, boffn[NB];
 #pragma unroll
   for (int i = 0; i < MTI; ++i)
 #pragma unroll
     for (int j = 0; j < NTI; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-
-  // prefetch registers: one K chunk of the input tile, of the 1x1 weights and of the small weights
-  f4 rin[NI], rb[NB], rw;
-  // every global access below is (wave-uniform base pointer, held in SGPRs) + (32-bit lane offset):
-  // no 64-bit VALU address arithmetic in the K loop.
-  auto issue_loads = [&](int k0) {
-    if constexpr (!FROMRGB) {
-      const float* __restrict__ xk = xb + k0;
-#pragma unroll
-      for (int j = 0; j < NI; ++j) rin[j] = ld4(xk + goff[j]);
-    }
-    const float* __restrict__ wk = gwpw + k0;
-#pragma unroll
-    for (int j = 0; j < NB; ++j) rb[j] = ld4(wk + boff[j]);
-    // depthwise taps of channels [k0,k0+KC) are KC*9 contiguous floats of conv1.weight, then the bias
-    if (tid < KC * 9 / 4) rw = ld4(gwdw + (size_t)k0 * 9 + (unsigned)(tid * 4));
-    else if (tid < NW4) rw = ld4(gbdw + k0 + (unsigned)((tid - KC * 9 / 4) * 4));
-    if constexpr (FROMRGB) {
-      if (tid >= NW4 && tid < NW4 + KC) rw = ld4(p.frgb_w + (size_t)k0 * 4 + (unsigned)((tid - NW4) * 4));
-      else if (tid >= NW4 + KC && tid < NW4 + NF4) rw = ld4(p.frgb_b + k0 + (unsigned)((tid - NW4 - KC) * 4));
-    }
-  };
   // interior tiles (no padding anywhere in the wave's items) skip the zero-fill selects
   const bool wave_all_valid = __all(vmask == emask);
 
-  PROF_MARK(0);
   // ======================================= K loop ==========================================
-  const int nkc = p.CI / KC;
-  issue_loads(0);
-  if constexpr (FROMRGB) __syncthreads();           // rgb_s visible to the tile builder below
   for (int c = 0; c < nkc; ++c) {
     const int k0 = c * KC;
     float* bcur = b_s + (c & 1) * p.b_stride;
-    if (p.b_stride == 0) __syncthreads();           // single weight buffer: wait for the MFMAs of chunk c-1
+    if (p.b_stride == 0 || (MODE == MODE_PW && p.a_stride == 0)) __syncthreads();   // single buffers: wait for the MFMAs of chunk c-1
 
     // ---- S1: prefetched chunk -> LDS -----------------------------------------------------------
     // depthwise taps go to LDS tap-major ([9][KC]) so the strip below reads one float4 per tap
-    if (tid < KC * 9 / 4) {
+    if constexpr (MODE == MODE_PW) {
+    } else if (tid < KC * 9 / 4) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int f = tid * 4 + e;                   // flat index into [KC][9]
@@ -331,7 +367,8 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, MINW) sepconv_kernel(const SepArgs p)
       st4(bcur + (i >> LG_QC) * AS + (i & (QC - 1)) * 4, rb[j]);
     }
     if constexpr (FROMRGB) {
-      __syncthreads();                              // w_s (fromrgb weights of this chunk) visible
+      if (c == 0 && tid < npix_in) st4(rgb_s + tid * 4, rraw);
+      __syncthreads();                              // w_s (fromrgb weights of this chunk) and rgb_s visible
       // x = act(fromrgb(img)) (reference :194-195), 4 -> CI pointwise with bias, per halo pixel
 #pragma unroll
       for (int j = 0; j < NI; ++j) {
@@ -355,7 +392,17 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, MINW) sepconv_kernel(const SepArgs p)
         }
       }
     } else {
-      if (wave_all_valid) {
+      if constexpr (MODE == MODE_PW) {
+        // pointwise GEMM: the input pixels ARE the A operand rows (item i = row i/QC, k-quad i%QC)
+        float* acur = a_s + (c & 1) * p.a_stride;
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+          const int i = tid + j * kThreads;
+          f4 v = rin[j];
+          if (!(vmask & (1u << j))) v = f4{0.f, 0.f, 0.f, 0.f};
+          st4(acur + (i >> LG_QC) * AS + (i & (QC - 1)) * 4, v);
+        }
+      } else if (wave_all_valid) {
 #pragma unroll
         for (int j = 0; j < NI; ++j)
           if (emask & (1u << j)) st4(in_s + (tid + j * kThreads) * 4, rin[j]);
@@ -372,13 +419,22 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, MINW) sepconv_kernel(const SepArgs p)
     }
     __syncthreads();
     PROF_MARK(1);
-    if (c + 1 < nkc) issue_loads(k0 + KC);          // in flight during the depthwise stage and the MFMAs
+    if (c + 1 < nkc) {
+      issue_loads(b0, goff, boff, k0 + KC);         // in flight during the depthwise stage and the MFMAs
+    } else if (has_next) {
+      // last chunk: prefetch the first chunk of my NEXT tile; it lands during the MFMAs and the epilogue
+      decode(tbase + tl + tstep, n0n, b0n, gy0n, gx0n);
+      make_items(b0n, gy0n, gx0n, goffn, vmaskn);
+      make_boff(n0n, boffn);
+      issue_loads(b0n, goffn, boffn, 0);
+      if constexpr (FROMRGB) rraw = load_raw(b0n, gy0n, gx0n);
+    }
 
     // ---- S2: depthwise 3x3 + bias + act (+ FIR down) -> A operand in LDS --------------------
     // One thread walks a column of the tile for 4 channels.  Every input row it reads (3 float4
     // from LDS) is scattered into three running sums (the outputs it is the bottom / middle / top
     // tap row of), so each LDS value is read once per column and no register window is kept.
-    if constexpr (MODE != MODE_DOWN) {
+    if constexpr (MODE != MODE_PW) {
       const int RS = 1 << lgRS;
       const int ncols = (IMGS * GW * QC) << lgRS;
       for (int it = tid; it < ncols; it += kThreads) {
@@ -414,64 +470,8 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, MINW) sepconv_kernel(const SepArgs p)
           st4(a_s + (mbase + (o << lgGW)) * AS + c4 * 4, act4(sacc));
         }
       }
-    } else {
-      // DOWN: column of the (2GH+2)x(2GW+2) high-resolution depthwise grid; the vertical half of the
-      // separable 4x4 FIR ([1,3,3,1]/8 per axis, stride 2, zero pad 1; reference :58-76) is folded
-      // into the walk, the horizontal half runs as a second pass over v_s.
-      const int DW = 2 * GW + 2;
-      const int ncols = IMGS * DW * QC;
-      for (int it = tid; it < ncols; it += kThreads) {
-        const int c4 = it & (QC - 1);
-        const int r = it >> LG_QC;
-        const int dx = r % DW, img = r / DW;
-        const int xim = 2 * gx0 - 1 + dx;
-        const bool colin = xim >= 0 && xim < p.W;
-        f4 w[9];
-#pragma unroll
-        for (int tap = 0; tap < 9; ++tap) w[tap] = ld4(w_s + tap * KC + c4 * 4);
-        const f4 bias = ld4(w_s + KC * 9 + c4 * 4);
-        f4 s2 = bias, s1 = bias, s0 = bias;
-        f4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = {0.f, 0.f, 0.f, 0.f};
-        const float* ip = in_s + ((img * IGH) * IGW + dx) * KC + c4 * 4;
-        const int yim0 = 2 * gy0 - 1;
-#pragma unroll 2
-        for (int I = 0; I < 2 * DGH + 4; ++I) {
-          const f4 L = ld4(ip), M = ld4(ip + KC), R = ld4(ip + 2 * KC);
-          ip += IGW * KC;
-          s2 += w[6] * L + w[7] * M + w[8] * R;
-          s1 += w[3] * L + w[4] * M + w[5] * R;
-          s0 += w[0] * L + w[1] * M + w[2] * R;
-          if (I >= 2) {
-            const int dy = I - 2;
-            const int yim = yim0 + dy;
-            f4 d = {0.f, 0.f, 0.f, 0.f};                        // FIR zero padding outside the image
-            if (colin && yim >= 0 && yim < p.H) d = act4(s2);
-            if ((dy & 1) == 0) {          // d-row 2j: tap 0 of output j, tap 2 of output j-1
-              v1 = 0.125f * d;
-              v0 += 0.375f * d;
-            } else {                      // d-row 2j+1: tap 1 of output j, tap 3 of output j-1 (completes it)
-              v1 += 0.375f * d;
-              v0 += 0.125f * d;
-              const int oy = (dy >> 1) - 1;
-              if (oy >= 0) st4(v_s + (((img << lgGH) + oy) * DW + dx) * KC + c4 * 4, v0);
-              v0 = v1;
-            }
-          }
-          s2 = s1; s1 = s0; s0 = bias;
-        }
-      }
       __syncthreads();
-      for (int it = tid; it < MT * QC; it += kThreads) {
-        const int c4 = it & (QC - 1);
-        const int m = it >> LG_QC;
-        const int ox = m & (GW - 1);
-        const int rr = m >> lgGW;                 // img*GH + oy
-        const float* vp = v_s + (rr * DW + 2 * ox) * KC + c4 * 4;
-        const f4 a = 0.125f * ld4(vp) + 0.375f * ld4(vp + KC) + 0.375f * ld4(vp + 2 * KC) + 0.125f * ld4(vp + 3 * KC);
-        st4(a_s + m * AS + c4 * 4, a);
-      }
     }
-    __syncthreads();
     PROF_MARK(2);
 
     // ---- S3: acc += A[MT x KC] * W^T[KC x NT] on the matrix cores ---------------------------
@@ -479,7 +479,7 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, MINW) sepconv_kernel(const SepArgs p)
     // reads 4 consecutive k with one ds_read_b128; the two lane halves take k = 8kk+4*half+t, the
     // same for A and B, so any assignment of k to (half,t) sums the full K.
     {
-      const float* ap = a_s + (wm * WROWS + l31) * AS + 4 * half;
+      const float* ap = a_s + (MODE == MODE_PW ? (c & 1) * p.a_stride : 0) + (wm * WROWS + l31) * AS + 4 * half;
       const float* bp = bcur + (wn * WCOLS + l31) * AS + 4 * half;
 #pragma unroll
       for (int kk = 0; kk < KC / 8; ++kk) {
@@ -501,6 +501,13 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, MINW) sepconv_kernel(const SepArgs p)
   }
 
   // ======================================= epilogue ========================================
+  // `tide` is the thread id laundered through an empty asm: everything the epilogue derives from it
+  // is then recomputed per tile instead of being hoisted above the K loop by LICM (which would keep
+  // ~100 loop-invariant epilogue addresses live in VGPRs across the MFMA loop and force spills).
+  int tide = tid;
+  MIGAN_OPAQUE(tide);
+  const int lanee = tide & 63, wavee = tide >> 6;
+  const int wme = wavee >> 1, wne = wavee & 1, l31e = lanee & 31, halfe = lanee >> 5;
   __syncthreads();                       // all waves done with a_s/b_s before g_s overwrites them
   // accumulator fragment -> LDS result tile.  C/D layout of the 32x32 MFMA: lane holds column
   // l&31, rows (r&3) + 8*(r>>2) + 4*(l>>5), r = 0..15.
@@ -510,8 +517,8 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, MINW) sepconv_kernel(const SepArgs p)
     for (int j = 0; j < NTI; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int row = wm * WROWS + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        const int col = wn * WCOLS + j * 32 + l31;
+        const int row = wme * WROWS + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * halfe;
+        const int col = wne * WCOLS + j * 32 + l31e;
         float v = acc[i][j][r];
         if constexpr (MODE == MODE_UP) {
           // halo pixels outside the low-resolution image contribute zeros to the upsampling FIR
@@ -535,8 +542,8 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, MINW) sepconv_kernel(const SepArgs p)
   // the main geometry the pixel offset of item k is a compile-time function of k, so every global
   // address is (uniform pointer advanced per item in SGPRs) + (one 32-bit lane offset computed once).
   constexpr int STEP = kThreads >> LG_QN;
-  const int c4 = tid & (QN - 1);
-  const int m0 = tid >> LG_QN;
+  const int c4 = tide & (QN - 1);
+  const int m0 = tide >> LG_QN;
   const int gxt = m0 & (GW - 1), gyt = (m0 >> lgGW) & (GH - 1);
   const size_t img_elems = (size_t)p.HO * p.WO * p.CO;
   float* __restrict__ yb = gy_ + (size_t)b0 * img_elems;
@@ -552,6 +559,8 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, MINW) sepconv_kernel(const SepArgs p)
     }
     const unsigned pix_t = (unsigned)((gy0 + gyt) * p.WO + gx0 + gxt);   // first pixel of this thread
     const unsigned off_t = pix_t * (unsigned)p.CO + (unsigned)(n0 + c4 * 4);
+    auto epi_items = [&](auto hn_, auto hs_) {
+      constexpr bool HN = decltype(hn_)::value, HS = decltype(hs_)::value;
 #pragma unroll
     for (int it0 = 0; it0 < ITEMS; it0 += UB) {
       f4 val[UB], sk[UB];
@@ -568,45 +577,51 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, MINW) sepconv_kernel(const SepArgs p)
           upix[u] = (dm >> lgGW) * p.WO + (dm & (GW - 1));
           loff[u] = off_t;
           ok[u] = true;
-          nz[u] = has_noise ? (gnoise + upix[u])[pix_t] : 0.0f;
+          if constexpr (HN) nz[u] = (gnoise + upix[u])[pix_t];
         } else {
           const int gx = m & (GW - 1), gy = (m >> lgGW) & (GH - 1), img = m >> (lgGW + lgGH);
           ok[u] = (b0 + img) < p.B;
           const unsigned pix = (unsigned)((gy0 + gy) * p.WO + gx0 + gx);
           upix[u] = 0;
           loff[u] = (unsigned)(ok[u] ? img : 0) * (unsigned)img_elems + pix * (unsigned)p.CO + (unsigned)(n0 + c4 * 4);
-          nz[u] = has_noise ? gnoise[pix] : 0.0f;
+          if constexpr (HN) nz[u] = gnoise[pix];
         }
-        sk[u] = sb ? ld4(sb + (size_t)upix[u] * p.CO + loff[u]) : f4{0.f, 0.f, 0.f, 0.f};
+        if constexpr (HS) sk[u] = ld4(sb + (size_t)upix[u] * p.CO + loff[u]);
       }
 #pragma unroll
       for (int u = 0; u < UB; ++u) {
         f4 v = val[u];
-        if (has_noise) v += MIGAN_FMUL_RN(nz[u], ns);                 // product rounded first, reference :166
+        if constexpr (HN) v += MIGAN_FMUL_RN(nz[u], ns);              // product rounded first, reference :166
         v = act4(v);
-        if (ok[u]) st4(yb + (size_t)upix[u] * p.CO + loff[u], sb ? v + sk[u] : v);
-        if (do_rgb) {
+        f4 outv = v;
+        if constexpr (HS) outv = v + sk[u];
+        if (ok[u]) st4(yb + (size_t)upix[u] * p.CO + loff[u], outv);
+        if constexpr (QN <= 32) if (do_rgb) {
           // ToRGB: 3 dot products over the CO channels of this pixel; the QN lanes holding one pixel
           // are contiguous in the wave -> butterfly reduction with wave shuffles.
           float r0 = v.x * tw0.x + v.y * tw0.y + v.z * tw0.z + v.w * tw0.w;
           float r1 = v.x * tw1.x + v.y * tw1.y + v.z * tw1.z + v.w * tw1.w;
           float r2 = v.x * tw2.x + v.y * tw2.y + v.z * tw2.z + v.w * tw2.w;
-#pragma unroll
-          for (int s = (QN > 32 ? 32 : QN / 2); s >= 1; s >>= 1) {
-            r0 += __shfl_xor(r0, s);
-            r1 += __shfl_xor(r1, s);
-            r2 += __shfl_xor(r2, s);
-          }
+          // xor butterfly over the QN <= 32 lanes of this pixel with ds_swizzle (no address VGPRs)
+          static_assert(QN <= 32, "fused ToRGB needs one pixel inside 32 lanes");
+          if constexpr (QN >= 32) { r0 += MIGAN_SWIZZLE_XOR(r0, 16); r1 += MIGAN_SWIZZLE_XOR(r1, 16); r2 += MIGAN_SWIZZLE_XOR(r2, 16); }
+          r0 += MIGAN_SWIZZLE_XOR(r0, 8); r1 += MIGAN_SWIZZLE_XOR(r1, 8); r2 += MIGAN_SWIZZLE_XOR(r2, 8);
+          r0 += MIGAN_SWIZZLE_XOR(r0, 4); r1 += MIGAN_SWIZZLE_XOR(r1, 4); r2 += MIGAN_SWIZZLE_XOR(r2, 4);
+          r0 += MIGAN_SWIZZLE_XOR(r0, 2); r1 += MIGAN_SWIZZLE_XOR(r1, 2); r2 += MIGAN_SWIZZLE_XOR(r2, 2);
+          r0 += MIGAN_SWIZZLE_XOR(r0, 1); r1 += MIGAN_SWIZZLE_XOR(r1, 1); r2 += MIGAN_SWIZZLE_XOR(r2, 1);
           if (c4 == 0) st4(racc_s + (m0 + (it0 + u) * STEP) * 4, f4{r0, r1, r2, 0.0f});
         }
       }
     }
+    };
+    if (has_noise) { if (sb) epi_items(TrueT{}, TrueT{}); else epi_items(TrueT{}, FalseT{}); }
+    else { if (sb) epi_items(FalseT{}, TrueT{}); else epi_items(FalseT{}, FalseT{}); }
     if (do_rgb) {
       // second pass, one thread per pixel: bias + 2x-upsampled previous image (reference :308-313),
       // planar store (consecutive threads -> consecutive x)
       __syncthreads();
-      if (tid < MT) {
-        const int m = tid;
+      if (tide < MT) {
+        const int m = tide;
         const int gx = m & (GW - 1);
         const int gy = (m >> lgGW) & (GH - 1);
         const int img = m >> (lgGW + lgGH);
@@ -632,6 +647,8 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, MINW) sepconv_kernel(const SepArgs p)
     // (signed: the first item of a thread may be a halo pixel above/left of the image)
     const int opix_t = 2 * (gy0 + gyt) * p.WO + 2 * (gx0 + gxt);
     const int ooff_t = opix_t * p.CO + n0 + c4 * 4;
+    auto epi_items = [&](auto hn_, auto hs_) {
+      constexpr bool HN = decltype(hn_)::value, HS = decltype(hs_)::value;
 #pragma unroll
     for (int k = 0; k < ITEMS; ++k) {
       const int dm = k * STEP;
@@ -666,8 +683,8 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, MINW) sepconv_kernel(const SepArgs p)
 #pragma unroll
         for (int bb = 0; bb < 2; ++bb) {
           const int dp = upix + a * p.WO + bb;                      // uniform
-          nz[a][bb] = has_noise ? gnoise[(unsigned)(lpix + dp)] : 0.0f;
-          sk[a][bb] = sb ? ld4(sb + (unsigned)(loff + dp * p.CO)) : f4{0.f, 0.f, 0.f, 0.f};
+          if constexpr (HN) nz[a][bb] = gnoise[(unsigned)(lpix + dp)];
+          if constexpr (HS) sk[a][bb] = ld4(sb + (unsigned)(loff + dp * p.CO));
         }
       f4 e[3], o[3];
 #pragma unroll
@@ -687,14 +704,189 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, MINW) sepconv_kernel(const SepArgs p)
 #pragma unroll
         for (int bb = 0; bb < 2; ++bb) {
           f4 v = out[a][bb];
-          if (has_noise) v += MIGAN_FMUL_RN(nz[a][bb], ns);
+          if constexpr (HN) v += MIGAN_FMUL_RN(nz[a][bb], ns);
           v = act4(v);
-          st4(yb + (unsigned)(loff + (upix + a * p.WO + bb) * p.CO), sb ? v + sk[a][bb] : v);
+          if constexpr (HS) v += sk[a][bb];
+          st4(yb + (unsigned)(loff + (upix + a * p.WO + bb) * p.CO), v);
         }
     }
+    };
+    if (has_noise) { if (sb) epi_items(TrueT{}, TrueT{}); else epi_items(TrueT{}, FalseT{}); }
+    else { if (sb) epi_items(FalseT{}, TrueT{}); else epi_items(FalseT{}, FalseT{}); }
   }
   PROF_MARK(5);
+  if (!has_next) break;
+  __syncthreads();                       // epilogue reads of g_s/racc_s done before the next tile refills LDS
+  tl += tstep;
+  n0 = n0n; b0 = b0n; gy0 = gy0n; gx0 = gx0n; vmask = vmaskn;
+#pragma unroll
+  for (int j = 0; j < NI; ++j) goff[j] = goffn[j];
+#pragma unroll
+  for (int j = 0; j < NB; ++j) boff[j] = boffn[j];
+  }  // tile loop
   PROF_END();
+}
+
+// ------------------------------------------------------------------------------------------------
+// First half of a down=2 SeparableConv2d (reference :155-160): depthwise 3x3 + bias, lrelu_agc, then
+// Downsample2d (4x4 FIR [1,3,3,1]x[1,3,3,1]/64, stride 2, zero pad 1; reference :58-76).  Writes the
+// half-resolution NHWC tensor the pointwise GEMM (sepconv_kernel<MODE_PW>) consumes.
+//
+// Un-fused from the GEMM on purpose: on gfx950 FP32 VALU work and v_mfma_f32 share one issue budget
+// (profiles/r01_ubench_mfma_valu_overlap.md), so the 4x larger high-resolution depthwise grid is
+// computed exactly once per pixel here (memory-bound, 3 workgroups per CU) instead of once per
+// Cout tile inside the MFMA loop.
+struct DwFirArgs {
+  const float* x;      // NHWC [B][H][W][C]
+  float* y;            // NHWC [B][H/2][W/2][C]
+  const float* wdw;    // conv1.weight [C][1][3][3]
+  const float* bdw;    // conv1.bias [C]
+  int B, H, W, C;
+  int lgGH, lgGW, lgIMGS;          // output tile: IMGS images x GH x GW low-resolution pixels (GH*GW*IMGS = 64)
+  int tiles_x, tiles_y, nkg, kpw;  // grid = tiles_x * tiles_y * ceil(B/IMGS) * nkg; a workgroup walks kpw 16-channel chunks (nkg*kpw = C/16)
+  int off_d, off_w;                // LDS carve (floats)
+};
+
+template <int NI, bool MAING>
+MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, 3) dwfir_kernel(const DwFirArgs p) {
+  MIGAN_DYN_SMEM(smem);
+  constexpr int KC = 16, QC = 4, LG_QC = 2, MT = 64;
+  const int tid = threadIdx.x;
+  const int lgGH = MAING ? 2 : p.lgGH, lgGW = MAING ? 4 : p.lgGW, lgIMGS = MAING ? 0 : p.lgIMGS;
+  const int GH = 1 << lgGH, GW = 1 << lgGW, IMGS = 1 << lgIMGS;
+  int t = xcd_remap((int)blockIdx.x, (int)gridDim.x);
+  const int kgrp = t % p.nkg; t /= p.nkg;                      // group of kpw consecutive 16-channel chunks
+  const int tx = t % p.tiles_x; t /= p.tiles_x;
+  const int ty = t % p.tiles_y;
+  const int b0 = (t / p.tiles_y) << lgIMGS;
+  const int gy0 = ty * GH, gx0 = tx * GW;                      // output tile origin
+  const int HO = p.H >> 1, WO = p.W >> 1;
+  const int IGH = 2 * GH + 4, IGW = 2 * GW + 4;
+  const int iy0 = 2 * gy0 - 2, ix0 = 2 * gx0 - 2;
+  const int npix_in = IMGS * IGH * IGW, nitems_in = npix_in * QC;
+  const int DH = 2 * GH + 2, DW = 2 * GW + 2, DH2 = GH + 1;
+  float* in_s = smem;
+  float* d_s = smem + p.off_d;
+  float* w_s = smem + p.off_w;
+  const float* __restrict__ xb = p.x + (size_t)b0 * p.H * p.W * p.C;
+  float* __restrict__ yb = p.y + (size_t)b0 * HO * WO * p.C;
+
+  // per-thread item descriptors (constant across the channel chunks this workgroup walks)
+  unsigned goff[NI];
+  unsigned vmask = 0, emask = 0;
+#pragma unroll
+  for (int j = 0; j < NI; ++j) {
+    const int i = tid + j * kThreads;
+    unsigned g = 0;
+    if (i < nitems_in) {
+      emask |= 1u << j;
+      const int c4 = i & (QC - 1);
+      const int pix = i >> LG_QC;
+      const int ix = pix % IGW;
+      const int r = pix / IGW;
+      const int iy = r % IGH, img = r / IGH;
+      const int yy = iy0 + iy, xx = ix0 + ix;
+      if (yy >= 0 && yy < p.H && xx >= 0 && xx < p.W && (b0 + img) < p.B) {
+        vmask |= 1u << j;
+        g = (unsigned)(((img * p.H + yy) * p.W + xx) * p.C + c4 * 4);
+      }
+    }
+    goff[j] = g;
+  }
+  f4 rin[NI], rw;
+  auto issue_loads = [&](int k0) {
+    const float* __restrict__ xk = xb + k0;
+#pragma unroll
+    for (int j = 0; j < NI; ++j) rin[j] = ld4(xk + goff[j]);
+    if (tid < KC * 9 / 4) rw = ld4(p.wdw + (size_t)k0 * 9 + (unsigned)(tid * 4));
+    else if (tid < KC * 10 / 4) rw = ld4(p.bdw + k0 + (unsigned)((tid - KC * 9 / 4) * 4));
+  };
+
+  const int kfirst = kgrp * p.kpw;
+  issue_loads(kfirst * KC);
+  for (int kk = 0; kk < p.kpw; ++kk) {
+    const int k0 = (kfirst + kk) * KC;
+    if (kk > 0) __syncthreads();                 // previous chunk's FIR pass is done with d_s (and in_s, w_s)
+    // prefetched chunk -> LDS (input tile with +2 halo, tap-major depthwise weights)
+    if (tid < KC * 9 / 4) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int f = tid * 4 + e;
+        w_s[(f % 9) * KC + f / 9] = rw[e];
+      }
+    } else if (tid < KC * 10 / 4) {
+      st4(w_s + tid * 4, rw);
+    }
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      if (emask & (1u << j)) {
+        f4 v = rin[j];
+        if (!(vmask & (1u << j))) v = f4{0.f, 0.f, 0.f, 0.f};
+        st4(in_s + (tid + j * kThreads) * 4, v);
+      }
+    }
+    __syncthreads();
+    if (kk + 1 < p.kpw) issue_loads(k0 + KC);    // next chunk in flight during both compute stages
+
+    // stage 1: depthwise 3x3 + bias + act on the (2GH+2)x(2GW+2) high-resolution grid this tile's FIR
+    // window touches -> d_s.  One item = 2 vertically adjacent grid pixels x 4 channels (4x3 register
+    // window: 12 LDS reads, 18 float4 FMAs).
+    const int nstrips = IMGS * DH2 * DW * QC;
+    const int yim0 = 2 * gy0 - 1, xim0 = 2 * gx0 - 1;
+    for (int it = tid; it < nstrips; it += kThreads) {
+      const int c4 = it & (QC - 1);
+      int r = it >> LG_QC;
+      const int dx = r % DW; r /= DW;
+      const int sy2 = r % DH2, img = r / DH2;
+      const int dy0 = 2 * sy2;
+      f4 w[9];
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) w[tap] = ld4(w_s + tap * KC + c4 * 4);
+      const f4 bias = ld4(w_s + KC * 9 + c4 * 4);
+      const float* ip = in_s + ((img * IGH + dy0) * IGW + dx) * KC + c4 * 4;
+      f4 win[4][3];
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        win[rr][0] = ld4(ip); win[rr][1] = ld4(ip + KC); win[rr][2] = ld4(ip + 2 * KC);
+        ip += IGW * KC;
+      }
+      const int xim = xim0 + dx;
+      const bool colin = xim >= 0 && xim < p.W;
+      float* dp = d_s + (((img * DH + dy0) * DW) + dx) * KC + c4 * 4;
+#pragma unroll
+      for (int o = 0; o < 2; ++o) {
+        f4 sacc = bias;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+          for (int kx = 0; kx < 3; ++kx) sacc += w[ky * 3 + kx] * win[o + ky][kx];
+        const int yim = yim0 + dy0 + o;
+        f4 d = {0.f, 0.f, 0.f, 0.f};                          // FIR zero padding outside the image (reference :67)
+        if (colin && yim >= 0 && yim < p.H) d = act4(sacc);
+        st4(dp + o * DW * KC, d);
+      }
+    }
+    __syncthreads();
+    // stage 2: 4x4 FIR, stride 2, taps outer([1,3,3,1])/64 (reference Downsample2d :58-76) -> HBM
+    for (int it = tid; it < MT * QC; it += kThreads) {
+      const int c4 = it & (QC - 1);
+      const int m = it >> LG_QC;
+      const int ox = m & (GW - 1), oy = (m >> lgGW) & (GH - 1), img = m >> (lgGW + lgGH);
+      if (b0 + img >= p.B) continue;
+      const float* dp = d_s + ((img * DH + 2 * oy) * DW + 2 * ox) * KC + c4 * 4;
+      f4 a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ky = 0; ky < 4; ++ky) {
+        const float fy = (ky == 0 || ky == 3) ? 1.0f : 3.0f;
+#pragma unroll
+        for (int kx = 0; kx < 4; ++kx) {
+          const float fx = (kx == 0 || kx == 3) ? 1.0f : 3.0f;
+          a += (fy * fx * (1.0f / 64.0f)) * ld4(dp + (ky * DW + kx) * KC);
+        }
+      }
+      st4(yb + (unsigned)((((img * HO) + gy0 + oy) * WO + gx0 + ox) * p.C + k0 + c4 * 4), a);
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------------------

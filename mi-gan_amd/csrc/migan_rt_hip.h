@@ -14,6 +14,9 @@
 #define MIGAN_MFMA_F32_32X32X2(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 #define MIGAN_FMUL_RN(a, b) __fmul_rn((a), (b))
 #define MIGAN_CLAMP(v, lo, hi) __builtin_amdgcn_fmed3f((v), (lo), (hi))     // v_med3_f32
+// ds_swizzle bit mode: lane' = ((lane & and_mask) | or_mask) ^ xor_mask inside groups of 32 lanes
+#define MIGAN_SWIZZLE_XOR(v, m) __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, (v)), (((m) << 10) | 0x1f)))
+#define MIGAN_OPAQUE(x) asm volatile("" : "+v"(x))
 #define MIGAN_CLOCK() __builtin_readcyclecounter()
 #define MIGAN_ATOMIC_ADD_U64(p, v) atomicAdd((p), (v))
 

@@ -33,7 +33,8 @@ class SepConvDesc(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in (
         "x", "y", "skip", "conv1_weight", "conv1_bias", "conv2_weight", "noise_const", "noise_strength",
         "fromrgb_weight", "fromrgb_bias", "torgb_weight", "torgb_bias", "img_prev", "img_out")] + [
-        (n, C.c_int) for n in ("batch", "cin", "cout", "res_in", "down", "up")]
+        (n, C.c_int) for n in ("batch", "cin", "cout", "res_in", "down", "up")] + [
+        ("scratch", C.c_void_p), ("scratch_bytes", C.c_size_t)]
 
 
 EXPORTS = (
@@ -103,7 +104,7 @@ class MiganLib:
     def sepconv_forward(self, stream: int = 0, **kw) -> None:
         d = SepConvDesc()
         for f, _ in SepConvDesc._fields_:
-            setattr(d, f, kw.pop(f, None if f not in ("batch", "cin", "cout", "res_in", "down", "up") else 0))
+            setattr(d, f, kw.pop(f, None if f not in ("batch", "cin", "cout", "res_in", "down", "up", "scratch_bytes") else 0))
         if kw:
             raise TypeError(f"unknown sepconv fields: {sorted(kw)}")
         d.down = d.down or 1

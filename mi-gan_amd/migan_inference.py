@@ -203,4 +203,4 @@ class Generator(nn.Module):
         if self._lib is None:
             self._lib = load_library()
         h = self._handle or MiganHandle(self._lib, self.resolution, 0)
-        return h.launches()
+        return h.launches()        # kernel names reflect the variants used by the last forward on this handle

@@ -86,8 +86,9 @@ def test_launch_plan_matches_the_survey_accounting(pkg, lib):
     """Per-image algorithmic work the roofline is computed from."""
     h512 = pkg.hipbind.MiganHandle(lib, 512)
     L = h512.launches()
-    seps = [l for l in L if "torgb_kernel" not in l["kernel"]]
+    seps = [l for l in L if "sepconv_kernel" in l["kernel"]]
     assert len(seps) == 32                                        # 32 SeparableConv2d @512
+    assert len([l for l in L if "dwfir_kernel" in l["kernel"]]) == 7   # one per down=2 layer
     assert abs(sum(l["mfma_flops"] for l in L) / 1e9 - 26.49) < 0.02   # 1x1 convs: 26.49 GFLOP
     assert abs(sum(l["flops"] for l in L) / 1e9 - 29.35) < 0.05        # all stages: 29.35 GFLOP
     assert abs(sum(l["bytes"] for l in L) / 1e6 - 965.7) < 1.0         # 965.7 MB fp32
@@ -135,3 +136,18 @@ def test_state_errors(pkg, lib):
     for r in (12, 4, 1024):
         with pytest.raises(ValueError):
             pkg.hipbind.MiganHandle(lib, r)
+
+
+def test_persistent_workgroups_same_results():
+    """Large launches run persistent workgroups that walk several tiles and prefetch the next tile's
+    first K chunk during the epilogue.  Force that path on the small emulator cases (the tuning knobs
+    are read once per process, hence the subprocess) and re-run the operator + generator suites."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for grid in ("8", "16"):
+        env = dict(os.environ, MIGAN_PERSIST_MIN="2", MIGAN_PERSIST_GRID=grid)
+        r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "tests/test_emu_sepconv.py",
+                            "tests/test_emu_generator.py", "-k", "not persistent_workgroups"],
+                           cwd=root, env=env, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]

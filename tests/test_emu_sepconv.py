@@ -47,9 +47,11 @@ def _run(lib, pkg, *, cin, cout, res_in, batch, down=1, up=1, noise=False, skip=
     w1, b1, w2 = aligned(sd["m.conv1.weight"]), aligned(sd["m.conv1.bias"]), aligned(sd["m.conv2.weight"])
     nc = aligned(sd["m.noise_const"]) if noise else None
     ns = aligned(sd["m.noise_strength"].reshape(1)) if noise else None
+    scratch = aligned(np.full((batch, res_out, res_out, cin), np.nan, dtype=np.float32)) if down == 2 else None
     lib.sepconv_forward(x=ptr(xh), y=ptr(y), skip=ptr(skh), conv1_weight=ptr(w1), conv1_bias=ptr(b1),
                         conv2_weight=ptr(w2), noise_const=ptr(nc), noise_strength=ptr(ns),
-                        batch=batch, cin=cin, cout=cout, res_in=res_in, down=down, up=up)
+                        batch=batch, cin=cin, cout=cout, res_in=res_in, down=down, up=up,
+                        scratch=ptr(scratch), scratch_bytes=0 if scratch is None else scratch.nbytes)
     got = nchw(y)
     assert np.isfinite(got).all(), "kernel left NaNs (unwritten output or read of unwritten LDS)"
     tol = 2e-5 * max(1.0, float(np.abs(want).max()))
@@ -139,6 +141,9 @@ def test_bad_arguments_are_rejected(lib):
     with pytest.raises(ValueError):
         lib.sepconv_forward(x=ptr(a), y=ptr(a), conv1_weight=ptr(a), conv1_bias=ptr(a), conv2_weight=ptr(a),
                             batch=1, cin=64, cout=64, res_in=12)          # not a power of two
+    with pytest.raises(ValueError, match="scratch"):
+        lib.sepconv_forward(x=ptr(a), y=ptr(a), conv1_weight=ptr(a), conv1_bias=ptr(a), conv2_weight=ptr(a),
+                            batch=1, cin=64, cout=64, res_in=16, down=2)   # down=2 without scratch
     with pytest.raises(ValueError):
         lib.sepconv_forward(x=None, y=ptr(a), conv1_weight=ptr(a), conv1_bias=ptr(a), conv2_weight=ptr(a),
                             batch=1, cin=64, cout=64, res_in=16)          # null tensor

@@ -64,7 +64,9 @@ def _sep(pkg, dev, *, cin, cout, res_in, batch, down=1, up=1, noise=False, skip=
     y = torch.full((batch, res_out, res_out, cout), float("nan"), device=dev)
     w = {k: t(v.reshape(1) if v.ndim == 0 else v) for k, v in sd.items()}
     p = lambda a: None if a is None else a.data_ptr()
+    scratch = torch.full((batch, res_out, res_out, cin), float("nan"), device=dev) if down == 2 else None
     lib.sepconv_forward(stream=int(torch.cuda.current_stream().cuda_stream), x=p(xh), y=p(y), skip=p(skh),
+                        scratch=p(scratch), scratch_bytes=0 if scratch is None else scratch.numel() * 4,
                         conv1_weight=p(w["m.conv1.weight"]), conv1_bias=p(w["m.conv1.bias"]), conv2_weight=p(w["m.conv2.weight"]),
                         noise_const=p(w.get("m.noise_const")), noise_strength=p(w.get("m.noise_strength")),
                         batch=batch, cin=cin, cout=cout, res_in=res_in, down=down, up=up)
