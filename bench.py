@@ -166,6 +166,18 @@ def main():
                 if i >= 3:
                     rounds.append(ms)
         roof = roofline_from_launches(launches, rounds, B)
+        # HBM bytes per launch of the dominant kernel from the PMC passes of this same command
+        # (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs; scripts/pmc_traffic.py applies the
+        # guide's KiB unit and gfx950 x2 read correction).  Committed under profiles/; null if absent.
+        tpath = os.path.join(ROOT, "profiles", "pmc_traffic_latest.json")
+        if R == 512 and B == 32 and os.path.exists(tpath):
+            try:
+                t = json.load(open(tpath)).get(roof["kernel"])
+                if t:
+                    roof["traffic"] = round(t["hbm_bytes_per_launch"])
+                    roof["traffic_source"] = "profiles/pmc_traffic_latest.json (rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE, avg per launch)"
+            except Exception:
+                pass
         if args.dump_layers:
             med = np.median(np.asarray(rounds), axis=0)
             with open(args.dump_layers, "w") as f:
