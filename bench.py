@@ -35,6 +35,9 @@ import torch
 
 PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 / 16x16x4_f32 peak
+PEAK_BF16_MFMA_TFLOPS = 2500.0 # MI355X_MICROARCH.md: dense bf16 MFMA peak
+# GEMM variant "bf16x3": every fp32 product costs six bf16 MFMA products, so the matrix-core ceiling in
+# ALGORITHMIC flops is 2500 / 6
 
 
 def parse():
@@ -53,7 +56,7 @@ def parse():
     return ap.parse_args()
 
 
-def roofline_from_launches(launches, ms_rounds, batch):
+def roofline_from_launches(launches, ms_rounds, batch, gemm="f32"):
     """Group the per-launch hipEvent durations by kernel symbol and describe the dominant one."""
     ms = np.median(np.asarray(ms_rounds, dtype=np.float64), axis=0)
     groups = {}
@@ -65,12 +68,13 @@ def roofline_from_launches(launches, ms_rounds, batch):
         g["bytes"] += L["bytes"] * batch
         g["n"] += 1
         g["layers"].append(L["layer"])
+    peak_mfma = PEAK_BF16_MFMA_TFLOPS / 6.0 if gemm == "bf16x3" else PEAK_F32_MFMA_TFLOPS
     name, g = max(groups.items(), key=lambda kv: kv[1]["ms"])
     sec = g["ms"] * 1e-3
-    t_mfma = g["mfma"] / (PEAK_F32_MFMA_TFLOPS * 1e12)
+    t_mfma = g["mfma"] / (peak_mfma * 1e12)
     t_hbm = g["bytes"] / (PEAK_HBM_GBS * 1e9)
     if t_mfma >= t_hbm:
-        bound, achieved, peak, unit = "mfma", g["mfma"] / sec / 1e12, PEAK_F32_MFMA_TFLOPS, "TFLOP/s"
+        bound, achieved, peak, unit = "mfma", g["mfma"] / sec / 1e12, round(peak_mfma, 1), "TFLOP/s"
     else:
         bound, achieved, peak, unit = "hbm", g["bytes"] / sec / 1e9, PEAK_HBM_GBS, "GB/s"
     total_ms = float(ms.sum())
@@ -79,6 +83,9 @@ def roofline_from_launches(launches, ms_rounds, batch):
     roof = {
         "bound": bound, "achieved": round(achieved, 3), "peak": peak, "unit": unit,
         "frac": round(achieved / peak, 4), "traffic": None,
+        "gemm": gemm, "dominant_mfma_tflops": round(g["mfma"] / sec / 1e12, 2),
+        "frac_vs_fp32_mfma_peak": round(g["mfma"] / sec / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+        "dominant_hbm_gbs": round(g["bytes"] / sec / 1e9, 1),
         "kernel": name, "launches": g["n"], "avg_launch_ms": round(g["ms"] / g["n"], 4),
         "share_of_gpu_time": round(g["ms"] / total_ms, 4),
         "alg_per_launch": {"mfma_flop": g["mfma"] / g["n"], "bytes": g["bytes"] / g["n"]},
@@ -165,7 +172,8 @@ def main():
                 _, ms = model.forward_timed(x)
                 if i >= 3:
                     rounds.append(ms)
-        roof = roofline_from_launches(launches, rounds, B)
+        gemm = model._lib.gemm_variant()
+        roof = roofline_from_launches(launches, rounds, B, gemm)
         # HBM bytes per launch of the dominant kernel from the PMC passes of this same command
         # (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs; scripts/pmc_traffic.py applies the
         # guide's KiB unit and gfx950 x2 read correction).  Committed under profiles/; null if absent.
@@ -211,6 +219,8 @@ def main():
             "dtype": "f32", "data": "synthetic (seeded export-like weights, demo.py-style mask+image batches)",
             "config": {"workload": f"migan-{R} generator forward, batch={B} per GPU, {R}x{R}, fp32 (BASELINE configs[2])",
                        "global_batch": world * B, "resolution": R,
+                       "gemm": ("1x1 convs on bf16x3-split MFMA (6 bf16 products per fp32 product, fp32 accumulate)"
+                                if gemm == "bf16x3" else "1x1 convs on exact fp32 MFMA"),
                        "parallelism": f"batch-shard x{world}" + (" + RCCL all-gather of outputs" if gather else "")},
             "max_abs_vs_ref": parity,
             "roofline": roof,

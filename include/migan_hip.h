@@ -116,12 +116,19 @@ typedef struct migan_sepconv_desc {
   int up;                     /* 1 or 2 (Upsample2d, reference :79-103) */
   void* scratch;              /* down == 2 only: batch*(res_in/2)^2*cin floats (output of the depthwise+FIR kernel) */
   size_t scratch_bytes;
+  void* wsplit;               /* optional: 3*cout*cin*2 bytes for the bf16 weight planes of the bf16x3-split GEMM variant */
+  size_t wsplit_bytes;
 } migan_sepconv_desc;
 int migan_sepconv_forward(const migan_sepconv_desc* d, void* stream);
 
 const char* migan_last_error(void);
 /* "hip:gfx950" for the product library. */
 const char* migan_backend(void);
+/* How the 1x1 convolutions are multiplied (environment MIGAN_GEMM=f32|bf16x3, read once per process):
+ *   "f32"    v_mfma_f32_32x32x2_f32, exact fp32 products;
+ *   "bf16x3" (default) each fp32 operand split into three bf16 pieces, the six products of order <= 2^-16
+ *            on v_mfma_f32_32x32x16_bf16 with fp32 accumulation: fp32-grade accuracy at 6/16 of the MFMA cost. */
+const char* migan_gemm_variant(void);
 int migan_version(void);
 
 #ifdef __cplusplus

@@ -49,6 +49,7 @@ struct Geo {
   int NI = 6, MINW = 2;            // prefetch items per thread, workgroups per CU the kernel is built for
   bool maing = true;               // compile-time tile geometry (8x16 pixels, one image)
   bool persist = false;            // kernel variant whose workgroups walk several tiles
+  int gemmv = 0;                   // 0 exact fp32 MFMA, 1 bf16x3-split MFMA
   int a_stride = 0;
   int lgGH = 3, lgGW = 4, lgIMGS = 0;
   int sy = 8, sx = 16, off = 0, lgRS = 1;
@@ -69,6 +70,8 @@ inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 struct Tuning {
   int nt64_wgs_per_cu = 2;     // MIGAN_NT64_WGS: workgroups per CU targeted by the 64-column kernels (2 or 3)
   int force_single_b = 0;      // MIGAN_SINGLE_B=1: never double-buffer the 1x1 weight tile
+  int gemm_bf16x3 = 1;         // MIGAN_GEMM=f32|bf16x3: exact fp32 MFMA, or (default, 12 % faster end to end, same parity)
+                               // error-compensated bf16 MFMA: 6 products of 3-way bf16 splits, fp32 accumulate
   int persist_min = 8192;      // MIGAN_PERSIST_MIN: launches with at least this many tiles run persistent workgroups
   int persist_grid = 512;      // MIGAN_PERSIST_GRID: ... that many (2 per CU on MI355X), each walking its share of tiles
 };
@@ -77,6 +80,7 @@ inline Tuning& tuning() {
     Tuning v;
     if (const char* e = std::getenv("MIGAN_NT64_WGS")) v.nt64_wgs_per_cu = (std::atoi(e) == 3) ? 3 : 2;
     if (const char* e = std::getenv("MIGAN_SINGLE_B")) v.force_single_b = std::atoi(e) != 0;
+    if (const char* e = std::getenv("MIGAN_GEMM")) v.gemm_bf16x3 = (std::string(e) != "f32");
     if (const char* e = std::getenv("MIGAN_PERSIST_MIN")) v.persist_min = std::max(1, std::atoi(e));
     if (const char* e = std::getenv("MIGAN_PERSIST_GRID")) v.persist_grid = std::max(8, std::atoi(e) / 8 * 8);   // multiple of 8: one share per XCD
     return v;
@@ -84,8 +88,9 @@ inline Tuning& tuning() {
   return t;
 }
 
-inline Geo choose_geo(int mode, int cin, int cout, int res_in, bool fromrgb, bool fused_rgb = true) {
+inline Geo choose_geo(int mode, int cin, int cout, int res_in, bool fromrgb, bool fused_rgb = true, int gemmv = -1) {
   Geo g;
+  g.gemmv = gemmv < 0 ? tuning().gemm_bf16x3 : gemmv;
   g.mode = mode;
   g.fromrgb = fromrgb;
   MIGAN_CHECK(cin % 32 == 0 && cout % 64 == 0, MIGAN_EINVAL,
@@ -132,7 +137,9 @@ inline Geo choose_geo(int mode, int cin, int cout, int res_in, bool fromrgb, boo
   MIGAN_CHECK(items <= g.NI, MIGAN_EINVAL, "internal: input tile too large");
   g.MINW = (g.NT == 64) ? tuning().nt64_wgs_per_cu : 2;
   const int AS = g.KC + 4, GS = g.NT + 4;
-  const int asz = g.MT * AS, bsz = g.NT * AS;
+  // operand tiles in floats: fp32 rows of pitch KC+4, or three unpadded (XOR-swizzled) bf16 planes
+  const int asz = g.gemmv ? 3 * g.MT * (g.KC * 2) / 4 : g.MT * AS;
+  const int bsz = g.gemmv ? 3 * g.NT * (g.KC * 2) / 4 : g.NT * AS;
   const int gs = g.MT * GS + (fused_rgb ? g.MT * 4 : 0);
   const size_t limit = (size_t)(160 * 1024 / g.MINW);
   if (mode == MODE_PW) {
@@ -164,13 +171,16 @@ struct KernelEntry {
   bool fromrgb;
   int NI, MINW;
   bool maing, persist;
+  int gemmv;
   SepKernelFn fn;
   const char* name;
 };
 
-#define MIGAN_KERNEL(MODE, MT, NT, KC, RGB, NI, MINW, MAING, PERSIST)                                               \
-  {MODE, MT, NT, KC, RGB, NI, MINW, MAING, PERSIST, sepconv_kernel<MODE, MT, NT, KC, RGB, NI, MINW, MAING, PERSIST>, \
-   "migan::sepconv_kernel<" #MODE ", " #MT ", " #NT ", " #KC ", " #RGB ", " #NI ", " #MINW ", " #MAING ", " #PERSIST ">"}
+#define MIGAN_KERNEL1(MODE, MT, NT, KC, RGB, NI, MINW, MAING, PERSIST, GEMMV)                                                      \
+  {MODE, MT, NT, KC, RGB, NI, MINW, MAING, PERSIST, GEMMV, sepconv_kernel<MODE, MT, NT, KC, RGB, NI, MINW, MAING, PERSIST, GEMMV>, \
+   "migan::sepconv_kernel<" #MODE ", " #MT ", " #NT ", " #KC ", " #RGB ", " #NI ", " #MINW ", " #MAING ", " #PERSIST ", " #GEMMV ">"}
+#define MIGAN_KERNEL(MODE, MT, NT, KC, RGB, NI, MINW, MAING, PERSIST) \
+  MIGAN_KERNEL1(MODE, MT, NT, KC, RGB, NI, MINW, MAING, PERSIST, 0), MIGAN_KERNEL1(MODE, MT, NT, KC, RGB, NI, MINW, MAING, PERSIST, 1)
 
 inline const std::vector<KernelEntry>& kernel_table() {
   static const std::vector<KernelEntry> t = {
@@ -196,7 +206,7 @@ inline const std::vector<KernelEntry>& kernel_table() {
 inline const KernelEntry& pick_kernel(const Geo& g) {
   for (const auto& e : kernel_table())
     if (e.mode == g.mode && e.MT == g.MT && e.NT == g.NT && e.KC == g.KC && e.fromrgb == g.fromrgb && e.NI == g.NI &&
-        e.MINW == g.MINW && e.maing == g.maing && e.persist == g.persist)
+        e.MINW == g.MINW && e.maing == g.maing && e.persist == g.persist && e.gemmv == g.gemmv)
       return e;
   throw Error(MIGAN_EINVAL, "internal: no kernel instantiation for this geometry");
 }
@@ -307,6 +317,10 @@ inline void launch_dwfir(const DwGeo& g, DwFirArgs a, rt::stream_t stream) {
   else rt_check(rt::launch(dwfir_kernel<9, false>, a, dwfir_grid(g, a.B), kThreads, g.lds_bytes, stream), dwfir_name(g));
 }
 
+inline void launch_split(const SplitArgs& a, rt::stream_t stream) {
+  rt_check(rt::launch(split_weights_kernel, a, (unsigned)(a.n * kSplitBlocksPerTensor), kThreads, 0, stream), "migan::split_weights_kernel");
+}
+
 inline void launch_torgb(const RgbArgs& a, rt::stream_t stream) {
   const size_t npix = (size_t)a.B * a.H * a.W;
   const unsigned grid = (unsigned)((npix * 16 + kThreads - 1) / kThreads);
@@ -340,6 +354,7 @@ inline int channels_at(int res) {
 struct Buf {
   std::string name;
   size_t floats_per_image;
+  size_t fixed_floats = 0;     // batch-independent part (bf16 weight planes)
 };
 enum : int { BUF_NONE = -1, BUF_X = -2, BUF_Y = -3 };
 
@@ -355,6 +370,7 @@ struct Launch {
   int w_dw = -1, b_dw = -1, w_pw = -1, w_noise = -1, w_ns = -1, w_frgb = -1, b_frgb = -1, w_trgb = -1, b_trgb = -1;
   double flops = 0, mfma_flops = 0, bytes = 0;
   int wgs_batch1 = 0;
+  size_t wsplit_off = 0;             // element offset of this layer's bf16 weight planes in the wsplit buffer
 };
 
 }  // namespace migan
@@ -367,6 +383,7 @@ struct migan_handle {
   std::vector<migan::Launch> launches;
   std::vector<std::pair<std::string, int>> debug_tensors;   // layer name -> buffer id
   std::vector<rt::event_t> events;
+  int wsplit_buf = -1;
 
   int slot_index(const std::string& n) const {
     for (size_t i = 0; i < slots.size(); ++i)
@@ -464,6 +481,8 @@ inline void migan_handle::build_plan() {
   size_t max_dwt = 16;
   for (int res = R; res > 4; res /= 2) max_dwt = std::max(max_dwt, (size_t)(res / 2) * (res / 2) * channels_at(res));
   const int DWT = add_buf("dwfir_tmp", max_dwt);
+  wsplit_buf = add_buf("wsplit", 0);
+  size_t wsplit_elems = 0;
   int P0 = BUF_NONE, P1 = BUF_NONE, I0 = BUF_NONE, I1 = BUF_NONE;
   if (!debug) {
     P0 = add_buf("act0", max_act);
@@ -487,6 +506,8 @@ inline void migan_handle::build_plan() {
     L.w_dw = slot_index(layer + ".conv1.weight");
     L.b_dw = slot_index(layer + ".conv1.bias");
     L.w_pw = slot_index(layer + ".conv2.weight");
+    L.wsplit_off = wsplit_elems;
+    wsplit_elems += (size_t)3 * cin * cout;
     if (noise) {
       L.w_noise = slot_index(layer + ".noise_const");
       L.w_ns = slot_index(layer + ".noise_strength");
@@ -585,12 +606,13 @@ inline void migan_handle::build_plan() {
     if (debug && res != R) debug_tensors.push_back({b + ".img", img_out});
     img_cur = img_out;
   }
+  bufs[wsplit_buf].fixed_floats = (wsplit_elems * sizeof(unsigned short) + 3) / 4 + 64;
 }
 
 inline size_t migan_handle::buf_offset_bytes(int id, int batch) const {
   size_t off = 0;
   for (int i = 0; i < id; ++i) {
-    const size_t b = bufs[i].floats_per_image * (size_t)batch * sizeof(float);
+    const size_t b = (bufs[i].floats_per_image * (size_t)batch + bufs[i].fixed_floats) * sizeof(float);
     off += (b + 255) / 256 * 256;
   }
   return off;
@@ -622,6 +644,22 @@ inline void migan_handle::forward(const float* x, float* y, int batch, void* ws,
     return reinterpret_cast<float*>(static_cast<char*>(ws) + offs[id]);
   };
   auto wptr = [&](int s) -> const float* { return s < 0 ? nullptr : slots[s].ptr; };
+  unsigned short* wsplit = reinterpret_cast<unsigned short*>(static_cast<char*>(ws) + offs[wsplit_buf]);
+  if (tuning().gemm_bf16x3) {
+    // conv2.weight of every layer -> three bf16 planes (one launch; the weights are read in place every forward,
+    // so in-place parameter updates are always picked up)
+    SplitArgs sa{};
+    sa.dst = wsplit;
+    for (const Launch& L : launches) {
+      if (L.is_rgb || L.is_dwfir) continue;
+      MIGAN_CHECK(sa.n < 40, MIGAN_EINVAL, "internal: too many layers for the weight-split table");
+      sa.src[sa.n] = wptr(L.w_pw);
+      sa.dst_off[sa.n] = L.wsplit_off;
+      sa.count[sa.n] = (unsigned)(L.cin * L.cout);
+      ++sa.n;
+    }
+    launch_split(sa, stream);
+  }
   for (size_t li = 0; li < launches.size(); ++li) {
     const Launch& L = launches[li];
     if (timed) rt_check(rt::event_record(events[2 * li], stream), "hipEventRecord");
@@ -640,6 +678,7 @@ inline void migan_handle::forward(const float* x, float* y, int batch, void* ws,
       SepArgs a{};
       a.x = bptr(L.in_buf); a.y = bptr(L.out_buf); a.skip = bptr(L.skip_buf);
       a.wdw = wptr(L.w_dw); a.bdw = wptr(L.b_dw); a.wpw = wptr(L.w_pw);
+      a.wsplit = L.g.gemmv ? wsplit + L.wsplit_off : nullptr;
       a.noise = wptr(L.w_noise); a.noise_strength = wptr(L.w_ns);
       a.frgb_w = wptr(L.w_frgb); a.frgb_b = wptr(L.b_frgb);
       a.trgb_w = wptr(L.w_trgb); a.trgb_b = wptr(L.b_trgb);
@@ -885,12 +924,22 @@ int migan_sepconv_forward(const migan_sepconv_desc* d, void* stream) {
     mode = MODE_PW;
     gemm_res = res_out;
   }
-  const Geo g = choose_geo(mode, d->cin, d->cout, gemm_res, d->fromrgb_weight != nullptr);
+  // bf16x3-split GEMM needs room for the three bf16 weight planes; without it the exact fp32 MFMA path runs
+  const size_t wsplit_need = (size_t)3 * d->cin * d->cout * sizeof(unsigned short);
+  const int gemmv = (tuning().gemm_bf16x3 && d->wsplit != nullptr && d->wsplit_bytes >= wsplit_need) ? 1 : 0;
+  const Geo g = choose_geo(mode, d->cin, d->cout, gemm_res, d->fromrgb_weight != nullptr, true, gemmv);
+  if (gemmv) {
+    SplitArgs sa{};
+    sa.dst = (unsigned short*)d->wsplit;
+    sa.src[0] = (const float*)d->conv2_weight; sa.dst_off[0] = 0; sa.count[0] = (unsigned)(d->cin * d->cout); sa.n = 1;
+    launch_split(sa, (rt::stream_t)stream);
+  }
   MIGAN_CHECK(d->torgb_weight == nullptr || (g.nchunks == 1 && mode != MODE_UP && d->img_out), MIGAN_EINVAL,
               "fused ToRGB needs cout <= 128, up == 1 and img_out");
   SepArgs a{};
   a.x = gemm_in; a.y = (float*)d->y; a.skip = (const float*)d->skip;
   a.wdw = (const float*)d->conv1_weight; a.bdw = (const float*)d->conv1_bias; a.wpw = (const float*)d->conv2_weight;
+  a.wsplit = gemmv ? (const unsigned short*)d->wsplit : nullptr;
   a.noise = (const float*)d->noise_const; a.noise_strength = (const float*)d->noise_strength;
   a.frgb_w = (const float*)d->fromrgb_weight; a.frgb_b = (const float*)d->fromrgb_bias;
   a.trgb_w = (const float*)d->torgb_weight; a.trgb_b = (const float*)d->torgb_bias;
@@ -919,6 +968,7 @@ int migan_prof_layer(int index, unsigned long long out[16]) {
 
 const char* migan_last_error(void) { return migan::last_error_ref().c_str(); }
 const char* migan_backend(void) { return rt::backend_name(); }
+const char* migan_gemm_variant(void) { return migan::tuning().gemm_bf16x3 ? "bf16x3" : "f32"; }
 int migan_version(void) { return 1; }
 
 }  // extern "C"

@@ -49,6 +49,7 @@ struct SepArgs {
   const float* wdw;            // conv1.weight [CI][1][3][3]
   const float* bdw;            // conv1.bias   [CI]
   const float* wpw;            // conv2.weight [CO][CI][1][1]
+  const unsigned short* wsplit;// GEMMV 1: conv2.weight as three bf16 planes [3][CO][CI] (split_weights_kernel), else null
   const float* noise;          // noise_const [HO][WO] or null
   const float* noise_strength; // scalar
   // EncoderBlock.fromrgb (reference :186,:194-195), only for FROMRGB instantiations
@@ -97,6 +98,26 @@ MIGAN_DEVICE MIGAN_INLINE f4 act4(f4 v) {
   t = t * 1.41421356237309515f;
   return f4{MIGAN_CLAMP(t.x, -256.0f, 256.0f), MIGAN_CLAMP(t.y, -256.0f, 256.0f), MIGAN_CLAMP(t.z, -256.0f, 256.0f),
             MIGAN_CLAMP(t.w, -256.0f, 256.0f)};
+}
+
+// ---- error-compensated bf16 GEMM operands -----------------------------------------------------
+// x = h1 + h2 + h3 (+ <= 2^-24 |x|) with h_i bf16: h1 = bf16(x), h2 = bf16(x - h1), h3 = bf16(x - h1 - h2)
+// (both subtractions are exact in fp32).  a*b is then summed from the six bf16 x bf16 products of
+// order <= 2^-16 (a1b1, a1b2, a2b1, a1b3, a2b2, a3b1), each exact in the MFMA's fp32 accumulator:
+// fp32-grade accuracy (whole-generator error vs fp64 7.7e-6, same as the fp32 path) at 6/16 of the
+// fp32-MFMA cost.
+typedef unsigned u2v __attribute__((ext_vector_type(2)));
+MIGAN_DEVICE MIGAN_INLINE float bf16lo_f32(unsigned pk) { return __builtin_bit_cast(float, pk << 16); }
+MIGAN_DEVICE MIGAN_INLINE float bf16hi_f32(unsigned pk) { return __builtin_bit_cast(float, pk & 0xffff0000u); }
+// split 4 floats into three planes of 4 bf16 (8 bytes each)
+MIGAN_DEVICE MIGAN_INLINE void split3_bf16(f4 v, u2v& h1, u2v& h2, u2v& h3) {
+  const unsigned a01 = MIGAN_PACK_BF16(v.x, v.y), a23 = MIGAN_PACK_BF16(v.z, v.w);
+  const f4 r1 = f4{v.x - bf16lo_f32(a01), v.y - bf16hi_f32(a01), v.z - bf16lo_f32(a23), v.w - bf16hi_f32(a23)};
+  const unsigned b01 = MIGAN_PACK_BF16(r1.x, r1.y), b23 = MIGAN_PACK_BF16(r1.z, r1.w);
+  const f4 r2 = f4{r1.x - bf16lo_f32(b01), r1.y - bf16hi_f32(b01), r1.z - bf16lo_f32(b23), r1.w - bf16hi_f32(b23)};
+  h1 = u2v{a01, a23};
+  h2 = u2v{b01, b23};
+  h3 = u2v{MIGAN_PACK_BF16(r2.x, r2.y), MIGAN_PACK_BF16(r2.z, r2.w)};
 }
 
 MIGAN_DEVICE MIGAN_INLINE f4 ld4(const float* p) { return *reinterpret_cast<const f4*>(p); }
@@ -150,9 +171,11 @@ MIGAN_DEVICE MIGAN_INLINE float up_prev3(const float* plane, int hp, int wp, int
 //   MINW   : launch bound, minimum waves per SIMD (= workgroups per CU)
 //   MAING  : compile-time tile geometry (8x16 pixels, one image per tile)
 //   PERSIST: workgroups walk several tiles and prefetch the next tile during the epilogue
+//   GEMMV  : 0 = exact fp32 MFMA (v_mfma_f32_32x32x2_f32); 1 = error-compensated bf16 MFMA
+//            (v_mfma_f32_32x32x16_bf16 x 6 on 3-way split operands, fp32 accumulate)
 //
 // Waves are laid out 2x2 over the MT x NT tile; each wave owns (MT/2)x(NT/2) as 32x32 MFMA tiles.
-template <int MODE, int MT, int NT, int KC, bool FROMRGB, int NI, int MINW, bool MAING, bool PERSIST>
+template <int MODE, int MT, int NT, int KC, bool FROMRGB, int NI, int MINW, bool MAING, bool PERSIST, int GEMMV>
 MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, MINW) sepconv_kernel(const SepArgs p) {
   static_assert(MODE != MODE_DOWN, "FIR-down layers run as dwfir_kernel + a MODE_PW pointwise GEMM");
   MIGAN_DYN_SMEM(smem);
@@ -168,8 +191,12 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, MINW) sepconv_kernel(const SepArgs p)
   constexpr int WROWS = MT / 2, WCOLS = NT / 2;    // per-wave tile
   constexpr int MTI = WROWS / 32, NTI = WCOLS / 32;
   static_assert(MTI >= 1 && NTI >= 1, "wave tile must be at least 32x32");
-  constexpr int NB = NT * QC / kThreads;           // float4 items of the 1x1 weight tile per thread
-  static_assert(NB >= 1 && NB * kThreads == NT * QC, "weight tile must split evenly over the threads");
+  constexpr bool BF = (GEMMV == 1);
+  constexpr int PB = KC * 2;                       // BF: bytes per row of one bf16 operand plane (XOR-swizzled 16-B slots, no padding)
+  constexpr int NSLOT = PB / 16;
+  constexpr int NB = BF ? 3 * NT * NSLOT / kThreads : NT * QC / kThreads;   // float4 items of the 1x1 weight tile per thread
+  static_assert(NB >= 1 && NB * kThreads == (BF ? 3 * NT * NSLOT : NT * QC), "weight tile must split evenly over the threads");
+  static_assert(!BF || KC == 32, "the bf16 GEMM variant is built for 32-channel chunks");
   constexpr int NW4 = KC * 10 / 4;                 // float4s of depthwise weights (9 taps) + bias per chunk
   constexpr int NF4 = FROMRGB ? KC * 5 / 4 : 0;    // float4s of fromrgb weights (4 per channel) + bias
   constexpr int SEGH = 4;                          // output rows per depthwise strip (NORMAL / UP)
@@ -232,6 +259,19 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, MINW) sepconv_kernel(const SepArgs p)
   float* w_s = smem + p.off_w;              // [KC*9] depthwise taps, [KC] bias, (FROMRGB: [KC*4] + [KC])
   float* g_s = smem;                        // after the K loop: [MT][GS], aliases the buffers above
   float* racc_s = smem + MT * GS;           // fused ToRGB partial sums [MT][4]
+  // A-operand row m, channels 4*c4..4*c4+3 of the current chunk
+  auto emit_a = [&](float* abase, int m, int c4, f4 v) {
+    if constexpr (BF) {
+      u2v h1, h2, h3;
+      split3_bf16(v, h1, h2, h3);
+      char* d = reinterpret_cast<char*>(abase) + m * PB + (((c4 >> 1) ^ ((m >> 2) & (NSLOT - 1))) << 4) + ((c4 & 1) << 3);
+      *reinterpret_cast<u2v*>(d) = h1;
+      *reinterpret_cast<u2v*>(d + MT * PB) = h2;
+      *reinterpret_cast<u2v*>(d + 2 * MT * PB) = h3;
+    } else {
+      st4(abase + m * AS + c4 * 4, v);
+    }
+  };
 
   // input-tile geometry (input-resolution coordinates)
   constexpr int HALO = (MODE == MODE_PW) ? 0 : 1;
@@ -274,7 +314,13 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, MINW) sepconv_kernel(const SepArgs p)
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
       const int i = tid + j * kThreads;
-      boff_[j] = (unsigned)((n0_ + (i >> LG_QC)) * p.CI + (i & (QC - 1)) * 4);
+      if constexpr (BF) {
+        // item = (plane, row n, 16-byte slot of 8 bf16); offset in bf16 elements inside [3][CO][CI]
+        const int plane = i / (NT * NSLOT), rem = i % (NT * NSLOT);
+        boff_[j] = (unsigned)(((plane * p.CO + n0_ + rem / NSLOT) * p.CI) + (rem % NSLOT) * 8);
+      } else {
+        boff_[j] = (unsigned)((n0_ + (i >> LG_QC)) * p.CI + (i & (QC - 1)) * 4);
+      }
     }
   };
   // FROMRGB: raw 4-channel network input (NCHW) of this thread's halo pixel (npix_in <= 256)
@@ -310,9 +356,15 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, MINW) sepconv_kernel(const SepArgs p)
 #pragma unroll
       for (int j = 0; j < NI; ++j) rin[j] = ld4(xk + goff_[j]);
     }
-    const float* __restrict__ wk = gwpw + k0;
+    if constexpr (BF) {
+      const unsigned short* __restrict__ wk = p.wsplit + k0;
 #pragma unroll
-    for (int j = 0; j < NB; ++j) rb[j] = ld4(wk + boff_[j]);
+      for (int j = 0; j < NB; ++j) rb[j] = ld4(reinterpret_cast<const float*>(wk + boff_[j]));
+    } else {
+      const float* __restrict__ wk = gwpw + k0;
+#pragma unroll
+      for (int j = 0; j < NB; ++j) rb[j] = ld4(wk + boff_[j]);
+    }
     // depthwise taps of channels [k0,k0+KC) are KC*9 contiguous floats of conv1.weight, then the bias
     if constexpr (MODE != MODE_PW) {
       if (tid < KC * 9 / 4) rw = ld4(gwdw + (size_t)k0 * 9 + (unsigned)(tid * 4));
@@ -364,7 +416,14 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, MINW) sepconv_kernel(const SepArgs p)
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
       const int i = tid + j * kThreads;
-      st4(bcur + (i >> LG_QC) * AS + (i & (QC - 1)) * 4, rb[j]);
+      if constexpr (BF) {
+        const int plane = i / (NT * NSLOT), rem = i % (NT * NSLOT);
+        const int n = rem / NSLOT, slot = rem % NSLOT;
+        char* dst = reinterpret_cast<char*>(bcur) + (plane * NT + n) * PB + ((slot ^ ((n >> 2) & (NSLOT - 1))) << 4);
+        st4(reinterpret_cast<float*>(dst), rb[j]);
+      } else {
+        st4(bcur + (i >> LG_QC) * AS + (i & (QC - 1)) * 4, rb[j]);
+      }
     }
     if constexpr (FROMRGB) {
       if (c == 0 && tid < npix_in) st4(rgb_s + tid * 4, rraw);
@@ -400,7 +459,7 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, MINW) sepconv_kernel(const SepArgs p)
           const int i = tid + j * kThreads;
           f4 v = rin[j];
           if (!(vmask & (1u << j))) v = f4{0.f, 0.f, 0.f, 0.f};
-          st4(acur + (i >> LG_QC) * AS + (i & (QC - 1)) * 4, v);
+          emit_a(acur, i >> LG_QC, i & (QC - 1), v);
         }
       } else if (wave_all_valid) {
 #pragma unroll
@@ -467,7 +526,7 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, MINW) sepconv_kernel(const SepArgs p)
           for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
             for (int kx = 0; kx < 3; ++kx) sacc += w[ky * 3 + kx] * win[(o + ky) % 3][kx];
-          st4(a_s + (mbase + (o << lgGW)) * AS + c4 * 4, act4(sacc));
+          emit_a(a_s, mbase + (o << lgGW), c4, act4(sacc));
         }
       }
       __syncthreads();
@@ -478,6 +537,42 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, MINW) sepconv_kernel(const SepArgs p)
     // v_mfma_f32_32x32x2_f32: lane l supplies A[i=l&31][k=l>>5] and B[k=l>>5][j=l&31].  Each lane
     // reads 4 consecutive k with one ds_read_b128; the two lane halves take k = 8kk+4*half+t, the
     // same for A and B, so any assignment of k to (half,t) sums the full K.
+    if constexpr (BF) {
+      // v_mfma_f32_32x32x16_bf16: lane l supplies A[i=l&31][k=8*(l>>5)..+7] and B[k=8*(l>>5)..+7][j=l&31]
+      // as one 16-byte LDS read each; three planes per operand, six MFMAs per 32x32 tile and k-step,
+      // smallest products first.
+      const char* ab = reinterpret_cast<const char*>(a_s + (MODE == MODE_PW ? (c & 1) * p.a_stride : 0));
+      const char* bb = reinterpret_cast<const char*>(bcur);
+#pragma unroll
+      for (int ks = 0; ks < KC / 16; ++ks) {
+        f4 av[MTI][3], bv[NTI][3];
+#pragma unroll
+        for (int i = 0; i < MTI; ++i) {
+          const int row = wm * WROWS + i * 32 + l31;
+          const char* q = ab + row * PB + (((2 * ks + half) ^ ((row >> 2) & (NSLOT - 1))) << 4);
+#pragma unroll
+          for (int pl = 0; pl < 3; ++pl) av[i][pl] = ld4(reinterpret_cast<const float*>(q + pl * MT * PB));
+        }
+#pragma unroll
+        for (int j = 0; j < NTI; ++j) {
+          const int row = wn * WCOLS + j * 32 + l31;
+          const char* q = bb + row * PB + (((2 * ks + half) ^ ((row >> 2) & (NSLOT - 1))) << 4);
+#pragma unroll
+          for (int pl = 0; pl < 3; ++pl) bv[j][pl] = ld4(reinterpret_cast<const float*>(q + pl * NT * PB));
+        }
+#pragma unroll
+        for (int i = 0; i < MTI; ++i)
+#pragma unroll
+          for (int j = 0; j < NTI; ++j) {
+            acc[i][j] = MIGAN_MFMA_BF16_32X32X16(av[i][2], bv[j][0], acc[i][j]);
+            acc[i][j] = MIGAN_MFMA_BF16_32X32X16(av[i][1], bv[j][1], acc[i][j]);
+            acc[i][j] = MIGAN_MFMA_BF16_32X32X16(av[i][0], bv[j][2], acc[i][j]);
+            acc[i][j] = MIGAN_MFMA_BF16_32X32X16(av[i][1], bv[j][0], acc[i][j]);
+            acc[i][j] = MIGAN_MFMA_BF16_32X32X16(av[i][0], bv[j][1], acc[i][j]);
+            acc[i][j] = MIGAN_MFMA_BF16_32X32X16(av[i][0], bv[j][0], acc[i][j]);
+          }
+      }
+    } else
     {
       const float* ap = a_s + (MODE == MODE_PW ? (c & 1) * p.a_stride : 0) + (wm * WROWS + l31) * AS + 4 * half;
       const float* bp = bcur + (wn * WCOLS + l31) * AS + 4 * half;
@@ -886,6 +981,32 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, 3) dwfir_kernel(const DwFirArgs p) {
       }
       st4(yb + (unsigned)((((img * HO) + gy0 + oy) * WO + gx0 + ox) * p.C + k0 + c4 * 4), a);
     }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// conv2.weight [CO][CI] fp32 -> three bf16 planes [3][CO*CI] for the error-compensated bf16 GEMM.
+// One launch per forward covers every layer (table of up to 40 tensors passed by value).
+struct SplitArgs {
+  const float* src[40];
+  unsigned long long dst_off[40];   // element offset of plane 0 inside `dst`
+  unsigned count[40];               // CO*CI
+  unsigned short* dst;
+  int n;
+};
+constexpr int kSplitBlocksPerTensor = 32;
+MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, 2) split_weights_kernel(const SplitArgs p) {
+  const int t = (int)blockIdx.x / kSplitBlocksPerTensor, blk = (int)blockIdx.x % kSplitBlocksPerTensor;
+  if (t >= p.n) return;
+  const unsigned cnt = p.count[t];
+  const float* __restrict__ src = p.src[t];
+  unsigned short* __restrict__ dst = p.dst + p.dst_off[t];
+  for (unsigned i = (blk * kThreads + threadIdx.x) * 4; i < cnt; i += kSplitBlocksPerTensor * kThreads * 4) {
+    u2v h1, h2, h3;
+    split3_bf16(ld4(src + i), h1, h2, h3);
+    *reinterpret_cast<u2v*>(dst + i) = h1;
+    *reinterpret_cast<u2v*>(dst + cnt + i) = h2;
+    *reinterpret_cast<u2v*>(dst + 2 * (size_t)cnt + i) = h3;
   }
 }
 

@@ -13,6 +13,13 @@
 // v_mfma_f32_32x32x2_f32: exact-f32 matrix FMA (D = A[32x2] * B[2x32] + C), 64 cycles per SIMD
 #define MIGAN_MFMA_F32_32X32X2(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 #define MIGAN_FMUL_RN(a, b) __fmul_rn((a), (b))
+// v_mfma_f32_32x32x16_bf16: D = A[32x16] * B[16x32] + C, operands as 8 bf16 (16 bytes) per lane
+typedef __bf16 migan_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 migan_bf16x2 __attribute__((ext_vector_type(2)));
+#define MIGAN_MFMA_BF16_32X32X16(a, b, c) \
+  __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(migan_bf16x8, (a)), __builtin_bit_cast(migan_bf16x8, (b)), (c), 0, 0, 0)
+// two fp32 -> packed bf16 pair, round to nearest even (v_cvt_pk_bf16_f32); low half = first argument
+#define MIGAN_PACK_BF16(lo, hi) __builtin_bit_cast(unsigned, migan_bf16x2{(__bf16)(lo), (__bf16)(hi)})
 #define MIGAN_CLAMP(v, lo, hi) __builtin_amdgcn_fmed3f((v), (lo), (hi))     // v_med3_f32
 // ds_swizzle bit mode: lane' = ((lane & and_mask) | or_mask) ^ xor_mask inside groups of 32 lanes
 #define MIGAN_SWIZZLE_XOR(v, m) __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, (v)), (((m) << 10) | 0x1f)))

@@ -34,14 +34,14 @@ class SepConvDesc(C.Structure):
         "x", "y", "skip", "conv1_weight", "conv1_bias", "conv2_weight", "noise_const", "noise_strength",
         "fromrgb_weight", "fromrgb_bias", "torgb_weight", "torgb_bias", "img_prev", "img_out")] + [
         (n, C.c_int) for n in ("batch", "cin", "cout", "res_in", "down", "up")] + [
-        ("scratch", C.c_void_p), ("scratch_bytes", C.c_size_t)]
+        ("scratch", C.c_void_p), ("scratch_bytes", C.c_size_t), ("wsplit", C.c_void_p), ("wsplit_bytes", C.c_size_t)]
 
 
 EXPORTS = (
     "migan_create", "migan_destroy", "migan_num_weights", "migan_weight_info", "migan_set_weight",
     "migan_commit", "migan_workspace_bytes", "migan_forward", "migan_num_launches", "migan_launch_info",
     "migan_forward_timed", "migan_set_debug", "migan_debug_tensor", "migan_sepconv_forward",
-    "migan_last_error", "migan_backend", "migan_version",
+    "migan_last_error", "migan_backend", "migan_gemm_variant", "migan_version",
 )
 
 
@@ -81,8 +81,9 @@ class MiganLib:
         L.migan_sepconv_forward.argtypes = [C.POINTER(SepConvDesc), vp]
         L.migan_last_error.restype = C.c_char_p
         L.migan_backend.restype = C.c_char_p
+        L.migan_gemm_variant.restype = C.c_char_p
         for name in EXPORTS:
-            if name not in ("migan_last_error", "migan_backend"):
+            if name not in ("migan_last_error", "migan_backend", "migan_gemm_variant"):
                 getattr(L, name).restype = ci
 
     # -- error mapping: EINVAL -> ValueError-like, like the reference's constructor / load_state_dict
@@ -101,10 +102,13 @@ class MiganLib:
     def backend(self) -> str:
         return self.lib.migan_backend().decode()
 
+    def gemm_variant(self) -> str:
+        return self.lib.migan_gemm_variant().decode()
+
     def sepconv_forward(self, stream: int = 0, **kw) -> None:
         d = SepConvDesc()
         for f, _ in SepConvDesc._fields_:
-            setattr(d, f, kw.pop(f, None if f not in ("batch", "cin", "cout", "res_in", "down", "up", "scratch_bytes") else 0))
+            setattr(d, f, kw.pop(f, None if f not in ("batch", "cin", "cout", "res_in", "down", "up", "scratch_bytes", "wsplit_bytes") else 0))
         if kw:
             raise TypeError(f"unknown sepconv fields: {sorted(kw)}")
         d.down = d.down or 1

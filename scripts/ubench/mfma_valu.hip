@@ -7,6 +7,7 @@
 #include <vector>
 typedef float f4 __attribute__((ext_vector_type(4)));
 typedef float f16v __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 __global__ void __launch_bounds__(512, 2) k(float* out, int iters, int role_lo, int role_hi, int mfma_per_iter, int valu_per_iter) {
   __shared__ float lds[8192];
@@ -25,6 +26,21 @@ __global__ void __launch_bounds__(512, 2) k(float* out, int iters, int role_lo, 
         a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(x, y, a1, 0, 0, 0);
         a2 = __builtin_amdgcn_mfma_f32_32x32x2f32(x, y, a2, 0, 0, 0);
         a3 = __builtin_amdgcn_mfma_f32_32x32x2f32(x, y, a3, 0, 0, 0);
+      }
+    }
+    for (int q = 0; q < 16; ++q) r += a0[q] + a1[q] + a2[q] + a3[q];
+  } else if (role == 3) {
+    // bf16 MFMA 32x32x16 (8 bf16 per lane for A and B)
+    f16v a0 = {}, a1 = {}, a2 = {}, a3 = {};
+    bf16x8 x, y;
+    for (int q = 0; q < 8; ++q) { x[q] = (__bf16)(threadIdx.x * 0.01f + q); y[q] = (__bf16)1.0f; }
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll 4
+      for (int j = 0; j < mfma_per_iter; j += 4) {
+        a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x, y, a0, 0, 0, 0);
+        a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x, y, a1, 0, 0, 0);
+        a2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x, y, a2, 0, 0, 0);
+        a3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x, y, a3, 0, 0, 0);
       }
     }
     for (int q = 0; q < 16; ++q) r += a0[q] + a1[q] + a2[q] + a3[q];
@@ -75,12 +91,14 @@ int main() {
       {"VALU only, 1 wave/SIMD", 256, 1, 1}, {"VALU only, 2 waves/SIMD", 512, 1, 1},
       {"MFMA wave + VALU wave per SIMD", 512, 0, 1}, {"LDS only, 1 wave/SIMD", 256, 2, 2},
       {"MFMA wave + LDS wave per SIMD", 512, 0, 2}, {"VALU wave + LDS wave per SIMD", 512, 1, 2},
+      {"bf16 MFMA only, 1 wave/SIMD", 256, 3, 3}, {"bf16 MFMA only, 2 waves/SIMD", 512, 3, 3},
+      {"bf16 MFMA wave + VALU wave per SIMD", 512, 3, 1}, {"bf16 MFMA wave + fp32 MFMA wave", 512, 3, 0},
   };
   for (auto& t : tests) {
     float ms = run(t.threads, t.lo, t.hi, iters, mpi, vpi);
     int nw_lo = 4, nw_hi = t.threads == 512 ? 4 : 0;
     double mf = 0, vf = 0, lb = 0;
-    auto add = [&](int role, int nw) { if (role == 0) mf += nw * mfma_flop_wave; if (role == 1) vf += nw * valu_flop_wave; if (role == 2) lb += nw * 1024.0 * vpi * iters; };
+    auto add = [&](int role, int nw) { if (role == 3) mf += nw * mfma_flop_wave * 8; if (role == 0) mf += nw * mfma_flop_wave; if (role == 1) vf += nw * valu_flop_wave; if (role == 2) lb += nw * 1024.0 * vpi * iters; };
     add(t.lo, nw_lo); add(t.hi, nw_hi);
     printf("%-34s %8.3f ms  MFMA %7.1f TF/s  VALU %7.1f TF/s  LDS %7.1f TB/s\n", t.name, ms, 256 * mf / ms / 1e9, 256 * vf / ms / 1e9, 256 * lb / ms / 1e9);
   }

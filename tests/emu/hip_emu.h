@@ -56,6 +56,7 @@ struct Block {
   unsigned wave_gen[kMaxWaves] = {0};
   int wave_alive[kMaxWaves] = {0};
   float xa[kMaxWaves][64], xb[kMaxWaves][64];
+  unsigned xq[kMaxWaves][64][4], yq[kMaxWaves][64][4];
   void (*invoke)(const void*) = nullptr;
   const void* arg = nullptr;
   char* stacks = nullptr;
@@ -168,6 +169,41 @@ inline emu_f16v hipemu_mfma_f32_32x32x2(float a, float bv, emu_f16v c) {
   return c;
 }
 #define MIGAN_MFMA_F32_32X32X2(a, b, c) hipemu_mfma_f32_32x32x2((a), (b), (c))
+
+// bf16 helpers and v_mfma_f32_32x32x16_bf16: lane l supplies A[i=l&31][k=8*(l>>5)+e] and
+// B[k=8*(l>>5)+e][j=l&31], e = 0..7 (16 bytes per operand per lane); C/D layout as the f32 form.
+inline unsigned hipemu_bf16_rne(float f) {
+  unsigned u;
+  std::memcpy(&u, &f, 4);
+  return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
+}
+#define MIGAN_PACK_BF16(lo, hi) (hipemu_bf16_rne(lo) | (hipemu_bf16_rne(hi) << 16))
+typedef float emu_f4 __attribute__((ext_vector_type(4)));
+inline emu_f16v hipemu_mfma_bf16_32x32x16(emu_f4 a, emu_f4 bv, emu_f16v c) {
+  hipemu::Block* b = hipemu::tl_blk;
+  const int w = b->cur >> 6, l = b->cur & 63;
+  std::memcpy(b->xq[w][l], &a, 16);
+  std::memcpy(b->yq[w][l], &bv, 16);
+  hipemu::wave_barrier();
+  const int j = l & 31, hh = l >> 5;
+  auto elem = [](const unsigned* q, int e) {
+    const unsigned pk = q[e >> 1];
+    const unsigned bits = (e & 1) ? (pk & 0xffff0000u) : (pk << 16);
+    float f;
+    std::memcpy(&f, &bits, 4);
+    return f;
+  };
+  for (int r = 0; r < 16; ++r) {
+    const int i = (r & 3) + 8 * (r >> 2) + 4 * hh;
+    double s = 0.0;
+    for (int k = 0; k < 16; ++k)
+      s += (double)elem(b->xq[w][i + 32 * (k >> 3)], k & 7) * (double)elem(b->yq[w][j + 32 * (k >> 3)], k & 7);
+    c[r] = (float)((double)c[r] + s);
+  }
+  hipemu::wave_barrier();
+  return c;
+}
+#define MIGAN_MFMA_BF16_32X32X16(a, b, c) hipemu_mfma_bf16_32x32x16((a), (b), (c))
 
 // ---- the runtime surface the host code uses ----------------------------------------------------------
 namespace rt {

@@ -48,10 +48,12 @@ def _run(lib, pkg, *, cin, cout, res_in, batch, down=1, up=1, noise=False, skip=
     nc = aligned(sd["m.noise_const"]) if noise else None
     ns = aligned(sd["m.noise_strength"].reshape(1)) if noise else None
     scratch = aligned(np.full((batch, res_out, res_out, cin), np.nan, dtype=np.float32)) if down == 2 else None
+    wsp = aligned(np.full((3 * cin * cout + 1) // 2 + 8, np.nan, dtype=np.float32))      # bf16 weight planes (bf16x3 GEMM)
     lib.sepconv_forward(x=ptr(xh), y=ptr(y), skip=ptr(skh), conv1_weight=ptr(w1), conv1_bias=ptr(b1),
                         conv2_weight=ptr(w2), noise_const=ptr(nc), noise_strength=ptr(ns),
                         batch=batch, cin=cin, cout=cout, res_in=res_in, down=down, up=up,
-                        scratch=ptr(scratch), scratch_bytes=0 if scratch is None else scratch.nbytes)
+                        scratch=ptr(scratch), scratch_bytes=0 if scratch is None else scratch.nbytes,
+                        wsplit=ptr(wsp), wsplit_bytes=wsp.nbytes)
     got = nchw(y)
     assert np.isfinite(got).all(), "kernel left NaNs (unwritten output or read of unwritten LDS)"
     tol = 2e-5 * max(1.0, float(np.abs(want).max()))

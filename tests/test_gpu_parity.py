@@ -65,8 +65,10 @@ def _sep(pkg, dev, *, cin, cout, res_in, batch, down=1, up=1, noise=False, skip=
     w = {k: t(v.reshape(1) if v.ndim == 0 else v) for k, v in sd.items()}
     p = lambda a: None if a is None else a.data_ptr()
     scratch = torch.full((batch, res_out, res_out, cin), float("nan"), device=dev) if down == 2 else None
+    wsp = torch.full(((3 * cin * cout + 1) // 2 + 8,), float("nan"), device=dev)           # bf16 weight planes (bf16x3 GEMM)
     lib.sepconv_forward(stream=int(torch.cuda.current_stream().cuda_stream), x=p(xh), y=p(y), skip=p(skh),
                         scratch=p(scratch), scratch_bytes=0 if scratch is None else scratch.numel() * 4,
+                        wsplit=p(wsp), wsplit_bytes=wsp.numel() * 4,
                         conv1_weight=p(w["m.conv1.weight"]), conv1_bias=p(w["m.conv1.bias"]), conv2_weight=p(w["m.conv2.weight"]),
                         noise_const=p(w.get("m.noise_const")), noise_strength=p(w.get("m.noise_strength")),
                         batch=batch, cin=cin, cout=cout, res_in=res_in, down=down, up=up)
@@ -251,3 +253,17 @@ def test_cpu_tensor_is_refused(pkg, dev):
     m = pkg.Generator(resolution=16)
     with pytest.raises(RuntimeError):
         m(torch.zeros(1, 4, 16, 16))
+
+
+def test_exact_fp32_mfma_variant_also_passes(pkg, dev):
+    """The default GEMM variant is the bf16x3-split MFMA; the exact fp32-MFMA kernels (MIGAN_GEMM=f32, read once
+    per process) must hold the same parity."""
+    import subprocess
+    import sys
+    assert pkg.load_library().gemm_variant() in ("bf16x3", "f32")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MIGAN_GEMM="f32")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", "tests/test_gpu_parity.py", "-k",
+                        "sepconv_operator or vs_numpy_oracle or full_size or every_layer"],
+                       cwd=root, env=env, capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
