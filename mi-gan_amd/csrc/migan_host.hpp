@@ -50,6 +50,7 @@ struct Geo {
   bool maing = true;               // compile-time tile geometry (8x16 pixels, one image)
   bool persist = false;            // kernel variant whose workgroups walk several tiles
   int gemmv = 0;                   // 0 exact fp32 MFMA, 1 bf16x3-split MFMA
+  bool torgb = false;              // kernel variant with the ToRGB tail in its epilogue
   int a_stride = 0;
   int lgGH = 3, lgGW = 4, lgIMGS = 0;
   int sy = 8, sx = 16, off = 0, lgRS = 1;
@@ -68,19 +69,19 @@ inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
 // Tuning knobs read once from the environment (experiments only; defaults are the shipped choice).
 struct Tuning {
-  int nt64_wgs_per_cu = 2;     // MIGAN_NT64_WGS: workgroups per CU targeted by the 64-column kernels (2 or 3)
   int force_single_b = 0;      // MIGAN_SINGLE_B=1: never double-buffer the 1x1 weight tile
   int gemm_bf16x3 = 1;         // MIGAN_GEMM=f32|bf16x3: exact fp32 MFMA, or (default, 12 % faster end to end, same parity)
                                // error-compensated bf16 MFMA: 6 products of 3-way bf16 splits, fp32 accumulate
+  int ablate = 0;              // MIGAN_ABLATE (measurement builds compiled with -DMIGAN_ABLATE only)
   int persist_min = 8192;      // MIGAN_PERSIST_MIN: launches with at least this many tiles run persistent workgroups
   int persist_grid = 512;      // MIGAN_PERSIST_GRID: ... that many (2 per CU on MI355X), each walking its share of tiles
 };
 inline Tuning& tuning() {
   static Tuning t = [] {
     Tuning v;
-    if (const char* e = std::getenv("MIGAN_NT64_WGS")) v.nt64_wgs_per_cu = (std::atoi(e) == 3) ? 3 : 2;
     if (const char* e = std::getenv("MIGAN_SINGLE_B")) v.force_single_b = std::atoi(e) != 0;
     if (const char* e = std::getenv("MIGAN_GEMM")) v.gemm_bf16x3 = (std::string(e) != "f32");
+    if (const char* e = std::getenv("MIGAN_ABLATE")) v.ablate = std::atoi(e);
     if (const char* e = std::getenv("MIGAN_PERSIST_MIN")) v.persist_min = std::max(1, std::atoi(e));
     if (const char* e = std::getenv("MIGAN_PERSIST_GRID")) v.persist_grid = std::max(8, std::atoi(e) / 8 * 8);   // multiple of 8: one share per XCD
     return v;
@@ -135,12 +136,13 @@ inline Geo choose_geo(int mode, int cin, int cout, int res_in, bool fromrgb, boo
   if (mode == MODE_PW) g.NI = 4;
   else g.NI = g.maing ? 6 : 9;
   MIGAN_CHECK(items <= g.NI, MIGAN_EINVAL, "internal: input tile too large");
-  g.MINW = (g.NT == 64) ? tuning().nt64_wgs_per_cu : 2;
+  g.MINW = 2;                                    // 2 workgroups per CU (3 measured slower: profiles/r01 notes)
   const int AS = g.KC + 4, GS = g.NT + 4;
   // operand tiles in floats: fp32 rows of pitch KC+4, or three unpadded (XOR-swizzled) bf16 planes
   const int asz = g.gemmv ? 3 * g.MT * (g.KC * 2) / 4 : g.MT * AS;
   const int bsz = g.gemmv ? 3 * g.NT * (g.KC * 2) / 4 : g.NT * AS;
-  const int gs = g.MT * GS + (fused_rgb ? g.MT * 4 : 0);
+  const int gs = g.MT * GS;   // accumulator tile; the fused ToRGB partial sums reuse its slots
+  (void)fused_rgb;
   const size_t limit = (size_t)(160 * 1024 / g.MINW);
   if (mode == MODE_PW) {
     // A and B operands double buffered: one barrier per K chunk
@@ -172,15 +174,19 @@ struct KernelEntry {
   int NI, MINW;
   bool maing, persist;
   int gemmv;
+  bool torgb;
   SepKernelFn fn;
   const char* name;
 };
 
-#define MIGAN_KERNEL1(MODE, MT, NT, KC, RGB, NI, MINW, MAING, PERSIST, GEMMV)                                                      \
-  {MODE, MT, NT, KC, RGB, NI, MINW, MAING, PERSIST, GEMMV, sepconv_kernel<MODE, MT, NT, KC, RGB, NI, MINW, MAING, PERSIST, GEMMV>, \
-   "migan::sepconv_kernel<" #MODE ", " #MT ", " #NT ", " #KC ", " #RGB ", " #NI ", " #MINW ", " #MAING ", " #PERSIST ", " #GEMMV ">"}
+#define MIGAN_KERNEL1(MODE, MT, NT, KC, RGB, NI, MINW, MAING, PERSIST, GEMMV, TORGB)                                                      \
+  {MODE, MT, NT, KC, RGB, NI, MINW, MAING, PERSIST, GEMMV, TORGB,                                                                        \
+   sepconv_kernel<MODE, MT, NT, KC, RGB, NI, MINW, MAING, PERSIST, GEMMV, TORGB>,                                                        \
+   "migan::sepconv_kernel<" #MODE ", " #MT ", " #NT ", " #KC ", " #RGB ", " #NI ", " #MINW ", " #MAING ", " #PERSIST ", " #GEMMV ", " #TORGB ">"}
 #define MIGAN_KERNEL(MODE, MT, NT, KC, RGB, NI, MINW, MAING, PERSIST) \
-  MIGAN_KERNEL1(MODE, MT, NT, KC, RGB, NI, MINW, MAING, PERSIST, 0), MIGAN_KERNEL1(MODE, MT, NT, KC, RGB, NI, MINW, MAING, PERSIST, 1)
+  MIGAN_KERNEL1(MODE, MT, NT, KC, RGB, NI, MINW, MAING, PERSIST, 0, false), MIGAN_KERNEL1(MODE, MT, NT, KC, RGB, NI, MINW, MAING, PERSIST, 1, false)
+#define MIGAN_KERNEL_TORGB(NT, NI, MAING) \
+  MIGAN_KERNEL1(0, 128, NT, 32, false, NI, 2, MAING, false, 0, true), MIGAN_KERNEL1(0, 128, NT, 32, false, NI, 2, MAING, false, 1, true)
 
 inline const std::vector<KernelEntry>& kernel_table() {
   static const std::vector<KernelEntry> t = {
@@ -191,6 +197,8 @@ inline const std::vector<KernelEntry>& kernel_table() {
       MIGAN_KERNEL(0, 128, 128, 32, true, 6, 2, true, false),  MIGAN_KERNEL(0, 128, 128, 32, true, 9, 2, false, false),
       MIGAN_KERNEL(0, 128, 64, 32, true, 6, 2, true, false),   MIGAN_KERNEL(0, 128, 64, 32, true, 9, 2, false, false),
       MIGAN_KERNEL(0, 128, 64, 32, true, 6, 2, true, true),
+      // plain layers whose epilogue also produces the running RGB image (CO == NT)
+      MIGAN_KERNEL_TORGB(128, 6, true), MIGAN_KERNEL_TORGB(128, 9, false), MIGAN_KERNEL_TORGB(64, 6, true), MIGAN_KERNEL_TORGB(64, 9, false),
       // FIR-up layers (MODE 2)
       MIGAN_KERNEL(2, 128, 128, 32, false, 6, 2, true, false), MIGAN_KERNEL(2, 128, 128, 32, false, 9, 2, false, false),
       MIGAN_KERNEL(2, 128, 64, 32, false, 6, 2, true, false),  MIGAN_KERNEL(2, 128, 64, 32, false, 9, 2, false, false),
@@ -206,7 +214,7 @@ inline const std::vector<KernelEntry>& kernel_table() {
 inline const KernelEntry& pick_kernel(const Geo& g) {
   for (const auto& e : kernel_table())
     if (e.mode == g.mode && e.MT == g.MT && e.NT == g.NT && e.KC == g.KC && e.fromrgb == g.fromrgb && e.NI == g.NI &&
-        e.MINW == g.MINW && e.maing == g.maing && e.persist == g.persist && e.gemmv == g.gemmv)
+        e.MINW == g.MINW && e.maing == g.maing && e.persist == g.persist && e.gemmv == g.gemmv && e.torgb == g.torgb)
       return e;
   throw Error(MIGAN_EINVAL, "internal: no kernel instantiation for this geometry");
 }
@@ -283,6 +291,7 @@ inline void fill_geo(SepArgs& a, const Geo& g) {
   a.off_a = g.off_a; a.off_b = g.off_b; a.off_v = g.off_v; a.off_rgb = g.off_rgb; a.off_w = g.off_w;
   a.b_stride = g.b_stride;
   a.a_stride = g.a_stride;
+  a.ablate = tuning().ablate;
   a.prof = prof_buffer();
 }
 
@@ -304,6 +313,9 @@ inline void launch_sepconv(Geo g, const SepArgs& a, rt::stream_t stream) {
   prepare_kernels();
   const bool fused_rgb = a.trgb_w != nullptr;
   g.persist = use_persistent(g, a.B, fused_rgb);
+  g.torgb = fused_rgb;
+  MIGAN_CHECK(!fused_rgb || (g.mode == MODE_NORMAL && !g.fromrgb && g.nchunks == 1 && g.MINW == 2), MIGAN_EINVAL,
+              "ToRGB can only be fused into a plain layer whose output channels fit one column tile");
   const KernelEntry& k = pick_kernel(g);
   rt_check(rt::launch(k.fn, a, grid_of(g, a.B, fused_rgb), kThreads, g.lds_bytes, stream), k.name);
 }
@@ -589,6 +601,8 @@ inline void migan_handle::build_plan() {
     if (l2.g.nchunks == 1) {
       // one workgroup owns all output channels of its pixels: ToRGB fused into the conv2 epilogue
       l2.w_trgb = wt; l2.b_trgb = bt;
+      l2.g.torgb = true;
+      l2.kernel = pick_kernel(l2.g).name;
       l2.imgprev_buf = img_cur; l2.imgout_buf = img_out;
       l2.flops += rgb_flops; l2.bytes += rgb_bytes;
     } else {
@@ -688,6 +702,7 @@ inline void migan_handle::forward(const float* x, float* y, int batch, void* ws,
       launch_sepconv(L.g, a, stream);
       Geo gl = L.g;
       gl.persist = use_persistent(gl, batch, a.trgb_w != nullptr);
+      gl.torgb = a.trgb_w != nullptr;
       L.kernel_last = pick_kernel(gl).name;
     }
     if (timed) rt_check(rt::event_record(events[2 * li + 1], stream), "hipEventRecord");

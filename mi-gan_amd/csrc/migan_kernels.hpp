@@ -70,6 +70,8 @@ struct SepArgs {
   int off_a, off_b, off_v, off_rgb, off_w;   // LDS carve, in floats
   int b_stride;                    // floats between the two 1x1-weight buffers (0 = single buffered)
   int a_stride;                    // MODE_PW: floats between the two A-operand buffers
+  int ablate;                      // measurement builds only (MIGAN_ABLATE): bit0 no epilogue stores, bit1 no epilogue,
+                                   // bit2 no depthwise stage, bit3 no MFMA, bit4 no global input loads; 0 in production
 };
 
 struct RgbArgs {
@@ -149,6 +151,30 @@ MIGAN_DEVICE MIGAN_INLINE float up_prev3(const float* plane, int hp, int wp, int
   return (vy0 ? wy0 * r0 : 0.0f) + (vy1 ? (1.0f - wy0) * r1 : 0.0f);
 }
 
+// the same in two steps: load the (clamped) 2x2 taps early, combine them later
+MIGAN_DEVICE MIGAN_INLINE void up_taps(const float* plane, int hp, int wp, int oy, int ox, float (&t)[4]) {
+  const int iy = oy >> 1, ix = ox >> 1;
+  const int y0 = (oy & 1) ? iy : iy - 1, x0 = (ox & 1) ? ix : ix - 1;
+  const int cy0 = y0 >= 0 ? y0 : 0, cy1 = y0 + 1 < hp ? y0 + 1 : hp - 1, cx0 = x0 >= 0 ? x0 : 0, cx1 = x0 + 1 < wp ? x0 + 1 : wp - 1;
+  t[0] = plane[(size_t)cy0 * wp + cx0]; t[1] = plane[(size_t)cy0 * wp + cx1];
+  t[2] = plane[(size_t)cy1 * wp + cx0]; t[3] = plane[(size_t)cy1 * wp + cx1];
+}
+MIGAN_DEVICE MIGAN_INLINE float up_combine(const float (&t)[4], int oy, int ox, int hp, int wp) {
+  const int iy = oy >> 1, ix = ox >> 1;
+  const int y0 = (oy & 1) ? iy : iy - 1, x0 = (ox & 1) ? ix : ix - 1;
+  const float wy0 = (oy & 1) ? 0.75f : 0.25f, wx0 = (ox & 1) ? 0.75f : 0.25f;
+  const bool vy0 = y0 >= 0, vy1 = y0 + 1 < hp, vx0 = x0 >= 0, vx1 = x0 + 1 < wp;
+  const float r0 = (vx0 ? wx0 * t[0] : 0.0f) + (vx1 ? (1.0f - wx0) * t[1] : 0.0f);
+  const float r1 = (vx0 ? wx0 * t[2] : 0.0f) + (vx1 ? (1.0f - wx0) * t[3] : 0.0f);
+  return (vy0 ? wy0 * r0 : 0.0f) + (vy1 ? (1.0f - wy0) * r1 : 0.0f);
+}
+
+#ifdef MIGAN_ABLATE
+#define MIGAN_ABL(bit) ((p.ablate & (bit)) != 0)
+#else
+#define MIGAN_ABL(bit) false
+#endif
+
 #ifdef MIGAN_PHASE_PROF
 #define PROF_BEGIN() long long prof_t = (long long)MIGAN_CLOCK(); long long prof_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
 #define PROF_MARK(i) do { const long long n_ = (long long)MIGAN_CLOCK(); prof_acc[i] += n_ - prof_t; prof_t = n_; } while (0)
@@ -175,7 +201,7 @@ MIGAN_DEVICE MIGAN_INLINE float up_prev3(const float* plane, int hp, int wp, int
 //            (v_mfma_f32_32x32x16_bf16 x 6 on 3-way split operands, fp32 accumulate)
 //
 // Waves are laid out 2x2 over the MT x NT tile; each wave owns (MT/2)x(NT/2) as 32x32 MFMA tiles.
-template <int MODE, int MT, int NT, int KC, bool FROMRGB, int NI, int MINW, bool MAING, bool PERSIST, int GEMMV>
+template <int MODE, int MT, int NT, int KC, bool FROMRGB, int NI, int MINW, bool MAING, bool PERSIST, int GEMMV, bool TORGB>
 MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, MINW) sepconv_kernel(const SepArgs p) {
   static_assert(MODE != MODE_DOWN, "FIR-down layers run as dwfir_kernel + a MODE_PW pointwise GEMM");
   MIGAN_DYN_SMEM(smem);
@@ -255,10 +281,10 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, MINW) sepconv_kernel(const SepArgs p)
   float* a_s = smem + p.off_a;              // [MT][AS]
   float* b_s = smem + p.off_b;              // [NT][AS] x (1 or 2 buffers)
   float* v_s = smem + p.off_v;              // DOWN: depthwise grid [IMGS][2GH+2][2GW+2][KC]
+  static_assert(!TORGB || (MODE == MODE_NORMAL && !PERSIST), "ToRGB is fused into plain, non-persistent layers only");
   float* rgb_s = smem + p.off_rgb;          // FROMRGB: [npix_in][4]
   float* w_s = smem + p.off_w;              // [KC*9] depthwise taps, [KC] bias, (FROMRGB: [KC*4] + [KC])
   float* g_s = smem;                        // after the K loop: [MT][GS], aliases the buffers above
-  float* racc_s = smem + MT * GS;           // fused ToRGB partial sums [MT][4]
   // A-operand row m, channels 4*c4..4*c4+3 of the current chunk
   auto emit_a = [&](float* abase, int m, int c4, f4 v) {
     if constexpr (BF) {
@@ -353,8 +379,13 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, MINW) sepconv_kernel(const SepArgs p)
   auto issue_loads = [&](int b0_, const unsigned (&goff_)[NI], const unsigned (&boff_)[NB], int k0) {
     if constexpr (!FROMRGB) {
       const float* __restrict__ xk = gx_ + (size_t)b0_ * p.H * p.W * p.CI + k0;
+      if (MIGAN_ABL(16)) {
 #pragma unroll
-      for (int j = 0; j < NI; ++j) rin[j] = ld4(xk + goff_[j]);
+        for (int j = 0; j < NI; ++j) rin[j] = f4{0.5f, 0.25f, -0.5f, 1.0f};
+      } else {
+#pragma unroll
+        for (int j = 0; j < NI; ++j) rin[j] = ld4(xk + goff_[j]);
+      }
     }
     if constexpr (BF) {
       const unsigned short* __restrict__ wk = p.wsplit + k0;
@@ -494,6 +525,7 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, MINW) sepconv_kernel(const SepArgs p)
     // from LDS) is scattered into three running sums (the outputs it is the bottom / middle / top
     // tap row of), so each LDS value is read once per column and no register window is kept.
     if constexpr (MODE != MODE_PW) {
+      if (!MIGAN_ABL(4)) {
       const int RS = 1 << lgRS;
       const int ncols = (IMGS * GW * QC) << lgRS;
       for (int it = tid; it < ncols; it += kThreads) {
@@ -529,6 +561,7 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, MINW) sepconv_kernel(const SepArgs p)
           emit_a(a_s, mbase + (o << lgGW), c4, act4(sacc));
         }
       }
+      }
       __syncthreads();
     }
     PROF_MARK(2);
@@ -537,7 +570,8 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, MINW) sepconv_kernel(const SepArgs p)
     // v_mfma_f32_32x32x2_f32: lane l supplies A[i=l&31][k=l>>5] and B[k=l>>5][j=l&31].  Each lane
     // reads 4 consecutive k with one ds_read_b128; the two lane halves take k = 8kk+4*half+t, the
     // same for A and B, so any assignment of k to (half,t) sums the full K.
-    if constexpr (BF) {
+    if (MIGAN_ABL(8)) {
+    } else if constexpr (BF) {
       // v_mfma_f32_32x32x16_bf16: lane l supplies A[i=l&31][k=8*(l>>5)..+7] and B[k=8*(l>>5)..+7][j=l&31]
       // as one 16-byte LDS read each; three planes per operand, six MFMAs per 32x32 tile and k-step,
       // smallest products first.
@@ -595,6 +629,7 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, MINW) sepconv_kernel(const SepArgs p)
     PROF_MARK(3);
   }
 
+  if (!MIGAN_ABL(2)) {
   // ======================================= epilogue ========================================
   // `tide` is the thread id laundered through an empty asm: everything the epilogue derives from it
   // is then recomputed per tile instead of being hoisted above the K loop by LICM (which would keep
@@ -645,12 +680,28 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, MINW) sepconv_kernel(const SepArgs p)
   const float* __restrict__ sb = gskip ? gskip + (size_t)b0 * img_elems : nullptr;
 
   if constexpr (MODE != MODE_UP) {
-    const bool do_rgb = p.trgb_w != nullptr;
+    constexpr bool do_rgb = TORGB;          // ToRGB fused into this epilogue (host: CO == NT, trgb_w set)
     f4 tw0 = {0.f, 0.f, 0.f, 0.f}, tw1 = tw0, tw2 = tw0;
-    if (do_rgb) {
+    if constexpr (do_rgb) {
       tw0 = ld4(p.trgb_w + n0 + c4 * 4);
       tw1 = ld4(p.trgb_w + p.CO + n0 + c4 * 4);
       tw2 = ld4(p.trgb_w + 2 * p.CO + n0 + c4 * 4);
+    }
+    // tail-pass pixel of this thread pair and the taps of the previous (half resolution) RGB image under it
+    int rgb_oy = 0, rgb_ox = 0, rgb_b = 0;
+    bool rgb_ok = false;
+    float pv[3][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    if constexpr (do_rgb) {
+      const int m = tide >> 1;
+      rgb_oy = gy0 + ((m >> lgGW) & (GH - 1));
+      rgb_ox = gx0 + (m & (GW - 1));
+      rgb_b = b0 + (m >> (lgGW + lgGH));
+      rgb_ok = (tide & 1) == 0 && rgb_b < p.B;
+      if (rgb_ok && p.img_prev) {
+        const size_t plane4 = ((size_t)p.HO * p.WO) >> 2;
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) up_taps(p.img_prev + ((size_t)rgb_b * 3 + ch) * plane4, p.HO >> 1, p.WO >> 1, rgb_oy, rgb_ox, pv[ch]);
+      }
     }
     const unsigned pix_t = (unsigned)((gy0 + gyt) * p.WO + gx0 + gxt);   // first pixel of this thread
     const unsigned off_t = pix_t * (unsigned)p.CO + (unsigned)(n0 + c4 * 4);
@@ -690,49 +741,38 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, MINW) sepconv_kernel(const SepArgs p)
         v = act4(v);
         f4 outv = v;
         if constexpr (HS) outv = v + sk[u];
-        if (ok[u]) st4(yb + (size_t)upix[u] * p.CO + loff[u], outv);
-        if constexpr (QN <= 32) if (do_rgb) {
-          // ToRGB: 3 dot products over the CO channels of this pixel; the QN lanes holding one pixel
-          // are contiguous in the wave -> butterfly reduction with wave shuffles.
-          float r0 = v.x * tw0.x + v.y * tw0.y + v.z * tw0.z + v.w * tw0.w;
-          float r1 = v.x * tw1.x + v.y * tw1.y + v.z * tw1.z + v.w * tw1.w;
-          float r2 = v.x * tw2.x + v.y * tw2.y + v.z * tw2.z + v.w * tw2.w;
-          // xor butterfly over the QN <= 32 lanes of this pixel with ds_swizzle (no address VGPRs)
-          static_assert(QN <= 32, "fused ToRGB needs one pixel inside 32 lanes");
-          if constexpr (QN >= 32) { r0 += MIGAN_SWIZZLE_XOR(r0, 16); r1 += MIGAN_SWIZZLE_XOR(r1, 16); r2 += MIGAN_SWIZZLE_XOR(r2, 16); }
-          r0 += MIGAN_SWIZZLE_XOR(r0, 8); r1 += MIGAN_SWIZZLE_XOR(r1, 8); r2 += MIGAN_SWIZZLE_XOR(r2, 8);
-          r0 += MIGAN_SWIZZLE_XOR(r0, 4); r1 += MIGAN_SWIZZLE_XOR(r1, 4); r2 += MIGAN_SWIZZLE_XOR(r2, 4);
-          r0 += MIGAN_SWIZZLE_XOR(r0, 2); r1 += MIGAN_SWIZZLE_XOR(r1, 2); r2 += MIGAN_SWIZZLE_XOR(r2, 2);
-          r0 += MIGAN_SWIZZLE_XOR(r0, 1); r1 += MIGAN_SWIZZLE_XOR(r1, 1); r2 += MIGAN_SWIZZLE_XOR(r2, 1);
-          if (c4 == 0) st4(racc_s + (m0 + (it0 + u) * STEP) * 4, f4{r0, r1, r2, 0.0f});
+        if (ok[u] && !MIGAN_ABL(1)) st4(yb + (size_t)upix[u] * p.CO + loff[u], outv);
+        if constexpr (do_rgb) {
+          // ToRGB (reference :312): this lane's share of the 3 dot products over the CO channels of the pixel
+          // goes into the g_s slot the item just consumed; the per-pixel sums are formed in the tail pass below.
+          const float r0 = v.x * tw0.x + v.y * tw0.y + v.z * tw0.z + v.w * tw0.w;
+          const float r1 = v.x * tw1.x + v.y * tw1.y + v.z * tw1.z + v.w * tw1.w;
+          const float r2 = v.x * tw2.x + v.y * tw2.y + v.z * tw2.z + v.w * tw2.w;
+          st4(g_s + (m0 + (it0 + u) * STEP) * GS + c4 * 4, f4{r0, r1, r2, 0.0f});
         }
       }
     }
     };
     if (has_noise) { if (sb) epi_items(TrueT{}, TrueT{}); else epi_items(TrueT{}, FalseT{}); }
     else { if (sb) epi_items(FalseT{}, TrueT{}); else epi_items(FalseT{}, FalseT{}); }
-    if (do_rgb) {
-      // second pass, one thread per pixel: bias + 2x-upsampled previous image (reference :308-313),
-      // planar store (consecutive threads -> consecutive x)
+    if constexpr (do_rgb) {
+      // tail pass: two threads per pixel each sum half of the QN partials of its row of g_s, one ds_swizzle
+      // exchange combines them; the even thread adds bias + the 2x-upsampled previous image (its 4 taps per
+      // channel were loaded before the item loop) and writes the three planes (consecutive x per lane pair).
       __syncthreads();
-      if (tide < MT) {
-        const int m = tide;
-        const int gx = m & (GW - 1);
-        const int gy = (m >> lgGW) & (GH - 1);
-        const int img = m >> (lgGW + lgGH);
-        const int oy = gy0 + gy, ox = gx0 + gx, b = b0 + img;
-        if (b < p.B) {
-          const f4 r = ld4(racc_s + m * 4);
-          const float rgb[3] = {r.x + p.trgb_b[0], r.y + p.trgb_b[1], r.z + p.trgb_b[2]};
-          const size_t plane = (size_t)p.HO * p.WO;
+      const int m = tide >> 1, hsel = tide & 1;
+      f4 sum = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-          for (int ch = 0; ch < 3; ++ch) {
-            float up = 0.0f;
-            if (p.img_prev)
-              up = up_prev3(p.img_prev + ((size_t)b * 3 + ch) * (plane >> 2), p.HO >> 1, p.WO >> 1, oy, ox);
-            p.img_out[((size_t)b * 3 + ch) * plane + (size_t)oy * p.WO + ox] = up + rgb[ch];
-          }
-        }
+      for (int q = 0; q < QN / 2; ++q) sum += ld4(g_s + m * GS + (hsel * (QN / 2) + q) * 4);
+      sum.x += MIGAN_SWIZZLE_XOR(sum.x, 1);
+      sum.y += MIGAN_SWIZZLE_XOR(sum.y, 1);
+      sum.z += MIGAN_SWIZZLE_XOR(sum.z, 1);
+      if (rgb_ok) {
+        const float rgb[3] = {sum.x + p.trgb_b[0], sum.y + p.trgb_b[1], sum.z + p.trgb_b[2]};
+        const size_t plane = (size_t)p.HO * p.WO;
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch)
+          p.img_out[((size_t)rgb_b * 3 + ch) * plane + (size_t)rgb_oy * p.WO + rgb_ox] = up_combine(pv[ch], rgb_oy, rgb_ox, p.HO >> 1, p.WO >> 1) + rgb[ch];
       }
     }
   } else {
@@ -802,16 +842,17 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, MINW) sepconv_kernel(const SepArgs p)
           if constexpr (HN) v += MIGAN_FMUL_RN(nz[a][bb], ns);
           v = act4(v);
           if constexpr (HS) v += sk[a][bb];
-          st4(yb + (unsigned)(loff + (upix + a * p.WO + bb) * p.CO), v);
+          if (!MIGAN_ABL(1)) st4(yb + (unsigned)(loff + (upix + a * p.WO + bb) * p.CO), v);
         }
     }
     };
     if (has_noise) { if (sb) epi_items(TrueT{}, TrueT{}); else epi_items(TrueT{}, FalseT{}); }
     else { if (sb) epi_items(FalseT{}, TrueT{}); else epi_items(FalseT{}, FalseT{}); }
   }
+  }
   PROF_MARK(5);
   if (!has_next) break;
-  __syncthreads();                       // epilogue reads of g_s/racc_s done before the next tile refills LDS
+  __syncthreads();                       // epilogue reads of g_s done before the next tile refills LDS
   tl += tstep;
   n0 = n0n; b0 = b0n; gy0 = gy0n; gx0 = gx0n; vmask = vmaskn;
 #pragma unroll

@@ -22,7 +22,13 @@ typedef __bf16 migan_bf16x2 __attribute__((ext_vector_type(2)));
 #define MIGAN_PACK_BF16(lo, hi) __builtin_bit_cast(unsigned, migan_bf16x2{(__bf16)(lo), (__bf16)(hi)})
 #define MIGAN_CLAMP(v, lo, hi) __builtin_amdgcn_fmed3f((v), (lo), (hi))     // v_med3_f32
 // ds_swizzle bit mode: lane' = ((lane & and_mask) | or_mask) ^ xor_mask inside groups of 32 lanes
-#define MIGAN_SWIZZLE_XOR(v, m) __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, (v)), (((m) << 10) | 0x1f)))
+// (a function, not a macro body: __builtin_bit_cast applied directly to a vector element lvalue such as `v.y`
+// reads element 0 with this compiler; passing the float by value is safe)
+template <int M>
+__device__ __forceinline__ float migan_swizzle_xor(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), ((M << 10) | 0x1f)));
+}
+#define MIGAN_SWIZZLE_XOR(v, m) migan_swizzle_xor<(m)>(v)
 #define MIGAN_OPAQUE(x) asm volatile("" : "+v"(x))
 #define MIGAN_CLOCK() __builtin_readcyclecounter()
 #define MIGAN_ATOMIC_ADD_U64(p, v) atomicAdd((p), (v))

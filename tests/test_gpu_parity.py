@@ -97,6 +97,73 @@ def test_sepconv_operator(pkg, dev, kw):
     _sep(pkg, dev, **kw)
 
 
+@pytest.mark.parametrize("with_prev,cout,res,batch", [(False, 64, 16, 2), (True, 64, 32, 1), (True, 128, 16, 2), (True, 128, 8, 3),
+                                                      (True, 64, 4, 5)])
+def test_sepconv_with_fused_torgb(pkg, dev, with_prev, cout, res, batch):
+    """conv2 of a synthesis block with the ToRGB + running-image update fused into its epilogue
+    (reference :308-313): both the feature map and the three image planes."""
+    lib = pkg.load_library()
+    s = pkg.synth
+    cin, seed = cout, 9
+    sd = {"m.conv1.weight": (s.normal((cin, 1, 3, 3), seed, "w1") * 0.4).astype(np.float32),
+          "m.conv1.bias": (s.normal((cin,), seed, "b1") * 0.5).astype(np.float32),
+          "m.conv2.weight": (s.normal((cout, cin, 1, 1), seed, "w2") / np.sqrt(cin)).astype(np.float32),
+          "m.noise_const": s.normal((res, res), seed, "nc").astype(np.float32),
+          "m.noise_strength": np.asarray(0.21, dtype=np.float32)}
+    tw = (s.normal((3, cout, 1, 1), seed, "tw") / np.sqrt(cout)).astype(np.float32)
+    tb = (s.normal((3,), seed, "tb") * 0.3).astype(np.float32)
+    x = s.normal((batch, cin, res, res), seed, "x").astype(np.float32)
+    prev = s.normal((batch, 3, res // 2, res // 2), seed, "prev").astype(np.float32) if with_prev else None
+    feat = orc.separable_conv(x.copy(), sd, "m")
+    want_img = orc.pointwise(feat, tw, tb)
+    if with_prev:
+        want_img = orc.upsample2d(prev) + want_img
+    t = lambda a: None if a is None else torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    p = lambda a: None if a is None else a.data_ptr()
+    xh = t(np.transpose(x, (0, 2, 3, 1)))
+    y = torch.full((batch, res, res, cout), float("nan"), device=dev)
+    img = torch.full((batch, 3, res, res), float("nan"), device=dev)
+    w = {k: t(v.reshape(1) if v.ndim == 0 else v) for k, v in sd.items()}
+    twd, tbd, pvd = t(tw), t(tb), t(prev)
+    wsp = torch.full(((3 * cin * cout + 1) // 2 + 8,), float("nan"), device=dev)
+    lib.sepconv_forward(stream=int(torch.cuda.current_stream().cuda_stream), x=p(xh), y=p(y), wsplit=p(wsp), wsplit_bytes=wsp.numel() * 4,
+                        conv1_weight=p(w["m.conv1.weight"]), conv1_bias=p(w["m.conv1.bias"]), conv2_weight=p(w["m.conv2.weight"]),
+                        noise_const=p(w["m.noise_const"]), noise_strength=p(w["m.noise_strength"]),
+                        torgb_weight=p(twd), torgb_bias=p(tbd), img_prev=p(pvd), img_out=p(img),
+                        batch=batch, cin=cin, cout=cout, res_in=res)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(y.permute(0, 3, 1, 2).cpu().numpy(), feat, rtol=0, atol=2e-5 * max(1.0, float(np.abs(feat).max())))
+    np.testing.assert_allclose(img.cpu().numpy(), want_img, rtol=0, atol=2e-5 * max(1.0, float(np.abs(want_img).max())))
+
+
+@pytest.mark.parametrize("cin,cout,res,batch", [(64, 64, 32, 2), (128, 128, 16, 1), (64, 128, 8, 3)])
+def test_sepconv_with_fused_fromrgb(pkg, dev, cin, cout, res, batch):
+    """conv1 of the first encoder block: act(fromrgb(x)) built in LDS from the NCHW network input (reference :193-196)."""
+    lib = pkg.load_library()
+    s = pkg.synth
+    seed = 7
+    sd = {"m.conv1.weight": (s.normal((cin, 1, 3, 3), seed, "w1") * 0.4).astype(np.float32),
+          "m.conv1.bias": (s.normal((cin,), seed, "b1") * 0.5).astype(np.float32),
+          "m.conv2.weight": (s.normal((cout, cin, 1, 1), seed, "w2") / np.sqrt(cin)).astype(np.float32)}
+    fw = (s.normal((cin, 4, 1, 1), seed, "fw") * 0.5).astype(np.float32)
+    fb = (s.normal((cin,), seed, "fb") * 0.2).astype(np.float32)
+    img = s.make_input(batch, res, seed=seed)
+    want = orc.separable_conv(orc.lrelu_agc(orc.pointwise(img, fw, fb)), sd, "m")
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    xd = t(img)
+    y = torch.full((batch, res, res, cout), float("nan"), device=dev)
+    w = {k: t(v) for k, v in sd.items()}
+    fwd, fbd = t(fw), t(fb)
+    wsp = torch.full(((3 * cin * cout + 1) // 2 + 8,), float("nan"), device=dev)
+    lib.sepconv_forward(stream=int(torch.cuda.current_stream().cuda_stream), x=xd.data_ptr(), y=y.data_ptr(),
+                        wsplit=wsp.data_ptr(), wsplit_bytes=wsp.numel() * 4,
+                        conv1_weight=w["m.conv1.weight"].data_ptr(), conv1_bias=w["m.conv1.bias"].data_ptr(),
+                        conv2_weight=w["m.conv2.weight"].data_ptr(), fromrgb_weight=fwd.data_ptr(), fromrgb_bias=fbd.data_ptr(),
+                        batch=batch, cin=cin, cout=cout, res_in=res)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(y.permute(0, 3, 1, 2).cpu().numpy(), want, rtol=0, atol=2e-5 * max(1.0, float(np.abs(want).max())))
+
+
 # ----------------------------------------------------------------------------- whole generator
 @pytest.mark.parametrize("res,batch,seed", [(8, 3, 21), (16, 5, 22), (64, 3, 23)])
 def test_generator_vs_numpy_oracle(pkg, dev, res, batch, seed):
