@@ -35,9 +35,13 @@ import torch
 
 PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 / 16x16x4_f32 peak
-PEAK_BF16_MFMA_TFLOPS = 2500.0 # MI355X_MICROARCH.md: dense bf16 MFMA peak
-# GEMM variant "bf16x3": every fp32 product costs six bf16 MFMA products, so the matrix-core ceiling in
-# ALGORITHMIC flops is 2500 / 6
+PEAK_BF16_MFMA_TFLOPS = 2500.0 # MI355X_MICROARCH.md: dense bf16 / fp16 MFMA peak
+# Split GEMM variants: every fp32 product costs six bf16 MFMA products ("bf16x3") or three fp16 MFMA
+# products ("f16x2"), so the matrix-core ceiling in ALGORITHMIC flops is 2500 / 6 resp. 2500 / 3
+MFMA_PRODUCTS = {"f32": None, "bf16x3": 6.0, "f16x2": 3.0}
+GEMM_TEXT = {"f32": "1x1 convs on exact fp32 MFMA",
+             "bf16x3": "1x1 convs on bf16x3-split MFMA (6 bf16 products per fp32 product, fp32 accumulate)",
+             "f16x2": "1x1 convs on f16x2-split MFMA (3 fp16 products per fp32 product on scaled operands, fp32 accumulate)"}
 
 
 def parse():
@@ -68,7 +72,7 @@ def roofline_from_launches(launches, ms_rounds, batch, gemm="f32"):
         g["bytes"] += L["bytes"] * batch
         g["n"] += 1
         g["layers"].append(L["layer"])
-    peak_mfma = PEAK_BF16_MFMA_TFLOPS / 6.0 if gemm == "bf16x3" else PEAK_F32_MFMA_TFLOPS
+    peak_mfma = PEAK_BF16_MFMA_TFLOPS / MFMA_PRODUCTS[gemm] if MFMA_PRODUCTS.get(gemm) else PEAK_F32_MFMA_TFLOPS
     name, g = max(groups.items(), key=lambda kv: kv[1]["ms"])
     sec = g["ms"] * 1e-3
     t_mfma = g["mfma"] / (peak_mfma * 1e12)
@@ -219,8 +223,7 @@ def main():
             "dtype": "f32", "data": "synthetic (seeded export-like weights, demo.py-style mask+image batches)",
             "config": {"workload": f"migan-{R} generator forward, batch={B} per GPU, {R}x{R}, fp32 (BASELINE configs[2])",
                        "global_batch": world * B, "resolution": R,
-                       "gemm": ("1x1 convs on bf16x3-split MFMA (6 bf16 products per fp32 product, fp32 accumulate)"
-                                if gemm == "bf16x3" else "1x1 convs on exact fp32 MFMA"),
+                       "gemm": GEMM_TEXT.get(gemm, gemm),
                        "parallelism": f"batch-shard x{world}" + (" + RCCL all-gather of outputs" if gather else "")},
             "max_abs_vs_ref": parity,
             "roofline": roof,

@@ -49,7 +49,7 @@ struct Geo {
   int NI = 6, MINW = 2;            // prefetch items per thread, workgroups per CU the kernel is built for
   bool maing = true;               // compile-time tile geometry (8x16 pixels, one image)
   bool persist = false;            // kernel variant whose workgroups walk several tiles
-  int gemmv = 0;                   // 0 exact fp32 MFMA, 1 bf16x3-split MFMA
+  int gemmv = 0;                   // 0 exact fp32 MFMA, 1 bf16x3-split MFMA, 2 f16x2-split MFMA
   bool torgb = false;              // kernel variant with the ToRGB tail in its epilogue
   int a_stride = 0;
   int lgGH = 3, lgGW = 4, lgIMGS = 0;
@@ -70,8 +70,9 @@ inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 // Tuning knobs read once from the environment (experiments only; defaults are the shipped choice).
 struct Tuning {
   int force_single_b = 0;      // MIGAN_SINGLE_B=1: never double-buffer the 1x1 weight tile
-  int gemm_bf16x3 = 1;         // MIGAN_GEMM=f32|bf16x3: exact fp32 MFMA, or (default, 12 % faster end to end, same parity)
-                               // error-compensated bf16 MFMA: 6 products of 3-way bf16 splits, fp32 accumulate
+  int gemm = 2;                // MIGAN_GEMM=f32|bf16x3|f16x2: 0 exact fp32 MFMA; 1 error-compensated bf16 MFMA (6 products of
+                               // 3-way bf16 splits); 2 (default) error-compensated fp16 MFMA (3 products of scaled 2-way
+                               // fp16 splits); all accumulate in fp32 and have the same end-to-end error
   int ablate = 0;              // MIGAN_ABLATE (measurement builds compiled with -DMIGAN_ABLATE only)
   int persist_min = 8192;      // MIGAN_PERSIST_MIN: launches with at least this many tiles run persistent workgroups
   int persist_grid = 512;      // MIGAN_PERSIST_GRID: ... that many (2 per CU on MI355X), each walking its share of tiles
@@ -80,7 +81,7 @@ inline Tuning& tuning() {
   static Tuning t = [] {
     Tuning v;
     if (const char* e = std::getenv("MIGAN_SINGLE_B")) v.force_single_b = std::atoi(e) != 0;
-    if (const char* e = std::getenv("MIGAN_GEMM")) v.gemm_bf16x3 = (std::string(e) != "f32");
+    if (const char* e = std::getenv("MIGAN_GEMM")) v.gemm = std::string(e) == "f32" ? 0 : (std::string(e) == "bf16x3" ? 1 : 2);
     if (const char* e = std::getenv("MIGAN_ABLATE")) v.ablate = std::atoi(e);
     if (const char* e = std::getenv("MIGAN_PERSIST_MIN")) v.persist_min = std::max(1, std::atoi(e));
     if (const char* e = std::getenv("MIGAN_PERSIST_GRID")) v.persist_grid = std::max(8, std::atoi(e) / 8 * 8);   // multiple of 8: one share per XCD
@@ -91,7 +92,7 @@ inline Tuning& tuning() {
 
 inline Geo choose_geo(int mode, int cin, int cout, int res_in, bool fromrgb, bool fused_rgb = true, int gemmv = -1) {
   Geo g;
-  g.gemmv = gemmv < 0 ? tuning().gemm_bf16x3 : gemmv;
+  g.gemmv = gemmv < 0 ? tuning().gemm : gemmv;
   g.mode = mode;
   g.fromrgb = fromrgb;
   MIGAN_CHECK(cin % 32 == 0 && cout % 64 == 0, MIGAN_EINVAL,
@@ -139,8 +140,9 @@ inline Geo choose_geo(int mode, int cin, int cout, int res_in, bool fromrgb, boo
   g.MINW = 2;                                    // 2 workgroups per CU (3 measured slower: profiles/r01 notes)
   const int AS = g.KC + 4, GS = g.NT + 4;
   // operand tiles in floats: fp32 rows of pitch KC+4, or three unpadded (XOR-swizzled) bf16 planes
-  const int asz = g.gemmv ? 3 * g.MT * (g.KC * 2) / 4 : g.MT * AS;
-  const int bsz = g.gemmv ? 3 * g.NT * (g.KC * 2) / 4 : g.NT * AS;
+  const int npl = g.gemmv == 2 ? 2 : 3;
+  const int asz = g.gemmv ? npl * g.MT * (g.KC * 2) / 4 : g.MT * AS;
+  const int bsz = g.gemmv ? npl * g.NT * (g.KC * 2) / 4 : g.NT * AS;
   const int gs = g.MT * GS;   // accumulator tile; the fused ToRGB partial sums reuse its slots
   (void)fused_rgb;
   const size_t limit = (size_t)(160 * 1024 / g.MINW);
@@ -183,10 +185,12 @@ struct KernelEntry {
   {MODE, MT, NT, KC, RGB, NI, MINW, MAING, PERSIST, GEMMV, TORGB,                                                                        \
    sepconv_kernel<MODE, MT, NT, KC, RGB, NI, MINW, MAING, PERSIST, GEMMV, TORGB>,                                                        \
    "migan::sepconv_kernel<" #MODE ", " #MT ", " #NT ", " #KC ", " #RGB ", " #NI ", " #MINW ", " #MAING ", " #PERSIST ", " #GEMMV ", " #TORGB ">"}
-#define MIGAN_KERNEL(MODE, MT, NT, KC, RGB, NI, MINW, MAING, PERSIST) \
-  MIGAN_KERNEL1(MODE, MT, NT, KC, RGB, NI, MINW, MAING, PERSIST, 0, false), MIGAN_KERNEL1(MODE, MT, NT, KC, RGB, NI, MINW, MAING, PERSIST, 1, false)
-#define MIGAN_KERNEL_TORGB(NT, NI, MAING) \
-  MIGAN_KERNEL1(0, 128, NT, 32, false, NI, 2, MAING, false, 0, true), MIGAN_KERNEL1(0, 128, NT, 32, false, NI, 2, MAING, false, 1, true)
+#define MIGAN_KERNEL(MODE, MT, NT, KC, RGB, NI, MINW, MAING, PERSIST)                                                          \
+  MIGAN_KERNEL1(MODE, MT, NT, KC, RGB, NI, MINW, MAING, PERSIST, 0, false), MIGAN_KERNEL1(MODE, MT, NT, KC, RGB, NI, MINW, MAING, PERSIST, 1, false), \
+  MIGAN_KERNEL1(MODE, MT, NT, KC, RGB, NI, MINW, MAING, PERSIST, 2, false)
+#define MIGAN_KERNEL_TORGB(NT, NI, MAING)                                                                                       \
+  MIGAN_KERNEL1(0, 128, NT, 32, false, NI, 2, MAING, false, 0, true), MIGAN_KERNEL1(0, 128, NT, 32, false, NI, 2, MAING, false, 1, true), \
+  MIGAN_KERNEL1(0, 128, NT, 32, false, NI, 2, MAING, false, 2, true)
 
 inline const std::vector<KernelEntry>& kernel_table() {
   static const std::vector<KernelEntry> t = {
@@ -329,7 +333,12 @@ inline void launch_dwfir(const DwGeo& g, DwFirArgs a, rt::stream_t stream) {
   else rt_check(rt::launch(dwfir_kernel<9, false>, a, dwfir_grid(g, a.B), kThreads, g.lds_bytes, stream), dwfir_name(g));
 }
 
+// 16-bit elements one tensor occupies in a weight-split buffer: header + planes, rounded to 16 bytes
+inline size_t wsplit_elems_of(int cin, int cout) {
+  return (size_t)kSplitHeader + (((size_t)3 * cin * cout + 7) & ~(size_t)7);
+}
 inline void launch_split(const SplitArgs& a, rt::stream_t stream) {
+  if (a.f16) rt_check(rt::launch(weight_absmax_kernel, a, (unsigned)a.n, kThreads, 4 * sizeof(float), stream), "migan::weight_absmax_kernel");
   rt_check(rt::launch(split_weights_kernel, a, (unsigned)(a.n * kSplitBlocksPerTensor), kThreads, 0, stream), "migan::split_weights_kernel");
 }
 
@@ -518,8 +527,8 @@ inline void migan_handle::build_plan() {
     L.w_dw = slot_index(layer + ".conv1.weight");
     L.b_dw = slot_index(layer + ".conv1.bias");
     L.w_pw = slot_index(layer + ".conv2.weight");
-    L.wsplit_off = wsplit_elems;
-    wsplit_elems += (size_t)3 * cin * cout;
+    L.wsplit_off = wsplit_elems + kSplitHeader;      // planes start after the 16-byte header
+    wsplit_elems += wsplit_elems_of(cin, cout);
     if (noise) {
       L.w_noise = slot_index(layer + ".noise_const");
       L.w_ns = slot_index(layer + ".noise_strength");
@@ -659,11 +668,12 @@ inline void migan_handle::forward(const float* x, float* y, int batch, void* ws,
   };
   auto wptr = [&](int s) -> const float* { return s < 0 ? nullptr : slots[s].ptr; };
   unsigned short* wsplit = reinterpret_cast<unsigned short*>(static_cast<char*>(ws) + offs[wsplit_buf]);
-  if (tuning().gemm_bf16x3) {
-    // conv2.weight of every layer -> three bf16 planes (one launch; the weights are read in place every forward,
+  if (tuning().gemm) {
+    // conv2.weight of every layer -> 16-bit operand planes (one launch; the weights are read in place every forward,
     // so in-place parameter updates are always picked up)
     SplitArgs sa{};
     sa.dst = wsplit;
+    sa.f16 = tuning().gemm == 2;
     for (const Launch& L : launches) {
       if (L.is_rgb || L.is_dwfir) continue;
       MIGAN_CHECK(sa.n < 40, MIGAN_EINVAL, "internal: too many layers for the weight-split table");
@@ -940,13 +950,14 @@ int migan_sepconv_forward(const migan_sepconv_desc* d, void* stream) {
     gemm_res = res_out;
   }
   // bf16x3-split GEMM needs room for the three bf16 weight planes; without it the exact fp32 MFMA path runs
-  const size_t wsplit_need = (size_t)3 * d->cin * d->cout * sizeof(unsigned short);
-  const int gemmv = (tuning().gemm_bf16x3 && d->wsplit != nullptr && d->wsplit_bytes >= wsplit_need) ? 1 : 0;
+  const size_t wsplit_need = wsplit_elems_of(d->cin, d->cout) * sizeof(unsigned short);
+  const int gemmv = (d->wsplit != nullptr && d->wsplit_bytes >= wsplit_need) ? tuning().gemm : 0;
   const Geo g = choose_geo(mode, d->cin, d->cout, gemm_res, d->fromrgb_weight != nullptr, true, gemmv);
   if (gemmv) {
     SplitArgs sa{};
     sa.dst = (unsigned short*)d->wsplit;
-    sa.src[0] = (const float*)d->conv2_weight; sa.dst_off[0] = 0; sa.count[0] = (unsigned)(d->cin * d->cout); sa.n = 1;
+    sa.f16 = gemmv == 2;
+    sa.src[0] = (const float*)d->conv2_weight; sa.dst_off[0] = kSplitHeader; sa.count[0] = (unsigned)(d->cin * d->cout); sa.n = 1;
     launch_split(sa, (rt::stream_t)stream);
   }
   MIGAN_CHECK(d->torgb_weight == nullptr || (g.nchunks == 1 && mode != MODE_UP && d->img_out), MIGAN_EINVAL,
@@ -954,7 +965,7 @@ int migan_sepconv_forward(const migan_sepconv_desc* d, void* stream) {
   SepArgs a{};
   a.x = gemm_in; a.y = (float*)d->y; a.skip = (const float*)d->skip;
   a.wdw = (const float*)d->conv1_weight; a.bdw = (const float*)d->conv1_bias; a.wpw = (const float*)d->conv2_weight;
-  a.wsplit = gemmv ? (const unsigned short*)d->wsplit : nullptr;
+  a.wsplit = gemmv ? (const unsigned short*)d->wsplit + kSplitHeader : nullptr;
   a.noise = (const float*)d->noise_const; a.noise_strength = (const float*)d->noise_strength;
   a.frgb_w = (const float*)d->fromrgb_weight; a.frgb_b = (const float*)d->fromrgb_bias;
   a.trgb_w = (const float*)d->torgb_weight; a.trgb_b = (const float*)d->torgb_bias;
@@ -983,7 +994,10 @@ int migan_prof_layer(int index, unsigned long long out[16]) {
 
 const char* migan_last_error(void) { return migan::last_error_ref().c_str(); }
 const char* migan_backend(void) { return rt::backend_name(); }
-const char* migan_gemm_variant(void) { return migan::tuning().gemm_bf16x3 ? "bf16x3" : "f32"; }
+const char* migan_gemm_variant(void) {
+  const int g = migan::tuning().gemm;
+  return g == 2 ? "f16x2" : (g == 1 ? "bf16x3" : "f32");
+}
 int migan_version(void) { return 1; }
 
 }  // extern "C"

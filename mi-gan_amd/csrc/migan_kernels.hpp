@@ -122,6 +122,32 @@ MIGAN_DEVICE MIGAN_INLINE void split3_bf16(f4 v, u2v& h1, u2v& h2, u2v& h3) {
   h3 = u2v{MIGAN_PACK_BF16(r2.x, r2.y), MIGAN_PACK_BF16(r2.z, r2.w)};
 }
 
+// ---- error-compensated fp16 GEMM operands (GEMMV 2) ----------------------------------------------
+// x*s = h1 + h2 (+ <= 2^-22 |x*s|) with h_i fp16 (round to nearest even, 11-bit significands; the
+// subtraction is exact in fp32); a*b is summed from a2b1 + a1b2 + a1b1 (a2b2 <= 2^-22 |ab| is dropped),
+// each product exact in the MFMA's fp32 accumulator.  Power-of-two scales keep both operands inside
+// fp16's normal range: activations are bounded by the +-256 clamp of lrelu_agc (reference :21-23), so
+// kF16AScale = 2^7 maps them into +-2^15; every weight tensor is scaled so that its largest magnitude
+// lands in [2^13, 2^14) (weight_absmax_kernel).  The accumulators are multiplied by the exact inverse.
+// Whole-generator error vs float64: same as the fp32 path (scripts/split_accuracy.py), at 3/16 of
+// the fp32-MFMA cost.
+constexpr float kF16AScale = 128.0f;
+MIGAN_DEVICE MIGAN_INLINE void split2_f16(f4 v, u2v& h1, u2v& h2) {
+  const unsigned a01 = MIGAN_PACK_F16(v.x, v.y), a23 = MIGAN_PACK_F16(v.z, v.w);
+  const f4 r = f4{v.x - MIGAN_F16LO_F32(a01), v.y - MIGAN_F16HI_F32(a01), v.z - MIGAN_F16LO_F32(a23), v.w - MIGAN_F16HI_F32(a23)};
+  h1 = u2v{a01, a23};
+  h2 = u2v{MIGAN_PACK_F16(r.x, r.y), MIGAN_PACK_F16(r.z, r.w)};
+}
+// act4(v) * 2^S, exactly (a power-of-two scale commutes with every rounding of act4)
+template <int S>
+MIGAN_DEVICE MIGAN_INLINE f4 act4_scaled(f4 v) {
+  constexpr float sc = (float)(1 << S);
+  f4 t = __builtin_elementwise_max(v, v * 0.2f);
+  t = t * (1.41421356237309515f * sc);
+  return f4{MIGAN_CLAMP(t.x, -256.0f * sc, 256.0f * sc), MIGAN_CLAMP(t.y, -256.0f * sc, 256.0f * sc),
+            MIGAN_CLAMP(t.z, -256.0f * sc, 256.0f * sc), MIGAN_CLAMP(t.w, -256.0f * sc, 256.0f * sc)};
+}
+
 MIGAN_DEVICE MIGAN_INLINE f4 ld4(const float* p) { return *reinterpret_cast<const f4*>(p); }
 MIGAN_DEVICE MIGAN_INLINE void st4(float* p, f4 v) { *reinterpret_cast<f4*>(p) = v; }
 
@@ -198,7 +224,8 @@ MIGAN_DEVICE MIGAN_INLINE float up_combine(const float (&t)[4], int oy, int ox, 
 //   MAING  : compile-time tile geometry (8x16 pixels, one image per tile)
 //   PERSIST: workgroups walk several tiles and prefetch the next tile during the epilogue
 //   GEMMV  : 0 = exact fp32 MFMA (v_mfma_f32_32x32x2_f32); 1 = error-compensated bf16 MFMA
-//            (v_mfma_f32_32x32x16_bf16 x 6 on 3-way split operands, fp32 accumulate)
+//            (v_mfma_f32_32x32x16_bf16 x 6 on 3-way split operands, fp32 accumulate); 2 = error-
+//            compensated fp16 MFMA (v_mfma_f32_32x32x16_f16 x 3 on scaled 2-way split operands)
 //
 // Waves are laid out 2x2 over the MT x NT tile; each wave owns (MT/2)x(NT/2) as 32x32 MFMA tiles.
 template <int MODE, int MT, int NT, int KC, bool FROMRGB, int NI, int MINW, bool MAING, bool PERSIST, int GEMMV, bool TORGB>
@@ -217,12 +244,14 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, MINW) sepconv_kernel(const SepArgs p)
   constexpr int WROWS = MT / 2, WCOLS = NT / 2;    // per-wave tile
   constexpr int MTI = WROWS / 32, NTI = WCOLS / 32;
   static_assert(MTI >= 1 && NTI >= 1, "wave tile must be at least 32x32");
-  constexpr bool BF = (GEMMV == 1);
-  constexpr int PB = KC * 2;                       // BF: bytes per row of one bf16 operand plane (XOR-swizzled 16-B slots, no padding)
+  constexpr bool BF = (GEMMV >= 1);                // operands are planes of 16-bit pieces
+  constexpr bool F16 = (GEMMV == 2);
+  constexpr int NPL = F16 ? 2 : 3;                 // planes per operand
+  constexpr int PB = KC * 2;                       // BF: bytes per row of one 16-bit operand plane (XOR-swizzled 16-B slots, no padding)
   constexpr int NSLOT = PB / 16;
-  constexpr int NB = BF ? 3 * NT * NSLOT / kThreads : NT * QC / kThreads;   // float4 items of the 1x1 weight tile per thread
-  static_assert(NB >= 1 && NB * kThreads == (BF ? 3 * NT * NSLOT : NT * QC), "weight tile must split evenly over the threads");
-  static_assert(!BF || KC == 32, "the bf16 GEMM variant is built for 32-channel chunks");
+  constexpr int NB = BF ? NPL * NT * NSLOT / kThreads : NT * QC / kThreads;   // float4 items of the 1x1 weight tile per thread
+  static_assert(NB >= 1 && NB * kThreads == (BF ? NPL * NT * NSLOT : NT * QC), "weight tile must split evenly over the threads");
+  static_assert(!BF || KC == 32, "the split GEMM variants are built for 32-channel chunks");
   constexpr int NW4 = KC * 10 / 4;                 // float4s of depthwise weights (9 taps) + bias per chunk
   constexpr int NF4 = FROMRGB ? KC * 5 / 4 : 0;    // float4s of fromrgb weights (4 per channel) + bias
   constexpr int SEGH = 4;                          // output rows per depthwise strip (NORMAL / UP)
@@ -287,7 +316,14 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, MINW) sepconv_kernel(const SepArgs p)
   float* g_s = smem;                        // after the K loop: [MT][GS], aliases the buffers above
   // A-operand row m, channels 4*c4..4*c4+3 of the current chunk
   auto emit_a = [&](float* abase, int m, int c4, f4 v) {
-    if constexpr (BF) {
+    if constexpr (F16) {
+      // v already carries the 2^7 activation scale
+      u2v h1, h2;
+      split2_f16(v, h1, h2);
+      char* d = reinterpret_cast<char*>(abase) + m * PB + (((c4 >> 1) ^ ((m >> 2) & (NSLOT - 1))) << 4) + ((c4 & 1) << 3);
+      *reinterpret_cast<u2v*>(d) = h1;
+      *reinterpret_cast<u2v*>(d + MT * PB) = h2;
+    } else if constexpr (BF) {
       u2v h1, h2, h3;
       split3_bf16(v, h1, h2, h3);
       char* d = reinterpret_cast<char*>(abase) + m * PB + (((c4 >> 1) ^ ((m >> 2) & (NSLOT - 1))) << 4) + ((c4 & 1) << 3);
@@ -341,7 +377,7 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, MINW) sepconv_kernel(const SepArgs p)
     for (int j = 0; j < NB; ++j) {
       const int i = tid + j * kThreads;
       if constexpr (BF) {
-        // item = (plane, row n, 16-byte slot of 8 bf16); offset in bf16 elements inside [3][CO][CI]
+        // item = (plane, row n, 16-byte slot of 8 pieces); offset in 16-bit elements inside [NPL][CO][CI]
         const int plane = i / (NT * NSLOT), rem = i % (NT * NSLOT);
         boff_[j] = (unsigned)(((plane * p.CO + n0_ + rem / NSLOT) * p.CI) + (rem % NSLOT) * 8);
       } else {
@@ -490,6 +526,7 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, MINW) sepconv_kernel(const SepArgs p)
           const int i = tid + j * kThreads;
           f4 v = rin[j];
           if (!(vmask & (1u << j))) v = f4{0.f, 0.f, 0.f, 0.f};
+          if constexpr (F16) v = v * kF16AScale;
           emit_a(acur, i >> LG_QC, i & (QC - 1), v);
         }
       } else if (wave_all_valid) {
@@ -558,7 +595,8 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, MINW) sepconv_kernel(const SepArgs p)
           for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
             for (int kx = 0; kx < 3; ++kx) sacc += w[ky * 3 + kx] * win[(o + ky) % 3][kx];
-          emit_a(a_s, mbase + (o << lgGW), c4, act4(sacc));
+          if constexpr (F16) emit_a(a_s, mbase + (o << lgGW), c4, act4_scaled<7>(sacc));
+          else emit_a(a_s, mbase + (o << lgGW), c4, act4(sacc));
         }
       }
       }
@@ -572,38 +610,44 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, MINW) sepconv_kernel(const SepArgs p)
     // same for A and B, so any assignment of k to (half,t) sums the full K.
     if (MIGAN_ABL(8)) {
     } else if constexpr (BF) {
-      // v_mfma_f32_32x32x16_bf16: lane l supplies A[i=l&31][k=8*(l>>5)..+7] and B[k=8*(l>>5)..+7][j=l&31]
-      // as one 16-byte LDS read each; three planes per operand, six MFMAs per 32x32 tile and k-step,
-      // smallest products first.
+      // v_mfma_f32_32x32x16_{bf16,f16}: lane l supplies A[i=l&31][k=8*(l>>5)..+7] and B[k=8*(l>>5)..+7][j=l&31]
+      // as one 16-byte LDS read each; NPL planes per operand; six (bf16x3) or three (f16x2) MFMAs per
+      // 32x32 tile and k-step, smallest products first.
       const char* ab = reinterpret_cast<const char*>(a_s + (MODE == MODE_PW ? (c & 1) * p.a_stride : 0));
       const char* bb = reinterpret_cast<const char*>(bcur);
 #pragma unroll
       for (int ks = 0; ks < KC / 16; ++ks) {
-        f4 av[MTI][3], bv[NTI][3];
+        f4 av[MTI][NPL], bv[NTI][NPL];
 #pragma unroll
         for (int i = 0; i < MTI; ++i) {
           const int row = wm * WROWS + i * 32 + l31;
           const char* q = ab + row * PB + (((2 * ks + half) ^ ((row >> 2) & (NSLOT - 1))) << 4);
 #pragma unroll
-          for (int pl = 0; pl < 3; ++pl) av[i][pl] = ld4(reinterpret_cast<const float*>(q + pl * MT * PB));
+          for (int pl = 0; pl < NPL; ++pl) av[i][pl] = ld4(reinterpret_cast<const float*>(q + pl * MT * PB));
         }
 #pragma unroll
         for (int j = 0; j < NTI; ++j) {
           const int row = wn * WCOLS + j * 32 + l31;
           const char* q = bb + row * PB + (((2 * ks + half) ^ ((row >> 2) & (NSLOT - 1))) << 4);
 #pragma unroll
-          for (int pl = 0; pl < 3; ++pl) bv[j][pl] = ld4(reinterpret_cast<const float*>(q + pl * NT * PB));
+          for (int pl = 0; pl < NPL; ++pl) bv[j][pl] = ld4(reinterpret_cast<const float*>(q + pl * NT * PB));
         }
 #pragma unroll
         for (int i = 0; i < MTI; ++i)
 #pragma unroll
           for (int j = 0; j < NTI; ++j) {
-            acc[i][j] = MIGAN_MFMA_BF16_32X32X16(av[i][2], bv[j][0], acc[i][j]);
-            acc[i][j] = MIGAN_MFMA_BF16_32X32X16(av[i][1], bv[j][1], acc[i][j]);
-            acc[i][j] = MIGAN_MFMA_BF16_32X32X16(av[i][0], bv[j][2], acc[i][j]);
-            acc[i][j] = MIGAN_MFMA_BF16_32X32X16(av[i][1], bv[j][0], acc[i][j]);
-            acc[i][j] = MIGAN_MFMA_BF16_32X32X16(av[i][0], bv[j][1], acc[i][j]);
-            acc[i][j] = MIGAN_MFMA_BF16_32X32X16(av[i][0], bv[j][0], acc[i][j]);
+            if constexpr (F16) {
+              acc[i][j] = MIGAN_MFMA_F16_32X32X16(av[i][1], bv[j][0], acc[i][j]);
+              acc[i][j] = MIGAN_MFMA_F16_32X32X16(av[i][0], bv[j][1], acc[i][j]);
+              acc[i][j] = MIGAN_MFMA_F16_32X32X16(av[i][0], bv[j][0], acc[i][j]);
+            } else {
+              acc[i][j] = MIGAN_MFMA_BF16_32X32X16(av[i][NPL - 1], bv[j][0], acc[i][j]);
+              acc[i][j] = MIGAN_MFMA_BF16_32X32X16(av[i][1], bv[j][1], acc[i][j]);
+              acc[i][j] = MIGAN_MFMA_BF16_32X32X16(av[i][0], bv[j][NPL - 1], acc[i][j]);
+              acc[i][j] = MIGAN_MFMA_BF16_32X32X16(av[i][1], bv[j][0], acc[i][j]);
+              acc[i][j] = MIGAN_MFMA_BF16_32X32X16(av[i][0], bv[j][1], acc[i][j]);
+              acc[i][j] = MIGAN_MFMA_BF16_32X32X16(av[i][0], bv[j][0], acc[i][j]);
+            }
           }
       }
     } else
@@ -639,6 +683,9 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, MINW) sepconv_kernel(const SepArgs p)
   const int lanee = tide & 63, wavee = tide >> 6;
   const int wme = wavee >> 1, wne = wavee & 1, l31e = lanee & 31, halfe = lanee >> 5;
   __syncthreads();                       // all waves done with a_s/b_s before g_s overwrites them
+  // F16: 1 / (activation scale * weight scale), a power of two written next to the weight planes by weight_absmax_kernel
+  float acc_scale = 1.0f;
+  if constexpr (F16) acc_scale = reinterpret_cast<const float*>(p.wsplit)[-4];
   // accumulator fragment -> LDS result tile.  C/D layout of the 32x32 MFMA: lane holds column
   // l&31, rows (r&3) + 8*(r>>2) + 4*(l>>5), r = 0..15.
 #pragma unroll
@@ -650,6 +697,7 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, MINW) sepconv_kernel(const SepArgs p)
         const int row = wme * WROWS + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * halfe;
         const int col = wne * WCOLS + j * 32 + l31e;
         float v = acc[i][j][r];
+        if constexpr (F16) v *= acc_scale;
         if constexpr (MODE == MODE_UP) {
           // halo pixels outside the low-resolution image contribute zeros to the upsampling FIR
           // (reference pads with zeros :101), not the conv of a zero-padded input
@@ -1030,24 +1078,59 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, 3) dwfir_kernel(const DwFirArgs p) {
 // One launch per forward covers every layer (table of up to 40 tensors passed by value).
 struct SplitArgs {
   const float* src[40];
-  unsigned long long dst_off[40];   // element offset of plane 0 inside `dst`
+  unsigned long long dst_off[40];   // element (16-bit) offset of plane 0 inside `dst`; a 16-byte header precedes it
   unsigned count[40];               // CO*CI
   unsigned short* dst;
   int n;
+  int f16;                          // 0: three bf16 planes; 1: two fp16 planes of the scaled weights
 };
+constexpr int kSplitHeader = 8;     // 16-bit elements of header in front of the planes: float[0] = accumulator scale, float[2] = weight scale
 constexpr int kSplitBlocksPerTensor = 32;
+// f16x2 only: one workgroup per tensor finds max|w| and derives the power-of-two scales.
+MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, 2) weight_absmax_kernel(const SplitArgs p) {
+  MIGAN_DYN_SMEM(red);
+  const int t = (int)blockIdx.x;
+  const unsigned cnt = p.count[t];
+  const float* __restrict__ src = p.src[t];
+  float m = 0.0f;
+  for (unsigned i = threadIdx.x * 4; i < cnt; i += kThreads * 4) {
+    const f4 v = ld4(src + i);
+    m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+  }
+#pragma unroll
+  for (int sft = 32; sft >= 1; sft >>= 1) m = fmaxf(m, __shfl_xor(m, sft));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    int e = (int)((__builtin_bit_cast(unsigned, m) >> 23) & 0xffu) - 127;       // floor(log2(max|w|))
+    e = e < -100 ? -100 : (e > 100 ? 100 : e);
+    float* hdr = reinterpret_cast<float*>(p.dst + p.dst_off[t] - kSplitHeader);
+    hdr[2] = __builtin_bit_cast(float, (unsigned)(127 + 13 - e) << 23);           // weight scale: max|w| -> [2^13, 2^14)
+    hdr[0] = __builtin_bit_cast(float, (unsigned)(127 + e - 13 - 7) << 23);       // 1 / (weight scale * kF16AScale)
+    hdr[1] = m;
+  }
+}
 MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, 2) split_weights_kernel(const SplitArgs p) {
   const int t = (int)blockIdx.x / kSplitBlocksPerTensor, blk = (int)blockIdx.x % kSplitBlocksPerTensor;
   if (t >= p.n) return;
   const unsigned cnt = p.count[t];
   const float* __restrict__ src = p.src[t];
   unsigned short* __restrict__ dst = p.dst + p.dst_off[t];
+  const float sw = p.f16 ? reinterpret_cast<const float*>(dst - kSplitHeader)[2] : 1.0f;
   for (unsigned i = (blk * kThreads + threadIdx.x) * 4; i < cnt; i += kSplitBlocksPerTensor * kThreads * 4) {
-    u2v h1, h2, h3;
-    split3_bf16(ld4(src + i), h1, h2, h3);
-    *reinterpret_cast<u2v*>(dst + i) = h1;
-    *reinterpret_cast<u2v*>(dst + cnt + i) = h2;
-    *reinterpret_cast<u2v*>(dst + 2 * (size_t)cnt + i) = h3;
+    if (p.f16) {
+      u2v h1, h2;
+      split2_f16(ld4(src + i) * sw, h1, h2);
+      *reinterpret_cast<u2v*>(dst + i) = h1;
+      *reinterpret_cast<u2v*>(dst + cnt + i) = h2;
+    } else {
+      u2v h1, h2, h3;
+      split3_bf16(ld4(src + i), h1, h2, h3);
+      *reinterpret_cast<u2v*>(dst + i) = h1;
+      *reinterpret_cast<u2v*>(dst + cnt + i) = h2;
+      *reinterpret_cast<u2v*>(dst + 2 * (size_t)cnt + i) = h3;
+    }
   }
 }
 

@@ -20,6 +20,20 @@ typedef __bf16 migan_bf16x2 __attribute__((ext_vector_type(2)));
   __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(migan_bf16x8, (a)), __builtin_bit_cast(migan_bf16x8, (b)), (c), 0, 0, 0)
 // two fp32 -> packed bf16 pair, round to nearest even (v_cvt_pk_bf16_f32); low half = first argument
 #define MIGAN_PACK_BF16(lo, hi) __builtin_bit_cast(unsigned, migan_bf16x2{(__bf16)(lo), (__bf16)(hi)})
+// fp16 pieces (GEMMV 2): v_cvt_pk_f16_f32 (round to nearest even), v_cvt_f32_f16, v_mfma_f32_32x32x16_f16
+typedef _Float16 migan_f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 migan_f16x2 __attribute__((ext_vector_type(2)));
+typedef float migan_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned migan_pack_f16(float lo, float hi) {
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(migan_f32x2{lo, hi}, migan_f16x2));
+}
+__device__ __forceinline__ float migan_f16lo_f32(unsigned pk) { return (float)__builtin_bit_cast(migan_f16x2, pk).x; }
+__device__ __forceinline__ float migan_f16hi_f32(unsigned pk) { return (float)__builtin_bit_cast(migan_f16x2, pk).y; }
+#define MIGAN_PACK_F16(lo, hi) migan_pack_f16((lo), (hi))
+#define MIGAN_F16LO_F32(pk) migan_f16lo_f32(pk)
+#define MIGAN_F16HI_F32(pk) migan_f16hi_f32(pk)
+#define MIGAN_MFMA_F16_32X32X16(a, b, c) \
+  __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(migan_f16x8, (a)), __builtin_bit_cast(migan_f16x8, (b)), (c), 0, 0, 0)
 #define MIGAN_CLAMP(v, lo, hi) __builtin_amdgcn_fmed3f((v), (lo), (hi))     // v_med3_f32
 // ds_swizzle bit mode: lane' = ((lane & and_mask) | or_mask) ^ xor_mask inside groups of 32 lanes
 // (a function, not a macro body: __builtin_bit_cast applied directly to a vector element lvalue such as `v.y`

@@ -179,15 +179,58 @@ inline unsigned hipemu_bf16_rne(float f) {
 }
 #define MIGAN_PACK_BF16(lo, hi) (hipemu_bf16_rne(lo) | (hipemu_bf16_rne(hi) << 16))
 typedef float emu_f4 __attribute__((ext_vector_type(4)));
-inline emu_f16v hipemu_mfma_bf16_32x32x16(emu_f4 a, emu_f4 bv, emu_f16v c) {
+// IEEE binary16 <-> binary32 in software (round to nearest even, subnormals, overflow to infinity): what
+// v_cvt_pk_f16_f32 / v_cvt_f32_f16 do in the default rounding mode
+inline unsigned hipemu_f16_rne(float f) {
+  unsigned u;
+  std::memcpy(&u, &f, 4);
+  const unsigned sign = (u >> 16) & 0x8000u;
+  const unsigned ex = (u >> 23) & 0xffu;
+  unsigned man = u & 0x7fffffu;
+  if (ex == 0xff) return sign | 0x7c00u | (man ? 0x200u : 0u);
+  const int e = (int)ex - 127 + 15;
+  if (e >= 31) return sign | 0x7c00u;
+  if (e <= 0) {
+    if (e < -10) return sign;                                  // below half the smallest subnormal
+    man |= 0x800000u;
+    const int sh = 14 - e;                                     // 14..24
+    unsigned h = man >> sh;
+    const unsigned rem = man & ((1u << sh) - 1), halfway = 1u << (sh - 1);
+    if (rem > halfway || (rem == halfway && (h & 1))) ++h;
+    return sign | h;
+  }
+  unsigned h = ((unsigned)e << 10) | (man >> 13);
+  const unsigned rem = man & 0x1fffu;
+  if (rem > 0x1000u || (rem == 0x1000u && (h & 1))) ++h;      // carry into the exponent is the right answer
+  return sign | h;
+}
+inline float hipemu_f16_to_f32(unsigned h) {
+  const unsigned sign = (h & 0x8000u) << 16, ex = (h >> 10) & 0x1fu, man = h & 0x3ffu;
+  float f;
+  if (ex == 0) {
+    f = std::ldexp((float)man, -24);
+  } else if (ex == 31) {
+    const unsigned bits = 0x7f800000u | (man << 13);
+    std::memcpy(&f, &bits, 4);
+  } else {
+    const unsigned bits = ((ex - 15 + 127) << 23) | (man << 13);
+    std::memcpy(&f, &bits, 4);
+  }
+  return sign ? -f : f;
+}
+#define MIGAN_PACK_F16(lo, hi) (hipemu_f16_rne(lo) | (hipemu_f16_rne(hi) << 16))
+#define MIGAN_F16LO_F32(pk) hipemu_f16_to_f32((pk) & 0xffffu)
+#define MIGAN_F16HI_F32(pk) hipemu_f16_to_f32((pk) >> 16)
+inline emu_f16v hipemu_mfma_16b_32x32x16(emu_f4 a, emu_f4 bv, emu_f16v c, bool f16) {
   hipemu::Block* b = hipemu::tl_blk;
   const int w = b->cur >> 6, l = b->cur & 63;
   std::memcpy(b->xq[w][l], &a, 16);
   std::memcpy(b->yq[w][l], &bv, 16);
   hipemu::wave_barrier();
   const int j = l & 31, hh = l >> 5;
-  auto elem = [](const unsigned* q, int e) {
+  auto elem = [f16](const unsigned* q, int e) {
     const unsigned pk = q[e >> 1];
+    if (f16) return hipemu_f16_to_f32((e & 1) ? (pk >> 16) : (pk & 0xffffu));
     const unsigned bits = (e & 1) ? (pk & 0xffff0000u) : (pk << 16);
     float f;
     std::memcpy(&f, &bits, 4);
@@ -203,7 +246,8 @@ inline emu_f16v hipemu_mfma_bf16_32x32x16(emu_f4 a, emu_f4 bv, emu_f16v c) {
   hipemu::wave_barrier();
   return c;
 }
-#define MIGAN_MFMA_BF16_32X32X16(a, b, c) hipemu_mfma_bf16_32x32x16((a), (b), (c))
+#define MIGAN_MFMA_BF16_32X32X16(a, b, c) hipemu_mfma_16b_32x32x16((a), (b), (c), false)
+#define MIGAN_MFMA_F16_32X32X16(a, b, c) hipemu_mfma_16b_32x32x16((a), (b), (c), true)
 
 // ---- the runtime surface the host code uses ----------------------------------------------------------
 namespace rt {

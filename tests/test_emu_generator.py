@@ -140,13 +140,13 @@ def test_state_errors(pkg, lib):
 
 def test_persistent_workgroups_and_both_gemm_variants():
     """Large launches run persistent workgroups that walk several tiles and prefetch the next tile's
-    first K chunk during the epilogue; the 1x1 convs run either on exact fp32 MFMA or (default) on the
-    bf16x3-split MFMA.  Force the persistent path on the small emulator cases (the tuning knobs
+    first K chunk during the epilogue; the 1x1 convs run on exact fp32 MFMA, on the bf16x3-split MFMA or
+    (default) on the f16x2-split MFMA.  Force the persistent path on the small emulator cases (the tuning knobs
     are read once per process, hence the subprocess) and re-run the operator + generator suites."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    for grid, gemm in (("8", "bf16x3"), ("16", "f32")):
+    for grid, gemm in (("8", "f16x2"), ("16", "bf16x3"), ("8", "f32")):
         env = dict(os.environ, MIGAN_PERSIST_MIN="2", MIGAN_PERSIST_GRID=grid, MIGAN_GEMM=gemm)
         r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "tests/test_emu_sepconv.py",
                             "tests/test_emu_generator.py", "-k", "not persistent_workgroups"],

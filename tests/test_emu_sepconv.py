@@ -27,9 +27,10 @@ def _weights(pkg, cin, cout, seed, res_out, noise):
     return sd
 
 
-def _run(lib, pkg, *, cin, cout, res_in, batch, down=1, up=1, noise=False, skip=False, seed=1):
+def _run(lib, pkg, *, cin, cout, res_in, batch, down=1, up=1, noise=False, skip=False, seed=1, wscale=1.0):
     res_out = res_in // 2 if down == 2 else (res_in * 2 if up == 2 else res_in)
     sd = _weights(pkg, cin, cout, seed, res_out, noise)
+    sd["m.conv2.weight"] = (sd["m.conv2.weight"] * np.float32(wscale)).astype(np.float32)
     osd = dict(sd)
     if down == 2:
         osd["m.downsample.filter.weight"] = np.broadcast_to(orc.fir_taps(1.0), (cin, 1, 4, 4)).astype(np.float32)
@@ -133,6 +134,15 @@ def test_torgb_fused(lib, pkg, with_prev, cout):
                         img_prev=ptr(pv), img_out=ptr(img_out), batch=batch, cin=cin, cout=cout, res_in=res)
     np.testing.assert_allclose(nchw(y), feat, rtol=0, atol=2e-5 * max(1.0, float(np.abs(feat).max())))
     np.testing.assert_allclose(img_out, want_img, rtol=0, atol=2e-5 * max(1.0, float(np.abs(want_img).max())))
+
+
+@pytest.mark.parametrize("wscale", [3.0e3, 1.7e-5, 0.0])
+@pytest.mark.parametrize("kw", [dict(cin=64, cout=64, res_in=16, batch=1), dict(cin=32, cout=128, res_in=8, batch=2, down=2)])
+def test_weight_magnitude_does_not_matter(lib, pkg, kw, wscale):
+    """The split GEMM variants rescale every 1x1 weight tensor by a power of two derived from its largest
+    magnitude (f16x2) so fp16's narrow exponent range never shows: huge, tiny and all-zero weights keep the
+    same relative accuracy (large products hit the +-256 clamp of lrelu_agc, small ones stay far from it)."""
+    _run(lib, pkg, wscale=wscale, **kw)
 
 
 def test_bad_arguments_are_rejected(lib):

@@ -38,13 +38,13 @@ def test_library_is_the_hip_build(pkg, dev):
 
 
 # ----------------------------------------------------------------------------- operator level
-def _sep(pkg, dev, *, cin, cout, res_in, batch, down=1, up=1, noise=False, skip=False, seed=1):
+def _sep(pkg, dev, *, cin, cout, res_in, batch, down=1, up=1, noise=False, skip=False, seed=1, wscale=1.0):
     lib = pkg.load_library()
     res_out = res_in // 2 if down == 2 else (res_in * 2 if up == 2 else res_in)
     s = pkg.synth
     sd = {"m.conv1.weight": (s.normal((cin, 1, 3, 3), seed, "w1") * 0.4).astype(np.float32),
           "m.conv1.bias": (s.normal((cin,), seed, "b1") * 0.5).astype(np.float32),
-          "m.conv2.weight": (s.normal((cout, cin, 1, 1), seed, "w2") / np.sqrt(cin)).astype(np.float32)}
+          "m.conv2.weight": (s.normal((cout, cin, 1, 1), seed, "w2") / np.sqrt(cin) * np.float32(wscale)).astype(np.float32)}
     if noise:
         sd["m.noise_const"] = s.normal((res_out, res_out), seed, "nc").astype(np.float32)
         sd["m.noise_strength"] = np.asarray(0.37, dtype=np.float32)
@@ -95,6 +95,15 @@ def _sep(pkg, dev, *, cin, cout, res_in, batch, down=1, up=1, noise=False, skip=
 ])
 def test_sepconv_operator(pkg, dev, kw):
     _sep(pkg, dev, **kw)
+
+
+@pytest.mark.parametrize("wscale", [3.0e3, 1.7e-5, 0.0])
+@pytest.mark.parametrize("kw", [dict(cin=64, cout=64, res_in=16, batch=1), dict(cin=32, cout=128, res_in=8, batch=2, down=2),
+                                dict(cin=64, cout=128, res_in=16, batch=1, up=2, noise=True)])
+def test_sepconv_weight_magnitude_does_not_matter(pkg, dev, kw, wscale):
+    """f16x2 rescales each 1x1 weight tensor by a power of two taken from its largest magnitude, so fp16's
+    exponent range never shows: huge (outputs hit the +-256 clamp), tiny and all-zero weights keep the accuracy."""
+    _sep(pkg, dev, wscale=wscale, **kw)
 
 
 @pytest.mark.parametrize("with_prev,cout,res,batch", [(False, 64, 16, 2), (True, 64, 32, 1), (True, 128, 16, 2), (True, 128, 8, 3),
@@ -322,15 +331,16 @@ def test_cpu_tensor_is_refused(pkg, dev):
         m(torch.zeros(1, 4, 16, 16))
 
 
-def test_exact_fp32_mfma_variant_also_passes(pkg, dev):
-    """The default GEMM variant is the bf16x3-split MFMA; the exact fp32-MFMA kernels (MIGAN_GEMM=f32, read once
-    per process) must hold the same parity."""
+@pytest.mark.parametrize("gemm", ["f32", "bf16x3"])
+def test_other_gemm_variants_also_pass(pkg, dev, gemm):
+    """The default GEMM variant is the f16x2-split MFMA; the exact fp32-MFMA kernels and the bf16x3-split
+    kernels (MIGAN_GEMM=f32|bf16x3, read once per process) must hold the same parity."""
     import subprocess
     import sys
-    assert pkg.load_library().gemm_variant() in ("bf16x3", "f32")
+    assert pkg.load_library().gemm_variant() in ("f16x2", "bf16x3", "f32")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, MIGAN_GEMM="f32")
+    env = dict(os.environ, MIGAN_GEMM=gemm)
     r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", "tests/test_gpu_parity.py", "-k",
-                        "sepconv_operator or vs_numpy_oracle or full_size or every_layer"],
+                        "sepconv_operator or vs_numpy_oracle or full_size or every_layer or fused"],
                        cwd=root, env=env, capture_output=True, text=True, timeout=1200)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
