@@ -188,9 +188,9 @@ struct KernelEntry {
 #define MIGAN_KERNEL(MODE, MT, NT, KC, RGB, NI, MINW, MAING, PERSIST)                                                          \
   MIGAN_KERNEL1(MODE, MT, NT, KC, RGB, NI, MINW, MAING, PERSIST, 0, false), MIGAN_KERNEL1(MODE, MT, NT, KC, RGB, NI, MINW, MAING, PERSIST, 1, false), \
   MIGAN_KERNEL1(MODE, MT, NT, KC, RGB, NI, MINW, MAING, PERSIST, 2, false)
-#define MIGAN_KERNEL_TORGB(NT, NI, MAING)                                                                                       \
-  MIGAN_KERNEL1(0, 128, NT, 32, false, NI, 2, MAING, false, 0, true), MIGAN_KERNEL1(0, 128, NT, 32, false, NI, 2, MAING, false, 1, true), \
-  MIGAN_KERNEL1(0, 128, NT, 32, false, NI, 2, MAING, false, 2, true)
+#define MIGAN_KERNEL_TORGB(NT, NI, MAING, PERSIST)                                                                                \
+  MIGAN_KERNEL1(0, 128, NT, 32, false, NI, 2, MAING, PERSIST, 0, true), MIGAN_KERNEL1(0, 128, NT, 32, false, NI, 2, MAING, PERSIST, 1, true), \
+  MIGAN_KERNEL1(0, 128, NT, 32, false, NI, 2, MAING, PERSIST, 2, true)
 
 inline const std::vector<KernelEntry>& kernel_table() {
   static const std::vector<KernelEntry> t = {
@@ -202,7 +202,8 @@ inline const std::vector<KernelEntry>& kernel_table() {
       MIGAN_KERNEL(0, 128, 64, 32, true, 6, 2, true, false),   MIGAN_KERNEL(0, 128, 64, 32, true, 9, 2, false, false),
       MIGAN_KERNEL(0, 128, 64, 32, true, 6, 2, true, true),
       // plain layers whose epilogue also produces the running RGB image (CO == NT)
-      MIGAN_KERNEL_TORGB(128, 6, true), MIGAN_KERNEL_TORGB(128, 9, false), MIGAN_KERNEL_TORGB(64, 6, true), MIGAN_KERNEL_TORGB(64, 9, false),
+      MIGAN_KERNEL_TORGB(128, 6, true, false), MIGAN_KERNEL_TORGB(128, 9, false, false), MIGAN_KERNEL_TORGB(64, 6, true, false),
+      MIGAN_KERNEL_TORGB(64, 9, false, false),
       // FIR-up layers (MODE 2)
       MIGAN_KERNEL(2, 128, 128, 32, false, 6, 2, true, false), MIGAN_KERNEL(2, 128, 128, 32, false, 9, 2, false, false),
       MIGAN_KERNEL(2, 128, 64, 32, false, 6, 2, true, false),  MIGAN_KERNEL(2, 128, 64, 32, false, 9, 2, false, false),
@@ -306,7 +307,7 @@ inline unsigned tiles_of(const Geo& g, int batch) {
 // their next tile during the current epilogue; small ones keep one tile per workgroup.
 inline bool use_persistent(const Geo& g, int batch, bool fused_rgb) {
   const int total = (int)tiles_of(g, batch);
-  // measured on MI355X (profiles/): +2..7 % on the 512x512 layers, -7 % when the ToRGB tail is fused
+  // measured on MI355X (profiles/): +2..7 % on the 512x512 layers; with the ToRGB tail fused -7 % (first tail) / -3 % (LDS-reduction tail)
   return has_persistent_variant(g) && !fused_rgb && total >= tuning().persist_min && total > tuning().persist_grid;
 }
 inline unsigned grid_of(const Geo& g, int batch, bool fused_rgb = false) {

@@ -102,6 +102,14 @@ MIGAN_DEVICE MIGAN_INLINE f4 act4(f4 v) {
             MIGAN_CLAMP(t.w, -256.0f, 256.0f)};
 }
 
+// act4 with the gain pre-multiplied by a power of two s: act4g(v, fl(sqrt2 * s)) == act4(v * s) exactly
+MIGAN_DEVICE MIGAN_INLINE f4 act4g(f4 v, float gain) {
+  f4 t = __builtin_elementwise_max(v, v * 0.2f);
+  t = t * gain;
+  return f4{MIGAN_CLAMP(t.x, -256.0f, 256.0f), MIGAN_CLAMP(t.y, -256.0f, 256.0f), MIGAN_CLAMP(t.z, -256.0f, 256.0f),
+            MIGAN_CLAMP(t.w, -256.0f, 256.0f)};
+}
+
 // ---- error-compensated bf16 GEMM operands -----------------------------------------------------
 // x = h1 + h2 + h3 (+ <= 2^-24 |x|) with h_i bf16: h1 = bf16(x), h2 = bf16(x - h1), h3 = bf16(x - h1 - h2)
 // (both subtractions are exact in fp32).  a*b is then summed from the six bf16 x bf16 products of
@@ -477,8 +485,16 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, MINW) sepconv_kernel(const SepArgs p)
         const int f = tid * 4 + e;                   // flat index into [KC][9]
         w_s[(f % 9) * KC + f / 9] = rw[e];
       }
+    } else if (tid < NW4) {
+      st4(w_s + tid * 4, rw);                        // depthwise bias
+    } else if (FROMRGB && tid < NW4 + KC) {
+      // fromrgb.weight row of channel ch = tid - NW4 (4 inputs) -> input-major [4][KC] so the tile builder below
+      // reads one float4 of 4 channels per input (packed FMAs)
+      const int ch = tid - NW4;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) w_s[KC * 10 + e * KC + ch] = rw[e];
     } else if (tid < NW4 + NF4) {
-      st4(w_s + tid * 4, rw);
+      st4(w_s + tid * 4, rw);                        // fromrgb bias
     }
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
@@ -505,14 +521,10 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, MINW) sepconv_kernel(const SepArgs p)
           f4 v = {0.f, 0.f, 0.f, 0.f};
           if (vmask & (1u << j)) {
             const f4 raw = ld4(rgb_s + pix * 4);
-            const float* wr = w_s + KC * 10 + c4 * 16;
-            const f4 w0 = ld4(wr), w1 = ld4(wr + 4), w2 = ld4(wr + 8), w3 = ld4(wr + 12);
+            const float* wr = w_s + KC * 10 + c4 * 4;
+            const f4 w0 = ld4(wr), w1 = ld4(wr + KC), w2 = ld4(wr + 2 * KC), w3 = ld4(wr + 3 * KC);   // per input, 4 channels
             const f4 bb = ld4(w_s + KC * 14 + c4 * 4);
-            v.x = bb.x + (w0.x * raw.x + w0.y * raw.y + w0.z * raw.z + w0.w * raw.w);
-            v.y = bb.y + (w1.x * raw.x + w1.y * raw.y + w1.z * raw.z + w1.w * raw.w);
-            v.z = bb.z + (w2.x * raw.x + w2.y * raw.y + w2.z * raw.z + w2.w * raw.w);
-            v.w = bb.w + (w3.x * raw.x + w3.y * raw.y + w3.z * raw.z + w3.w * raw.w);
-            v = act4(v);
+            v = act4(bb + (w0 * raw.x + w1 * raw.y + w2 * raw.z + w3 * raw.w));
           }
           st4(in_s + i * 4, v);
         }
@@ -684,8 +696,11 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, MINW) sepconv_kernel(const SepArgs p)
   const int wme = wavee >> 1, wne = wavee & 1, l31e = lanee & 31, halfe = lanee >> 5;
   __syncthreads();                       // all waves done with a_s/b_s before g_s overwrites them
   // F16: 1 / (activation scale * weight scale), a power of two written next to the weight planes by weight_absmax_kernel
+  // The scale is applied where the epilogue touches each value anyway: folded into the noise add (one FMA) or,
+  // without noise, into the activation gain (both exact: power-of-two scaling commutes with every rounding).
   float acc_scale = 1.0f;
   if constexpr (F16) acc_scale = reinterpret_cast<const float*>(p.wsplit)[-4];
+  const float gain_s = 1.41421356237309515f * acc_scale;
   // accumulator fragment -> LDS result tile.  C/D layout of the 32x32 MFMA: lane holds column
   // l&31, rows (r&3) + 8*(r>>2) + 4*(l>>5), r = 0..15.
 #pragma unroll
@@ -697,7 +712,6 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, MINW) sepconv_kernel(const SepArgs p)
         const int row = wme * WROWS + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * halfe;
         const int col = wne * WCOLS + j * 32 + l31e;
         float v = acc[i][j][r];
-        if constexpr (F16) v *= acc_scale;
         if constexpr (MODE == MODE_UP) {
           // halo pixels outside the low-resolution image contribute zeros to the upsampling FIR
           // (reference pads with zeros :101), not the conv of a zero-padded input
@@ -785,8 +799,13 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, MINW) sepconv_kernel(const SepArgs p)
 #pragma unroll
       for (int u = 0; u < UB; ++u) {
         f4 v = val[u];
-        if constexpr (HN) v += MIGAN_FMUL_RN(nz[u], ns);              // product rounded first, reference :166
-        v = act4(v);
+        if constexpr (HN) {
+          if constexpr (F16) v = v * acc_scale + MIGAN_FMUL_RN(nz[u], ns);
+          else v += MIGAN_FMUL_RN(nz[u], ns);                         // product rounded first, reference :166
+          v = act4(v);
+        } else {
+          v = F16 ? act4g(v, gain_s) : act4(v);
+        }
         f4 outv = v;
         if constexpr (HS) outv = v + sk[u];
         if (ok[u] && !MIGAN_ABL(1)) st4(yb + (size_t)upix[u] * p.CO + loff[u], outv);
@@ -887,8 +906,13 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, MINW) sepconv_kernel(const SepArgs p)
 #pragma unroll
         for (int bb = 0; bb < 2; ++bb) {
           f4 v = out[a][bb];
-          if constexpr (HN) v += MIGAN_FMUL_RN(nz[a][bb], ns);
-          v = act4(v);
+          if constexpr (HN) {
+            if constexpr (F16) v = v * acc_scale + MIGAN_FMUL_RN(nz[a][bb], ns);
+            else v += MIGAN_FMUL_RN(nz[a][bb], ns);
+            v = act4(v);
+          } else {
+            v = F16 ? act4g(v, gain_s) : act4(v);
+          }
           if constexpr (HS) v += sk[a][bb];
           if (!MIGAN_ABL(1)) st4(yb + (unsigned)(loff + (upix + a * p.WO + bb) * p.CO), v);
         }
@@ -1017,16 +1041,17 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, 3) dwfir_kernel(const DwFirArgs p) {
     // window: 12 LDS reads, 18 float4 FMAs).
     const int nstrips = IMGS * DH2 * DW * QC;
     const int yim0 = 2 * gy0 - 1, xim0 = 2 * gx0 - 1;
+    // every strip of a thread has the same channel quad (kThreads % QC == 0): its taps are read once per chunk
+    const int c4 = tid & (QC - 1);
+    f4 w[9];
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) w[tap] = ld4(w_s + tap * KC + c4 * 4);
+    const f4 bias = ld4(w_s + KC * 9 + c4 * 4);
     for (int it = tid; it < nstrips; it += kThreads) {
-      const int c4 = it & (QC - 1);
       int r = it >> LG_QC;
       const int dx = r % DW; r /= DW;
       const int sy2 = r % DH2, img = r / DH2;
       const int dy0 = 2 * sy2;
-      f4 w[9];
-#pragma unroll
-      for (int tap = 0; tap < 9; ++tap) w[tap] = ld4(w_s + tap * KC + c4 * 4);
-      const f4 bias = ld4(w_s + KC * 9 + c4 * 4);
       const float* ip = in_s + ((img * IGH + dy0) * IGW + dx) * KC + c4 * 4;
       f4 win[4][3];
 #pragma unroll
