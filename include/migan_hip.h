@@ -116,7 +116,8 @@ typedef struct migan_sepconv_desc {
   int up;                     /* 1 or 2 (Upsample2d, reference :79-103) */
   void* scratch;              /* down == 2 only: batch*(res_in/2)^2*cin floats (output of the depthwise+FIR kernel) */
   size_t scratch_bytes;
-  void* wsplit;               /* optional: 3*cout*cin*2 bytes for the bf16 weight planes of the bf16x3-split GEMM variant */
+  void* wsplit;               /* optional: 16 + 3*cout*cin*2 bytes (16-byte aligned) for the 16-bit weight planes of the split GEMM
+                                 variants; null or too small -> the exact fp32-MFMA kernels run */
   size_t wsplit_bytes;
 } migan_sepconv_desc;
 int migan_sepconv_forward(const migan_sepconv_desc* d, void* stream);
@@ -124,10 +125,14 @@ int migan_sepconv_forward(const migan_sepconv_desc* d, void* stream);
 const char* migan_last_error(void);
 /* "hip:gfx950" for the product library. */
 const char* migan_backend(void);
-/* How the 1x1 convolutions are multiplied (environment MIGAN_GEMM=f32|bf16x3, read once per process):
+/* How the 1x1 convolutions are multiplied (environment MIGAN_GEMM=f32|bf16x3|f16x2, read once per process):
  *   "f32"    v_mfma_f32_32x32x2_f32, exact fp32 products;
- *   "bf16x3" (default) each fp32 operand split into three bf16 pieces, the six products of order <= 2^-16
- *            on v_mfma_f32_32x32x16_bf16 with fp32 accumulation: fp32-grade accuracy at 6/16 of the MFMA cost. */
+ *   "bf16x3" each fp32 operand split into three bf16 pieces, the six products of order <= 2^-16
+ *            on v_mfma_f32_32x32x16_bf16 with fp32 accumulation: fp32-grade accuracy at 6/16 of the MFMA cost;
+ *   "f16x2"  (default) operands scaled by exact powers of two into fp16's normal range (activations by the
+ *            +-256 clamp of lrelu_agc, each weight tensor by its largest magnitude) and split into two fp16
+ *            pieces; three products on v_mfma_f32_32x32x16_f16, fp32 accumulation: fp32-grade accuracy at
+ *            3/16 of the MFMA cost. */
 const char* migan_gemm_variant(void);
 int migan_version(void);
 
