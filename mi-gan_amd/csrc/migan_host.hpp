@@ -73,6 +73,7 @@ struct Tuning {
   int gemm = 2;                // MIGAN_GEMM=f32|bf16x3|f16x2: 0 exact fp32 MFMA; 1 error-compensated bf16 MFMA (6 products of
                                // 3-way bf16 splits); 2 (default) error-compensated fp16 MFMA (3 products of scaled 2-way
                                // fp16 splits); all accumulate in fp32 and have the same end-to-end error
+  int nt256 = 1;               // MIGAN_NT256=0|1: 64-pixel x 256-channel tiles for the 256-channel layer that feeds ToRGB (fuses it)
   int ablate = 0;              // MIGAN_ABLATE (measurement builds compiled with -DMIGAN_ABLATE only)
   int persist_min = 8192;      // MIGAN_PERSIST_MIN: launches with at least this many tiles run persistent workgroups
   int persist_grid = 512;      // MIGAN_PERSIST_GRID: ... that many (2 per CU on MI355X), each walking its share of tiles
@@ -82,6 +83,7 @@ inline Tuning& tuning() {
     Tuning v;
     if (const char* e = std::getenv("MIGAN_SINGLE_B")) v.force_single_b = std::atoi(e) != 0;
     if (const char* e = std::getenv("MIGAN_GEMM")) v.gemm = std::string(e) == "f32" ? 0 : (std::string(e) == "bf16x3" ? 1 : 2);
+    if (const char* e = std::getenv("MIGAN_NT256")) v.nt256 = std::atoi(e) != 0;
     if (const char* e = std::getenv("MIGAN_ABLATE")) v.ablate = std::atoi(e);
     if (const char* e = std::getenv("MIGAN_PERSIST_MIN")) v.persist_min = std::max(1, std::atoi(e));
     if (const char* e = std::getenv("MIGAN_PERSIST_GRID")) v.persist_grid = std::max(8, std::atoi(e) / 8 * 8);   // multiple of 8: one share per XCD
@@ -90,7 +92,7 @@ inline Tuning& tuning() {
   return t;
 }
 
-inline Geo choose_geo(int mode, int cin, int cout, int res_in, bool fromrgb, bool fused_rgb = true, int gemmv = -1) {
+inline Geo choose_geo(int mode, int cin, int cout, int res_in, bool fromrgb, bool with_torgb = false, int gemmv = -1) {
   Geo g;
   g.gemmv = gemmv < 0 ? tuning().gemm : gemmv;
   g.mode = mode;
@@ -102,7 +104,13 @@ inline Geo choose_geo(int mode, int cin, int cout, int res_in, bool fromrgb, boo
   int GH, GW, IMGS;
   if (mode == MODE_NORMAL) {
     g.MT = 128; g.KC = 32;
-    if (res_in >= 16) { GH = 8; GW = 16; IMGS = 1; }
+    if (res_in >= 16 && cout == 256 && with_torgb && tuning().nt256) {
+      // 256-channel layer followed by ToRGB: one workgroup owns all 256 output channels of 4x16 pixels so the
+      // ToRGB tail fuses into its epilogue (saves the feature re-read of torgb_kernel).  Measured on its own the
+      // 64 x 256 tile is ~7 % slower than 128 x 128 (2-row depthwise strips, twice the weight-tile traffic), so
+      // it is used only where it removes a launch.
+      g.MT = 64; g.NT = 256; GH = 4; GW = 16; IMGS = 1;
+    } else if (res_in >= 16) { GH = 8; GW = 16; IMGS = 1; }
     else if (res_in == 8) { GH = 8; GW = 8; IMGS = 2; }
     else { GH = 4; GW = 4; IMGS = 8; }
     g.sy = GH; g.sx = GW; g.off = 0;
@@ -133,8 +141,8 @@ inline Geo choose_geo(int mode, int cin, int cout, int res_in, bool fromrgb, boo
   const int halo = (mode == MODE_PW) ? 0 : 1;
   g.npix_in = IMGS * (GH + 2 * halo) * (GW + 2 * halo);
   const int items = cdiv(g.npix_in * QC, kThreads);
-  g.maing = (IMGS == 1 && GH == 8 && GW == 16);
-  if (mode == MODE_PW) g.NI = 4;
+  g.maing = (IMGS == 1 && GW == 16 && GH == (g.MT == 64 ? 4 : 8));
+  if (mode == MODE_PW || g.MT == 64) g.NI = 4;
   else g.NI = g.maing ? 6 : 9;
   MIGAN_CHECK(items <= g.NI, MIGAN_EINVAL, "internal: input tile too large");
   g.MINW = 2;                                    // 2 workgroups per CU (3 measured slower: profiles/r01 notes)
@@ -144,7 +152,6 @@ inline Geo choose_geo(int mode, int cin, int cout, int res_in, bool fromrgb, boo
   const int asz = g.gemmv ? npl * g.MT * (g.KC * 2) / 4 : g.MT * AS;
   const int bsz = g.gemmv ? npl * g.NT * (g.KC * 2) / 4 : g.NT * AS;
   const int gs = g.MT * GS;   // accumulator tile; the fused ToRGB partial sums reuse its slots
-  (void)fused_rgb;
   const size_t limit = (size_t)(160 * 1024 / g.MINW);
   if (mode == MODE_PW) {
     // A and B operands double buffered: one barrier per K chunk
@@ -188,9 +195,9 @@ struct KernelEntry {
 #define MIGAN_KERNEL(MODE, MT, NT, KC, RGB, NI, MINW, MAING, PERSIST)                                                          \
   MIGAN_KERNEL1(MODE, MT, NT, KC, RGB, NI, MINW, MAING, PERSIST, 0, false), MIGAN_KERNEL1(MODE, MT, NT, KC, RGB, NI, MINW, MAING, PERSIST, 1, false), \
   MIGAN_KERNEL1(MODE, MT, NT, KC, RGB, NI, MINW, MAING, PERSIST, 2, false)
-#define MIGAN_KERNEL_TORGB(NT, NI, MAING, PERSIST)                                                                                \
-  MIGAN_KERNEL1(0, 128, NT, 32, false, NI, 2, MAING, PERSIST, 0, true), MIGAN_KERNEL1(0, 128, NT, 32, false, NI, 2, MAING, PERSIST, 1, true), \
-  MIGAN_KERNEL1(0, 128, NT, 32, false, NI, 2, MAING, PERSIST, 2, true)
+#define MIGAN_KERNEL_TORGB(MT, NT, NI, MAING, PERSIST)                                                                            \
+  MIGAN_KERNEL1(0, MT, NT, 32, false, NI, 2, MAING, PERSIST, 0, true), MIGAN_KERNEL1(0, MT, NT, 32, false, NI, 2, MAING, PERSIST, 1, true), \
+  MIGAN_KERNEL1(0, MT, NT, 32, false, NI, 2, MAING, PERSIST, 2, true)
 
 inline const std::vector<KernelEntry>& kernel_table() {
   static const std::vector<KernelEntry> t = {
@@ -202,8 +209,10 @@ inline const std::vector<KernelEntry>& kernel_table() {
       MIGAN_KERNEL(0, 128, 64, 32, true, 6, 2, true, false),   MIGAN_KERNEL(0, 128, 64, 32, true, 9, 2, false, false),
       MIGAN_KERNEL(0, 128, 64, 32, true, 6, 2, true, true),
       // plain layers whose epilogue also produces the running RGB image (CO == NT)
-      MIGAN_KERNEL_TORGB(128, 6, true, false), MIGAN_KERNEL_TORGB(128, 9, false, false), MIGAN_KERNEL_TORGB(64, 6, true, false),
-      MIGAN_KERNEL_TORGB(64, 9, false, false),
+      MIGAN_KERNEL_TORGB(128, 128, 6, true, false), MIGAN_KERNEL_TORGB(128, 128, 9, false, false), MIGAN_KERNEL_TORGB(128, 64, 6, true, false),
+      MIGAN_KERNEL_TORGB(128, 64, 9, false, false),
+      // 256-channel layer + ToRGB: 64 pixels x 256 channels
+      MIGAN_KERNEL_TORGB(64, 256, 4, true, false),
       // FIR-up layers (MODE 2)
       MIGAN_KERNEL(2, 128, 128, 32, false, 6, 2, true, false), MIGAN_KERNEL(2, 128, 128, 32, false, 9, 2, false, false),
       MIGAN_KERNEL(2, 128, 64, 32, false, 6, 2, true, false),  MIGAN_KERNEL(2, 128, 64, 32, false, 9, 2, false, false),
@@ -518,10 +527,11 @@ inline void migan_handle::build_plan() {
     return id;
   };
   auto add_sep = [&](const std::string& layer, int mode, int cin, int cout, int res_in, int res_out, bool fromrgb,
-                     bool noise, int in_buf, int out_buf, int skip_buf) -> Launch& {
+                     bool noise, int in_buf, int out_buf, int skip_buf, bool with_torgb = false) -> Launch& {
     Launch L;
     L.layer = layer;
-    L.g = choose_geo(mode, cin, cout, res_in, fromrgb);
+    L.g = choose_geo(mode, cin, cout, res_in, fromrgb, with_torgb);
+    L.g.torgb = with_torgb && L.g.nchunks == 1;        // one workgroup owns all channels of its pixels: ToRGB fuses
     L.kernel = pick_kernel(L.g).name;
     L.cin = cin; L.cout = cout; L.res_in = res_in; L.res_out = res_out;
     L.in_buf = in_buf; L.out_buf = out_buf; L.skip_buf = skip_buf;
@@ -598,7 +608,7 @@ inline void migan_handle::build_plan() {
     if (res == 4) add_sep(b + ".conv1", MODE_NORMAL, c, c, 4, 4, false, false, cur, o1, feat[ilog2(4)]);
     else add_sep(b + ".conv1", MODE_UP, channels_at(res / 2), c, res / 2, res, false, true, cur, o1, feat[ilog2(res)]);
     const int o2 = out_for(b + ".conv2", res, c, P0);
-    Launch& l2 = add_sep(b + ".conv2", MODE_NORMAL, c, c, res, res, false, res > 4, o1, o2, BUF_NONE);
+    Launch& l2 = add_sep(b + ".conv2", MODE_NORMAL, c, c, res, res, false, res > 4, o1, o2, BUF_NONE, true);
     cur = o2;
     int img_out;
     if (res == R) img_out = BUF_Y;
@@ -953,7 +963,7 @@ int migan_sepconv_forward(const migan_sepconv_desc* d, void* stream) {
   // bf16x3-split GEMM needs room for the three bf16 weight planes; without it the exact fp32 MFMA path runs
   const size_t wsplit_need = wsplit_elems_of(d->cin, d->cout) * sizeof(unsigned short);
   const int gemmv = (d->wsplit != nullptr && d->wsplit_bytes >= wsplit_need) ? tuning().gemm : 0;
-  const Geo g = choose_geo(mode, d->cin, d->cout, gemm_res, d->fromrgb_weight != nullptr, true, gemmv);
+  const Geo g = choose_geo(mode, d->cin, d->cout, gemm_res, d->fromrgb_weight != nullptr, d->torgb_weight != nullptr, gemmv);
   if (gemmv) {
     SplitArgs sa{};
     sa.dst = (unsigned short*)d->wsplit;
@@ -962,7 +972,7 @@ int migan_sepconv_forward(const migan_sepconv_desc* d, void* stream) {
     launch_split(sa, (rt::stream_t)stream);
   }
   MIGAN_CHECK(d->torgb_weight == nullptr || (g.nchunks == 1 && mode != MODE_UP && d->img_out), MIGAN_EINVAL,
-              "fused ToRGB needs cout <= 128, up == 1 and img_out");
+              "fused ToRGB needs cout <= 128 (or 256 at >= 16x16), up == 1 and img_out");
   SepArgs a{};
   a.x = gemm_in; a.y = (float*)d->y; a.skip = (const float*)d->skip;
   a.wdw = (const float*)d->conv1_weight; a.bdw = (const float*)d->conv1_bias; a.wpw = (const float*)d->conv2_weight;

@@ -249,7 +249,8 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, MINW) sepconv_kernel(const SepArgs p)
   constexpr int QN = NT / 4;
   constexpr int LG_QN = (QN == 64) ? 6 : ((QN == 32) ? 5 : 4);
   static_assert(QN == 64 || QN == 32 || QN == 16, "NT must be 256, 128 or 64");
-  constexpr int WROWS = MT / 2, WCOLS = NT / 2;    // per-wave tile
+  constexpr int WM = (MT >= 128) ? 2 : 1, WN = 4 / WM;   // wave grid over the MT x NT tile: 2x2, or 1x4 for the 64 x 256 tile
+  constexpr int WROWS = MT / WM, WCOLS = NT / WN;  // per-wave tile
   constexpr int MTI = WROWS / 32, NTI = WCOLS / 32;
   static_assert(MTI >= 1 && NTI >= 1, "wave tile must be at least 32x32");
   constexpr bool BF = (GEMMV >= 1);                // operands are planes of 16-bit pieces
@@ -262,7 +263,7 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, MINW) sepconv_kernel(const SepArgs p)
   static_assert(!BF || KC == 32, "the split GEMM variants are built for 32-channel chunks");
   constexpr int NW4 = KC * 10 / 4;                 // float4s of depthwise weights (9 taps) + bias per chunk
   constexpr int NF4 = FROMRGB ? KC * 5 / 4 : 0;    // float4s of fromrgb weights (4 per channel) + bias
-  constexpr int SEGH = 4;                          // output rows per depthwise strip (NORMAL / UP)
+  constexpr int SEGH = (MT >= 128) ? 4 : 2;        // output rows per depthwise strip (NORMAL / UP)
 
   const float* __restrict__ gx_ = p.x;
   float* __restrict__ gy_ = p.y;
@@ -274,7 +275,7 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, MINW) sepconv_kernel(const SepArgs p)
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / WN, wn = wave % WN;
   const int l31 = lane & 31, half = lane >> 5;
   PROF_BEGIN();
 
@@ -282,7 +283,7 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, MINW) sepconv_kernel(const SepArgs p)
   // folds to shifts and multiply-highs; the NI == 9 instantiations serve the small-resolution layers
   // (several images per tile) with run-time geometry.
   constexpr bool MAINGEO = MAING;
-  const int lgGH = MAINGEO ? 3 : p.lgGH;
+  const int lgGH = MAINGEO ? (MT >= 128 ? 3 : 2) : p.lgGH;   // main tiles: 8x16 pixels (MT 128) or 4x16 (MT 64)
   const int lgGW = MAINGEO ? 4 : p.lgGW;
   const int lgIMGS = MAINGEO ? 0 : p.lgIMGS;
   const int lgRS = MAINGEO ? 1 : p.lgRS;
@@ -693,7 +694,7 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, MINW) sepconv_kernel(const SepArgs p)
   int tide = tid;
   MIGAN_OPAQUE(tide);
   const int lanee = tide & 63, wavee = tide >> 6;
-  const int wme = wavee >> 1, wne = wavee & 1, l31e = lanee & 31, halfe = lanee >> 5;
+  const int wme = wavee / WN, wne = wavee % WN, l31e = lanee & 31, halfe = lanee >> 5;
   __syncthreads();                       // all waves done with a_s/b_s before g_s overwrites them
   // F16: 1 / (activation scale * weight scale), a power of two written next to the weight planes by weight_absmax_kernel
   // The scale is applied where the epilogue touches each value anyway: folded into the noise add (one FMA) or,
@@ -758,7 +759,7 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, MINW) sepconv_kernel(const SepArgs p)
       rgb_oy = gy0 + ((m >> lgGW) & (GH - 1));
       rgb_ox = gx0 + (m & (GW - 1));
       rgb_b = b0 + (m >> (lgGW + lgGH));
-      rgb_ok = (tide & 1) == 0 && rgb_b < p.B;
+      rgb_ok = (tide & 1) == 0 && rgb_b < p.B && tide < 2 * MT;
       if (rgb_ok && p.img_prev) {
         const size_t plane4 = ((size_t)p.HO * p.WO) >> 2;
 #pragma unroll
@@ -827,14 +828,14 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, MINW) sepconv_kernel(const SepArgs p)
       // exchange combines them; the even thread adds bias + the 2x-upsampled previous image (its 4 taps per
       // channel were loaded before the item loop) and writes the three planes (consecutive x per lane pair).
       __syncthreads();
-      const int m = tide >> 1, hsel = tide & 1;
+      const int m = (tide >> 1) & (MT - 1), hsel = tide & 1;      // MT < 128: the upper threads repeat rows, results unused
       f4 sum = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int q = 0; q < QN / 2; ++q) sum += ld4(g_s + m * GS + (hsel * (QN / 2) + q) * 4);
       sum.x += MIGAN_SWIZZLE_XOR(sum.x, 1);
       sum.y += MIGAN_SWIZZLE_XOR(sum.y, 1);
       sum.z += MIGAN_SWIZZLE_XOR(sum.z, 1);
-      if (rgb_ok) {
+      if (rgb_ok) {   // (tide < 2 * MT is part of rgb_ok)
         const float rgb[3] = {sum.x + p.trgb_b[0], sum.y + p.trgb_b[1], sum.z + p.trgb_b[2]};
         const size_t plane = (size_t)p.HO * p.WO;
 #pragma unroll

@@ -43,6 +43,7 @@ __device__ __forceinline__ float migan_swizzle_xor(float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), ((M << 10) | 0x1f)));
 }
 #define MIGAN_SWIZZLE_XOR(v, m) migan_swizzle_xor<(m)>(v)
+#define MIGAN_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 #define MIGAN_OPAQUE(x) asm volatile("" : "+v"(x))
 #define MIGAN_CLOCK() __builtin_readcyclecounter()
 #define MIGAN_ATOMIC_ADD_U64(p, v) atomicAdd((p), (v))

@@ -125,6 +125,7 @@ void run_grid(void (*invoke)(const void*), const void* arg, unsigned grid, unsig
 inline float __shfl_xor(float v, int mask);
 #define MIGAN_CLAMP(v, lo, hi) fminf(fmaxf((v), (lo)), (hi))
 #define MIGAN_SWIZZLE_XOR(v, m) __shfl_xor((v), (m))
+#define MIGAN_SCHED_FENCE() do {} while (0)
 #define MIGAN_OPAQUE(x) asm volatile("" : "+r"(x))
 #define MIGAN_CLOCK() 0
 #define MIGAN_ATOMIC_ADD_U64(p, v) (*(p) += (v))

@@ -65,6 +65,8 @@ def _run(lib, pkg, *, cin, cout, res_in, batch, down=1, up=1, noise=False, skip=
     (64, 64, 16, 1, False, False),     # NT=64, one n-chunk, 2 tiles
     (32, 128, 16, 2, True, True),      # NT=128, single K chunk
     (64, 256, 32, 1, True, False),     # two n-chunks, 8 tiles (XCD remap over 16 workgroups)
+    (96, 512, 16, 3, True, True),      # four n-chunks, 3 K chunks, skip
+    (64, 384, 16, 1, False, False),    # 3 n-chunks of 128 (Cout not a multiple of 256)
     (64, 64, 8, 3, False, True),       # 2 images per tile, ragged batch
     (64, 128, 4, 3, True, False),      # 8 images per tile, ragged batch
 ])
@@ -110,7 +112,7 @@ def test_fromrgb_fused(lib, pkg):
     np.testing.assert_allclose(nchw(y), want, rtol=0, atol=2e-5 * max(1.0, float(np.abs(want).max())))
 
 
-@pytest.mark.parametrize("with_prev,cout", [(False, 64), (True, 64), (True, 128)])
+@pytest.mark.parametrize("with_prev,cout", [(False, 64), (True, 64), (True, 128), (True, 256)])
 def test_torgb_fused(lib, pkg, with_prev, cout):
     cin = cout
     res, batch = 16, 2

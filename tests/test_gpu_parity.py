@@ -82,6 +82,7 @@ def _sep(pkg, dev, *, cin, cout, res_in, batch, down=1, up=1, noise=False, skip=
     dict(cin=64, cout=64, res_in=16, batch=1),
     dict(cin=32, cout=128, res_in=16, batch=2, noise=True, skip=True),
     dict(cin=64, cout=256, res_in=32, batch=1, noise=True),
+    dict(cin=96, cout=512, res_in=16, batch=3, noise=True, skip=True),
     dict(cin=64, cout=64, res_in=8, batch=3, skip=True),
     dict(cin=64, cout=128, res_in=4, batch=3, noise=True),
     dict(cin=32, cout=64, res_in=32, batch=1, down=2),
@@ -107,7 +108,7 @@ def test_sepconv_weight_magnitude_does_not_matter(pkg, dev, kw, wscale):
 
 
 @pytest.mark.parametrize("with_prev,cout,res,batch", [(False, 64, 16, 2), (True, 64, 32, 1), (True, 128, 16, 2), (True, 128, 8, 3),
-                                                      (True, 64, 4, 5)])
+                                                      (True, 64, 4, 5), (True, 256, 32, 2), (False, 256, 16, 1)])
 def test_sepconv_with_fused_torgb(pkg, dev, with_prev, cout, res, batch):
     """conv2 of a synthesis block with the ToRGB + running-image update fused into its epilogue
     (reference :308-313): both the feature map and the three image planes."""
