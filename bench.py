@@ -198,7 +198,7 @@ def main():
         # ---- CPU baseline + parity on the same inputs (rank 0, N = 1 protocol) ---------------------
         cpu = None
         parity = None
-        if args.cpu_images > 0:
+        if args.cpu_images > 0 and world == 1:      # the CPU baseline is an N = 1 measurement (rank 0 only)
             from oracle import migan_torch_cpu as torc
             n = min(args.cpu_images, B)
             xs = x_np[:n]

@@ -51,6 +51,7 @@ struct Geo {
   bool persist = false;            // kernel variant whose workgroups walk several tiles
   int gemmv = 0;                   // 0 exact fp32 MFMA, 1 bf16x3-split MFMA, 2 f16x2-split MFMA
   bool torgb = false;              // kernel variant with the ToRGB tail in its epilogue
+  bool wide = false;               // sepconv_wide_kernel: 128 pixels x 256 channels, 512 threads, specialised wave groups
   int a_stride = 0;
   int lgGH = 3, lgGW = 4, lgIMGS = 0;
   int sy = 8, sx = 16, off = 0, lgRS = 1;
@@ -73,6 +74,7 @@ struct Tuning {
   int gemm = 2;                // MIGAN_GEMM=f32|bf16x3|f16x2: 0 exact fp32 MFMA; 1 error-compensated bf16 MFMA (6 products of
                                // 3-way bf16 splits); 2 (default) error-compensated fp16 MFMA (3 products of scaled 2-way
                                // fp16 splits); all accumulate in fp32 and have the same end-to-end error
+  int wide = 1;                // MIGAN_WIDE=0|1: 8-wave 128 x 256 tiles for plain layers with Cout % 256 == 0 (f16x2 GEMM only)
   int nt256 = 1;               // MIGAN_NT256=0|1: 64-pixel x 256-channel tiles for the 256-channel layer that feeds ToRGB (fuses it)
   int ablate = 0;              // MIGAN_ABLATE (measurement builds compiled with -DMIGAN_ABLATE only)
   int persist_min = 8192;      // MIGAN_PERSIST_MIN: launches with at least this many tiles run persistent workgroups
@@ -83,6 +85,7 @@ inline Tuning& tuning() {
     Tuning v;
     if (const char* e = std::getenv("MIGAN_SINGLE_B")) v.force_single_b = std::atoi(e) != 0;
     if (const char* e = std::getenv("MIGAN_GEMM")) v.gemm = std::string(e) == "f32" ? 0 : (std::string(e) == "bf16x3" ? 1 : 2);
+    if (const char* e = std::getenv("MIGAN_WIDE")) v.wide = std::atoi(e) != 0;
     if (const char* e = std::getenv("MIGAN_NT256")) v.nt256 = std::atoi(e) != 0;
     if (const char* e = std::getenv("MIGAN_ABLATE")) v.ablate = std::atoi(e);
     if (const char* e = std::getenv("MIGAN_PERSIST_MIN")) v.persist_min = std::max(1, std::atoi(e));
@@ -104,7 +107,11 @@ inline Geo choose_geo(int mode, int cin, int cout, int res_in, bool fromrgb, boo
   int GH, GW, IMGS;
   if (mode == MODE_NORMAL) {
     g.MT = 128; g.KC = 32;
-    if (res_in >= 16 && cout == 256 && with_torgb && tuning().nt256) {
+    if (res_in >= 16 && cout % 256 == 0 && !fromrgb && g.gemmv == 2 && tuning().wide) {
+      // wide layers: one 8-wave workgroup owns 256 output channels of 8x16 pixels; half of its waves run the
+      // depthwise stage of the next K chunk while the other half keeps the matrix cores busy (sepconv_wide_kernel)
+      g.wide = true; g.NT = 256; GH = 8; GW = 16; IMGS = 1;
+    } else if (res_in >= 16 && cout == 256 && with_torgb && tuning().nt256) {
       // 256-channel layer followed by ToRGB: one workgroup owns all 256 output channels of 4x16 pixels so the
       // ToRGB tail fuses into its epilogue (saves the feature re-read of torgb_kernel).  Measured on its own the
       // 64 x 256 tile is ~7 % slower than 128 x 128 (2-row depthwise strips, twice the weight-tile traffic), so
@@ -171,6 +178,12 @@ inline Geo choose_geo(int mode, int cin, int cout, int res_in, bool fromrgb, boo
     if (dbl <= limit && !tuning().force_single_b) { g.b_stride = bsz; g.lds_bytes = dbl; }   // double-buffered 1x1 weights: 2 barriers per K chunk
     else { g.b_stride = 0; g.lds_bytes = sgl; }
   }
+  if (g.wide) {
+    // sepconv_wide_kernel carves its own LDS: 2 x (input tile + taps + A planes + B planes), aliased by the result tile
+    const int in_sz = 10 * 18 * g.KC, w_sz = g.KC * 10, a_sz = 2 * g.MT * (g.KC * 2) / 4, b_sz = 2 * g.NT * (g.KC * 2) / 4;
+    g.NI = 3; g.b_stride = b_sz; g.a_stride = a_sz;
+    g.lds_bytes = (size_t)std::max(2 * (in_sz + w_sz + a_sz + b_sz), g.MT * (g.NT + 4)) * sizeof(float);
+  }
   MIGAN_CHECK(g.lds_bytes <= 160 * 1024, MIGAN_EINVAL, "internal: LDS tile exceeds 160 KiB");
   return g;
 }
@@ -225,6 +238,8 @@ inline const std::vector<KernelEntry>& kernel_table() {
   return t;
 }
 
+inline const char* wide_name(const Geo& g) { return g.torgb ? "migan::sepconv_wide_kernel<true>" : "migan::sepconv_wide_kernel<false>"; }
+inline const char* kernel_name(const Geo& g);
 inline const KernelEntry& pick_kernel(const Geo& g) {
   for (const auto& e : kernel_table())
     if (e.mode == g.mode && e.MT == g.MT && e.NT == g.NT && e.KC == g.KC && e.fromrgb == g.fromrgb && e.NI == g.NI &&
@@ -232,6 +247,8 @@ inline const KernelEntry& pick_kernel(const Geo& g) {
       return e;
   throw Error(MIGAN_EINVAL, "internal: no kernel instantiation for this geometry");
 }
+
+inline const char* kernel_name(const Geo& g) { return g.wide ? wide_name(g) : pick_kernel(g).name; }
 
 // persistent variants exist where they fit the register budget without spilling
 inline bool has_persistent_variant(const Geo& g) {
@@ -275,6 +292,8 @@ inline void prepare_kernels() {
   static bool done = false;
   if (done) return;
   for (const auto& e : kernel_table()) rt_check(rt::allow_dynamic_lds((const void*)e.fn, 96 * 1024), "hipFuncSetAttribute");
+  rt_check(rt::allow_dynamic_lds((const void*)sepconv_wide_kernel<true>, 160 * 1024), "hipFuncSetAttribute");
+  rt_check(rt::allow_dynamic_lds((const void*)sepconv_wide_kernel<false>, 160 * 1024), "hipFuncSetAttribute");
   rt_check(rt::allow_dynamic_lds((const void*)dwfir_kernel<7, true>, 96 * 1024), "hipFuncSetAttribute");
   rt_check(rt::allow_dynamic_lds((const void*)dwfir_kernel<9, false>, 96 * 1024), "hipFuncSetAttribute");
   done = true;
@@ -330,6 +349,12 @@ inline void launch_sepconv(Geo g, const SepArgs& a, rt::stream_t stream) {
   g.torgb = fused_rgb;
   MIGAN_CHECK(!fused_rgb || (g.mode == MODE_NORMAL && !g.fromrgb && g.nchunks == 1 && g.MINW == 2), MIGAN_EINVAL,
               "ToRGB can only be fused into a plain layer whose output channels fit one column tile");
+  if (g.wide) {
+    MIGAN_CHECK(a.wsplit != nullptr, MIGAN_EINVAL, "internal: the wide kernel needs the fp16 weight planes");
+    void (*fn)(const SepArgs) = fused_rgb ? sepconv_wide_kernel<true> : sepconv_wide_kernel<false>;
+    rt_check(rt::launch(fn, a, tiles_of(g, a.B), kWideThreads, g.lds_bytes, stream), wide_name(g));
+    return;
+  }
   const KernelEntry& k = pick_kernel(g);
   rt_check(rt::launch(k.fn, a, grid_of(g, a.B, fused_rgb), kThreads, g.lds_bytes, stream), k.name);
 }
@@ -532,7 +557,7 @@ inline void migan_handle::build_plan() {
     L.layer = layer;
     L.g = choose_geo(mode, cin, cout, res_in, fromrgb, with_torgb);
     L.g.torgb = with_torgb && L.g.nchunks == 1;        // one workgroup owns all channels of its pixels: ToRGB fuses
-    L.kernel = pick_kernel(L.g).name;
+    L.kernel = kernel_name(L.g);
     L.cin = cin; L.cout = cout; L.res_in = res_in; L.res_out = res_out;
     L.in_buf = in_buf; L.out_buf = out_buf; L.skip_buf = skip_buf;
     L.w_dw = slot_index(layer + ".conv1.weight");
@@ -622,7 +647,7 @@ inline void migan_handle::build_plan() {
       // one workgroup owns all output channels of its pixels: ToRGB fused into the conv2 epilogue
       l2.w_trgb = wt; l2.b_trgb = bt;
       l2.g.torgb = true;
-      l2.kernel = pick_kernel(l2.g).name;
+      l2.kernel = kernel_name(l2.g);
       l2.imgprev_buf = img_cur; l2.imgout_buf = img_out;
       l2.flops += rgb_flops; l2.bytes += rgb_bytes;
     } else {
@@ -724,7 +749,7 @@ inline void migan_handle::forward(const float* x, float* y, int batch, void* ws,
       Geo gl = L.g;
       gl.persist = use_persistent(gl, batch, a.trgb_w != nullptr);
       gl.torgb = a.trgb_w != nullptr;
-      L.kernel_last = pick_kernel(gl).name;
+      L.kernel_last = kernel_name(gl);
     }
     if (timed) rt_check(rt::event_record(events[2 * li + 1], stream), "hipEventRecord");
 #ifdef MIGAN_PHASE_PROF

@@ -937,6 +937,338 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, MINW) sepconv_kernel(const SepArgs p)
 }
 
 // ------------------------------------------------------------------------------------------------
+// Wide plain layers (Cout % 256 == 0, output >= 16x16, f16x2 GEMM): one workgroup of 8 waves owns
+// 8x16 pixels x 256 output channels, so the depthwise stage of a pixel runs Cout/256 instead of Cout/128
+// times, and the two halves of the workgroup are specialised so that stage never stalls the matrix cores:
+//
+//   waves 0-3 ("A"): depthwise 3x3 + act + fp16 split of chunk c+1 (-> a_s[(c+1)&1]), then their MFMAs of chunk c
+//   waves 4-7 ("B"): MFMAs of chunk c (they run on the same four SIMDs while A is in its VALU/LDS stage)
+//   all 512 threads: global -> register prefetch (input tile 3 chunks ahead, 1x1 weight planes 2 ahead),
+//                    register -> LDS stores, epilogue
+//
+// Everything the K loop touches is double buffered (input tile, taps, A planes, B planes: 145 KB), so one
+// barrier per chunk suffices.  MFMA wave grid 2 x 4, each wave 64 x 64 (same fragments as sepconv_kernel).
+constexpr int kWideThreads = 512;
+template <bool TORGB>
+MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(kWideThreads, 2) sepconv_wide_kernel(const SepArgs p) {
+  MIGAN_DYN_SMEM(smem);
+  constexpr int MT = 128, NT = 256, KC = 32, QC = 8, LG_QC = 3;
+  constexpr int GS = NT + 4, QN = NT / 4, LG_QN = 6;
+  constexpr int GH = 8, GW = 16, lgGW = 4;
+  constexpr int IGH = GH + 2, IGW = GW + 2, NPIX = IGH * IGW, NITEMS = NPIX * QC;
+  constexpr int NI = (NITEMS + kWideThreads - 1) / kWideThreads;            // 3 float4 input items per thread and chunk
+  constexpr int PB = KC * 2, NSLOT = PB / 16, NPL = 2;
+  constexpr int NB = NPL * NT * NSLOT / kWideThreads;                       // 4 float4 weight-plane items per thread and chunk
+  static_assert(NB * kWideThreads == NPL * NT * NSLOT, "weight tile must split evenly over the threads");
+  constexpr int NW4 = KC * 10 / 4;
+  constexpr int WN = 4, WROWS = 64, WCOLS = 64, MTI = 2, NTI = 2;
+  constexpr int SEGH = 4;
+  // LDS carve (floats)
+  constexpr int IN_SZ = NPIX * KC, W_SZ = KC * 10, A_SZ = NPL * MT * PB / 4, B_SZ = NPL * NT * PB / 4;
+  constexpr int OFF_IN = 0, OFF_W = OFF_IN + 2 * IN_SZ, OFF_A = OFF_W + 2 * W_SZ, OFF_B = OFF_A + 2 * A_SZ;
+  static_assert((OFF_B + 2 * B_SZ) * 4 <= 160 * 1024 && MT * GS * 4 <= 160 * 1024, "LDS budget");
+  float* g_s = smem;                                                        // after the K loop: [MT][GS]
+
+  const float* __restrict__ gx_ = p.x;
+  float* __restrict__ gy_ = p.y;
+  const float* __restrict__ gskip = p.skip;
+  const float* __restrict__ gnoise = p.noise;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int l31 = lane & 31, half = lane >> 5;
+  const bool groupA = tid < 256;
+
+  // tile schedule: same XCD-contiguous order as sepconv_kernel, one tile per workgroup
+  const int ntiles = p.tiles_x * p.tiles_y * p.nchunks * p.B;
+  const int xcd = (int)blockIdx.x & 7;
+  const int tq = ntiles >> 3, tr = ntiles & 7;
+  const int tbase = xcd < tr ? xcd * (tq + 1) : tr * (tq + 1) + (xcd - tr) * tq;
+  int t = tbase + ((int)blockIdx.x >> 3);
+  const int nch = t % p.nchunks; t /= p.nchunks;
+  const int tx = t % p.tiles_x;  t /= p.tiles_x;
+  const int ty = t % p.tiles_y;
+  const int n0 = nch * NT, b0 = t / p.tiles_y, gy0 = ty * GH, gx0 = tx * GW;
+
+  // per-thread item descriptors (constant across K chunks)
+  unsigned goff[NI], boff[NB], vmask = 0, emask = 0;
+#pragma unroll
+  for (int j = 0; j < NI; ++j) {
+    const int i = tid + j * kWideThreads;
+    unsigned g = 0;
+    if (i < NITEMS) {
+      emask |= 1u << j;
+      const int c4 = i & (QC - 1);
+      const int pix = i >> LG_QC;
+      const int ix = pix % IGW, iy = pix / IGW;
+      const int yy = gy0 - 1 + iy, xx = gx0 - 1 + ix;
+      if (yy >= 0 && yy < p.H && xx >= 0 && xx < p.W) {
+        vmask |= 1u << j;
+        g = (unsigned)((yy * p.W + xx) * p.CI + c4 * 4);
+      }
+    }
+    goff[j] = g;
+  }
+#pragma unroll
+  for (int j = 0; j < NB; ++j) {
+    const int i = tid + j * kWideThreads;
+    const int plane = i / (NT * NSLOT), rem = i % (NT * NSLOT);
+    boff[j] = (unsigned)(((plane * p.CO + n0 + rem / NSLOT) * p.CI) + (rem % NSLOT) * 8);
+  }
+  const float* __restrict__ xb = gx_ + (size_t)b0 * p.H * p.W * p.CI;
+  f4 rin[NI], rb[NB], rw;
+  auto load_in = [&](int k0) {                     // input tile + depthwise taps of one chunk
+#pragma unroll
+    for (int j = 0; j < NI; ++j) rin[j] = ld4(xb + k0 + goff[j]);
+    if (tid < KC * 9 / 4) rw = ld4(p.wdw + (size_t)k0 * 9 + (unsigned)(tid * 4));
+    else if (tid < NW4) rw = ld4(p.bdw + k0 + (unsigned)((tid - KC * 9 / 4) * 4));
+  };
+  auto load_b = [&](int k0) {                      // fp16 planes of the 1x1 weights of one chunk
+    const unsigned short* __restrict__ wk = p.wsplit + k0;
+#pragma unroll
+    for (int j = 0; j < NB; ++j) rb[j] = ld4(reinterpret_cast<const float*>(wk + boff[j]));
+  };
+  auto store_in = [&](int buf) {
+    float* in_s = smem + OFF_IN + buf * IN_SZ;
+    float* w_s = smem + OFF_W + buf * W_SZ;
+    if (tid < KC * 9 / 4) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int f = tid * 4 + e;                   // flat index into [KC][9] -> tap-major [9][KC]
+        w_s[(f % 9) * KC + f / 9] = rw[e];
+      }
+    } else if (tid < NW4) {
+      st4(w_s + tid * 4, rw);
+    }
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      if (emask & (1u << j)) {
+        f4 v = rin[j];
+        if (!(vmask & (1u << j))) v = f4{0.f, 0.f, 0.f, 0.f};
+        st4(in_s + (tid + j * kWideThreads) * 4, v);
+      }
+    }
+  };
+  auto store_b = [&](int buf) {
+    char* bb = reinterpret_cast<char*>(smem + OFF_B + buf * B_SZ);
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      const int i = tid + j * kWideThreads;
+      const int plane = i / (NT * NSLOT), rem = i % (NT * NSLOT);
+      const int n = rem / NSLOT, slot = rem % NSLOT;
+      st4(reinterpret_cast<float*>(bb + (plane * NT + n) * PB + ((slot ^ ((n >> 2) & (NSLOT - 1))) << 4)), rb[j]);
+    }
+  };
+  // depthwise 3x3 + bias + act (x 2^7) + fp16 split of one chunk: threads 0..255, one 4-row strip x 4 channels each
+  auto depthwise = [&](int buf, int abuf) {
+    const float* in_s = smem + OFF_IN + buf * IN_SZ;
+    const float* w_s = smem + OFF_W + buf * W_SZ;
+    char* a_b = reinterpret_cast<char*>(smem + OFF_A + abuf * A_SZ);
+    const int c4 = tid & (QC - 1);
+    const int gx = (tid >> LG_QC) & (GW - 1);
+    const int r0 = (tid >> (LG_QC + lgGW)) * SEGH;
+    f4 w[9];
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) w[tap] = ld4(w_s + tap * KC + c4 * 4);
+    const f4 bias = ld4(w_s + KC * 9 + c4 * 4);
+    const float* ip = in_s + (r0 * IGW + gx) * KC + c4 * 4;
+    f4 win[3][3];
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr) {
+      win[rr][0] = ld4(ip); win[rr][1] = ld4(ip + KC); win[rr][2] = ld4(ip + 2 * KC);
+      ip += IGW * KC;
+    }
+#pragma unroll
+    for (int o = 0; o < SEGH; ++o) {
+      const int nr = (o + 2) % 3;
+      win[nr][0] = ld4(ip); win[nr][1] = ld4(ip + KC); win[nr][2] = ld4(ip + 2 * KC);
+      ip += IGW * KC;
+      f4 sacc = bias;
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) sacc += w[ky * 3 + kx] * win[(o + ky) % 3][kx];
+      const int m = ((r0 + o) << lgGW) + gx;
+      u2v h1, h2;
+      split2_f16(act4_scaled<7>(sacc), h1, h2);
+      char* d = a_b + m * PB + (((c4 >> 1) ^ ((m >> 2) & (NSLOT - 1))) << 4) + ((c4 & 1) << 3);
+      *reinterpret_cast<u2v*>(d) = h1;
+      *reinterpret_cast<u2v*>(d + MT * PB) = h2;
+    }
+  };
+  f16v acc[MTI][NTI];
+#pragma unroll
+  for (int i = 0; i < MTI; ++i)
+#pragma unroll
+    for (int j = 0; j < NTI; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+  auto mfma_chunk = [&](int buf) {
+    const char* ab = reinterpret_cast<const char*>(smem + OFF_A + buf * A_SZ);
+    const char* bb = reinterpret_cast<const char*>(smem + OFF_B + buf * B_SZ);
+#pragma unroll
+    for (int ks = 0; ks < KC / 16; ++ks) {
+      f4 av[MTI][NPL], bv[NTI][NPL];
+#pragma unroll
+      for (int i = 0; i < MTI; ++i) {
+        const int row = wm * WROWS + i * 32 + l31;
+        const char* q = ab + row * PB + (((2 * ks + half) ^ ((row >> 2) & (NSLOT - 1))) << 4);
+#pragma unroll
+        for (int pl = 0; pl < NPL; ++pl) av[i][pl] = ld4(reinterpret_cast<const float*>(q + pl * MT * PB));
+      }
+#pragma unroll
+      for (int j = 0; j < NTI; ++j) {
+        const int row = wn * WCOLS + j * 32 + l31;
+        const char* q = bb + row * PB + (((2 * ks + half) ^ ((row >> 2) & (NSLOT - 1))) << 4);
+#pragma unroll
+        for (int pl = 0; pl < NPL; ++pl) bv[j][pl] = ld4(reinterpret_cast<const float*>(q + pl * NT * PB));
+      }
+#pragma unroll
+      for (int i = 0; i < MTI; ++i)
+#pragma unroll
+        for (int j = 0; j < NTI; ++j) {
+          acc[i][j] = MIGAN_MFMA_F16_32X32X16(av[i][1], bv[j][0], acc[i][j]);
+          acc[i][j] = MIGAN_MFMA_F16_32X32X16(av[i][0], bv[j][1], acc[i][j]);
+          acc[i][j] = MIGAN_MFMA_F16_32X32X16(av[i][0], bv[j][0], acc[i][j]);
+        }
+    }
+  };
+
+  // ---- prologue: chunk 0 complete in LDS (input, taps, A planes, B planes), chunk 1 input in LDS ----------
+  const int nkc = p.CI / KC;
+  load_in(0);
+  load_b(0);
+  store_in(0);
+  store_b(0);
+  if (1 < nkc) { load_in(KC); load_b(KC); }
+  __syncthreads();
+  if (groupA) depthwise(0, 0);
+  if (1 < nkc) store_in(1);
+  if (2 < nkc) load_in(2 * KC);
+  __syncthreads();
+  // ---- K loop: one barrier per chunk ------------------------------------------------------------------------
+  // at the top of iteration c: a_s[c&1], b_s[c&1] = chunk c; in_s/w_s[(c+1)&1] = chunk c+1;
+  // registers: weight planes of chunk c+1, input tile of chunk c+2
+  for (int c = 0; c < nkc; ++c) {
+    if (c + 1 < nkc) store_b((c + 1) & 1);        // last read by the MFMAs of chunk c-1
+    if (c + 2 < nkc) {
+      store_in(c & 1);                            // last read by the depthwise stage of chunk c
+      load_b((c + 2) * KC);
+    }
+    if (c + 3 < nkc) load_in((c + 3) * KC);
+    if (groupA && c + 1 < nkc) depthwise((c + 1) & 1, (c + 1) & 1);   // a_s[(c+1)&1] last read by the MFMAs of chunk c-1
+    mfma_chunk(c & 1);
+    __syncthreads();
+  }
+
+  // ======================================= epilogue ========================================
+  int tide = tid;
+  MIGAN_OPAQUE(tide);
+  const int lanee = tide & 63, wavee = tide >> 6;
+  const int wme = wavee / WN, wne = wavee % WN, l31e = lanee & 31, halfe = lanee >> 5;
+  const float acc_scale = reinterpret_cast<const float*>(p.wsplit)[-4];
+  const float gain_s = 1.41421356237309515f * acc_scale;
+#pragma unroll
+  for (int i = 0; i < MTI; ++i)
+#pragma unroll
+    for (int j = 0; j < NTI; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = wme * WROWS + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * halfe;
+        const int col = wne * WCOLS + j * 32 + l31e;
+        g_s[row * GS + col] = acc[i][j][r];
+      }
+  __syncthreads();
+
+  const bool has_noise = gnoise != nullptr;
+  const float ns = has_noise ? p.noise_strength[0] : 0.0f;
+  constexpr int ITEMS = MT * QN / kWideThreads;      // 16
+  constexpr int UB = 4;
+  constexpr int STEP = kWideThreads >> LG_QN;        // 8 GEMM rows between the items of a thread
+  const int c4 = tide & (QN - 1);
+  const int m0 = tide >> LG_QN;
+  const int gxt = m0 & (GW - 1), gyt = m0 >> lgGW;
+  const size_t img_elems = (size_t)p.HO * p.WO * p.CO;
+  float* __restrict__ yb = gy_ + (size_t)b0 * img_elems;
+  const float* __restrict__ sb = gskip ? gskip + (size_t)b0 * img_elems : nullptr;
+  f4 tw0 = {0.f, 0.f, 0.f, 0.f}, tw1 = tw0, tw2 = tw0;
+  int rgb_oy = 0, rgb_ox = 0;
+  bool rgb_ok = false;
+  float pv[3][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+  if constexpr (TORGB) {
+    tw0 = ld4(p.trgb_w + n0 + c4 * 4);
+    tw1 = ld4(p.trgb_w + p.CO + n0 + c4 * 4);
+    tw2 = ld4(p.trgb_w + 2 * p.CO + n0 + c4 * 4);
+    const int m = tide >> 1;
+    rgb_oy = gy0 + ((m >> lgGW) & (GH - 1));
+    rgb_ox = gx0 + (m & (GW - 1));
+    rgb_ok = (tide & 1) == 0 && tide < 2 * MT;
+    if (rgb_ok && p.img_prev) {
+      const size_t plane4 = ((size_t)p.HO * p.WO) >> 2;
+#pragma unroll
+      for (int ch = 0; ch < 3; ++ch) up_taps(p.img_prev + ((size_t)b0 * 3 + ch) * plane4, p.HO >> 1, p.WO >> 1, rgb_oy, rgb_ox, pv[ch]);
+    }
+  }
+  const unsigned pix_t = (unsigned)((gy0 + gyt) * p.WO + gx0 + gxt);
+  const unsigned off_t = pix_t * (unsigned)p.CO + (unsigned)(n0 + c4 * 4);
+  auto epi_items = [&](auto hn_, auto hs_) {
+    constexpr bool HN = decltype(hn_)::value, HS = decltype(hs_)::value;
+#pragma unroll
+    for (int it0 = 0; it0 < ITEMS; it0 += UB) {
+      f4 val[UB], sk[UB];
+      float nz[UB];
+      int upix[UB];
+#pragma unroll
+      for (int u = 0; u < UB; ++u) {
+        const int dm = (it0 + u) * STEP;
+        val[u] = ld4(g_s + (m0 + dm) * GS + c4 * 4);
+        upix[u] = (dm >> lgGW) * p.WO + (dm & (GW - 1));
+        if constexpr (HN) nz[u] = (gnoise + upix[u])[pix_t];
+        if constexpr (HS) sk[u] = ld4(sb + (size_t)upix[u] * p.CO + off_t);
+      }
+#pragma unroll
+      for (int u = 0; u < UB; ++u) {
+        f4 v = val[u];
+        if constexpr (HN) {
+          v = v * acc_scale + MIGAN_FMUL_RN(nz[u], ns);              // product rounded first, reference :166
+          v = act4(v);
+        } else {
+          v = act4g(v, gain_s);
+        }
+        f4 outv = v;
+        if constexpr (HS) outv = v + sk[u];
+        st4(yb + (size_t)upix[u] * p.CO + off_t, outv);
+        if constexpr (TORGB) {
+          const float r0 = v.x * tw0.x + v.y * tw0.y + v.z * tw0.z + v.w * tw0.w;
+          const float r1 = v.x * tw1.x + v.y * tw1.y + v.z * tw1.z + v.w * tw1.w;
+          const float r2 = v.x * tw2.x + v.y * tw2.y + v.z * tw2.z + v.w * tw2.w;
+          st4(g_s + (m0 + (it0 + u) * STEP) * GS + c4 * 4, f4{r0, r1, r2, 0.0f});
+        }
+      }
+    }
+  };
+  if (has_noise) { if (sb) epi_items(TrueT{}, TrueT{}); else epi_items(TrueT{}, FalseT{}); }
+  else { if (sb) epi_items(FalseT{}, TrueT{}); else epi_items(FalseT{}, FalseT{}); }
+  if constexpr (TORGB) {
+    __syncthreads();
+    const int m = (tide >> 1) & (MT - 1), hsel = tide & 1;
+    f4 sum = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int q = 0; q < QN / 2; ++q) sum += ld4(g_s + m * GS + (hsel * (QN / 2) + q) * 4);
+    sum.x += MIGAN_SWIZZLE_XOR(sum.x, 1);
+    sum.y += MIGAN_SWIZZLE_XOR(sum.y, 1);
+    sum.z += MIGAN_SWIZZLE_XOR(sum.z, 1);
+    if (rgb_ok) {
+      const float rgb[3] = {sum.x + p.trgb_b[0], sum.y + p.trgb_b[1], sum.z + p.trgb_b[2]};
+      const size_t plane = (size_t)p.HO * p.WO;
+#pragma unroll
+      for (int ch = 0; ch < 3; ++ch)
+        p.img_out[((size_t)b0 * 3 + ch) * plane + (size_t)rgb_oy * p.WO + rgb_ox] = up_combine(pv[ch], rgb_oy, rgb_ox, p.HO >> 1, p.WO >> 1) + rgb[ch];
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // First half of a down=2 SeparableConv2d (reference :155-160): depthwise 3x3 + bias, lrelu_agc, then
 // Downsample2d (4x4 FIR [1,3,3,1]x[1,3,3,1]/64, stride 2, zero pad 1; reference :58-76).  Writes the
 // half-resolution NHWC tensor the pointwise GEMM (sepconv_kernel<MODE_PW>) consumes.

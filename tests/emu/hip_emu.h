@@ -4,7 +4,7 @@
 // (mi-gan_amd/csrc/migan_kernels.hpp) and the same host plan / C ABI (migan_host.hpp) without a GPU,
 // to check tile indexing, LDS carving, barrier placement and the MFMA fragment mapping.
 //
-// Model: one workgroup = 256 lanes, each lane a user-level fiber (hand-rolled x86-64 context switch)
+// Model: one workgroup = 64..512 lanes (whole waves), each lane a user-level fiber (hand-rolled x86-64 context switch)
 // on ONE OS thread; lanes run to the next collective (__syncthreads, MFMA, shuffle) and then yield
 // round-robin.  Lane 0 therefore runs arbitrarily far ahead of lane 255 between barriers, which is
 // the most adversarial legal schedule: a missing barrier shows up as a wrong result.  LDS is filled
@@ -40,7 +40,7 @@ struct Lane {
   bool done = false;
 };
 
-constexpr int kMaxLanes = 256;
+constexpr int kMaxLanes = 512;
 constexpr int kMaxWaves = kMaxLanes / 64;
 constexpr size_t kStackBytes = 96 * 1024;
 
@@ -275,7 +275,7 @@ struct Thunk {
 
 template <class Args>
 inline int launch(void (*kernel)(const Args), const Args& a, unsigned grid, unsigned block, size_t lds, stream_t) {
-  if (block != 256 || lds > 160 * 1024) return 1;
+  if (block == 0 || block % 64 != 0 || block > (unsigned)hipemu::kMaxLanes || lds > 160 * 1024) return 1;
   Thunk<Args> t{kernel, &a};
   hipemu::run_grid(&Thunk<Args>::call, &t, grid, block, lds);
   return 0;

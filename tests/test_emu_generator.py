@@ -86,7 +86,7 @@ def test_launch_plan_matches_the_survey_accounting(pkg, lib):
     """Per-image algorithmic work the roofline is computed from."""
     h512 = pkg.hipbind.MiganHandle(lib, 512)
     L = h512.launches()
-    seps = [l for l in L if "sepconv_kernel" in l["kernel"]]
+    seps = [l for l in L if "sepconv_kernel" in l["kernel"] or "sepconv_wide_kernel" in l["kernel"]]
     assert len(seps) == 32                                        # 32 SeparableConv2d @512
     assert len([l for l in L if "dwfir_kernel" in l["kernel"]]) == 7   # one per down=2 layer
     assert abs(sum(l["mfma_flops"] for l in L) / 1e9 - 26.49) < 0.02   # 1x1 convs: 26.49 GFLOP

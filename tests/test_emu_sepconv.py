@@ -64,8 +64,10 @@ def _run(lib, pkg, *, cin, cout, res_in, batch, down=1, up=1, noise=False, skip=
 @pytest.mark.parametrize("cin,cout,res,batch,noise,skip", [
     (64, 64, 16, 1, False, False),     # NT=64, one n-chunk, 2 tiles
     (32, 128, 16, 2, True, True),      # NT=128, single K chunk
-    (64, 256, 32, 1, True, False),     # two n-chunks, 8 tiles (XCD remap over 16 workgroups)
-    (96, 512, 16, 3, True, True),      # four n-chunks, 3 K chunks, skip
+    (64, 256, 32, 1, True, False),     # wide kernel (8 waves, 128 x 256 tile), 2 K chunks, 8 tiles
+    (96, 512, 16, 3, True, True),      # wide kernel, two n-chunks, 3 K chunks, skip, ragged XCD split
+    (32, 256, 16, 2, False, True),     # wide kernel, a single K chunk
+    (160, 256, 16, 1, True, False),    # wide kernel, 5 K chunks (odd count)
     (64, 384, 16, 1, False, False),    # 3 n-chunks of 128 (Cout not a multiple of 256)
     (64, 64, 8, 3, False, True),       # 2 images per tile, ragged batch
     (64, 128, 4, 3, True, False),      # 8 images per tile, ragged batch

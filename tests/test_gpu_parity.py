@@ -83,6 +83,8 @@ def _sep(pkg, dev, *, cin, cout, res_in, batch, down=1, up=1, noise=False, skip=
     dict(cin=32, cout=128, res_in=16, batch=2, noise=True, skip=True),
     dict(cin=64, cout=256, res_in=32, batch=1, noise=True),
     dict(cin=96, cout=512, res_in=16, batch=3, noise=True, skip=True),
+    dict(cin=32, cout=256, res_in=16, batch=2, skip=True),
+    dict(cin=160, cout=256, res_in=64, batch=1, noise=True),
     dict(cin=64, cout=64, res_in=8, batch=3, skip=True),
     dict(cin=64, cout=128, res_in=4, batch=3, noise=True),
     dict(cin=32, cout=64, res_in=32, batch=1, down=2),
