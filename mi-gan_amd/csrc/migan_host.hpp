@@ -716,6 +716,7 @@ inline void migan_handle::forward(const float* x, float* y, int batch, void* ws,
       sa.src[sa.n] = wptr(L.w_pw);
       sa.dst_off[sa.n] = L.wsplit_off;
       sa.count[sa.n] = (unsigned)(L.cin * L.cout);
+      sa.ci[sa.n] = (unsigned)L.cin;
       ++sa.n;
     }
     launch_split(sa, stream);
@@ -993,7 +994,7 @@ int migan_sepconv_forward(const migan_sepconv_desc* d, void* stream) {
     SplitArgs sa{};
     sa.dst = (unsigned short*)d->wsplit;
     sa.f16 = gemmv == 2;
-    sa.src[0] = (const float*)d->conv2_weight; sa.dst_off[0] = kSplitHeader; sa.count[0] = (unsigned)(d->cin * d->cout); sa.n = 1;
+    sa.src[0] = (const float*)d->conv2_weight; sa.dst_off[0] = kSplitHeader; sa.count[0] = (unsigned)(d->cin * d->cout); sa.ci[0] = (unsigned)d->cin; sa.n = 1;
     launch_split(sa, (rt::stream_t)stream);
   }
   MIGAN_CHECK(d->torgb_weight == nullptr || (g.nchunks == 1 && mode != MODE_UP && d->img_out), MIGAN_EINVAL,

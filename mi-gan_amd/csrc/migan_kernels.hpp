@@ -49,7 +49,7 @@ struct SepArgs {
   const float* wdw;            // conv1.weight [CI][1][3][3]
   const float* bdw;            // conv1.bias   [CI]
   const float* wpw;            // conv2.weight [CO][CI][1][1]
-  const unsigned short* wsplit;// GEMMV 1: conv2.weight as three bf16 planes [3][CO][CI] (split_weights_kernel), else null
+  const unsigned short* wsplit;// GEMMV 1/2: conv2.weight as 16-bit planes, chunk-major [planes][CI/32][CO][32] (split_weights_kernel), else null
   const float* noise;          // noise_const [HO][WO] or null
   const float* noise_strength; // scalar
   // EncoderBlock.fromrgb (reference :186,:194-195), only for FROMRGB instantiations
@@ -212,11 +212,13 @@ MIGAN_DEVICE MIGAN_INLINE float up_combine(const float (&t)[4], int oy, int ox, 
 #ifdef MIGAN_PHASE_PROF
 #define PROF_BEGIN() long long prof_t = (long long)MIGAN_CLOCK(); long long prof_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
 #define PROF_MARK(i) do { const long long n_ = (long long)MIGAN_CLOCK(); prof_acc[i] += n_ - prof_t; prof_t = n_; } while (0)
+#define PROF_END_WIDE() do { if (p.prof && (tid == 0 || tid == 256)) { for (int i_ = 0; i_ < 8; ++i_) MIGAN_ATOMIC_ADD_U64(p.prof + i_, (unsigned long long)prof_acc[i_]); if (tid == 0) MIGAN_ATOMIC_ADD_U64(p.prof + 8, 1ull); } } while (0)
 #define PROF_END() do { if (p.prof && tid == 0) { for (int i_ = 0; i_ < 8; ++i_) MIGAN_ATOMIC_ADD_U64(p.prof + i_, (unsigned long long)prof_acc[i_]); MIGAN_ATOMIC_ADD_U64(p.prof + 8, 1ull); } } while (0)
 #else
 #define PROF_BEGIN() do {} while (0)
 #define PROF_MARK(i) do {} while (0)
 #define PROF_END() do {} while (0)
+#define PROF_END_WIDE() do {} while (0)
 #endif
 
 // ------------------------------------------------------------------------------------------------
@@ -386,9 +388,10 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, MINW) sepconv_kernel(const SepArgs p)
     for (int j = 0; j < NB; ++j) {
       const int i = tid + j * kThreads;
       if constexpr (BF) {
-        // item = (plane, row n, 16-byte slot of 8 pieces); offset in 16-bit elements inside [NPL][CO][CI]
+        // item = (plane, row n, 16-byte slot of 8 pieces); offset in 16-bit elements inside one K chunk of the
+        // chunk-major planes [NPL][CI/KC][CO][KC] (a workgroup's weight tile of a chunk is one contiguous run)
         const int plane = i / (NT * NSLOT), rem = i % (NT * NSLOT);
-        boff_[j] = (unsigned)(((plane * p.CO + n0_ + rem / NSLOT) * p.CI) + (rem % NSLOT) * 8);
+        boff_[j] = (unsigned)(plane * p.CO * p.CI + (n0_ + rem / NSLOT) * KC + (rem % NSLOT) * 8);
       } else {
         boff_[j] = (unsigned)((n0_ + (i >> LG_QC)) * p.CI + (i & (QC - 1)) * 4);
       }
@@ -433,7 +436,7 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, MINW) sepconv_kernel(const SepArgs p)
       }
     }
     if constexpr (BF) {
-      const unsigned short* __restrict__ wk = p.wsplit + k0;
+      const unsigned short* __restrict__ wk = p.wsplit + (size_t)k0 * p.CO;       // chunk k0/KC starts at (k0/KC) * CO * KC
 #pragma unroll
       for (int j = 0; j < NB; ++j) rb[j] = ld4(reinterpret_cast<const float*>(wk + boff_[j]));
     } else {
@@ -978,6 +981,9 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(kWideThreads, 2) sepconv_wide_kernel(const
   const int wm = wave / WN, wn = wave % WN;
   const int l31 = lane & 31, half = lane >> 5;
   const bool groupA = tid < 256;
+  PROF_BEGIN();
+  const int pslot = groupA ? 0 : 4;   // phase profile (debug builds): A waves -> slots 0..3, B waves -> 4..7 [stores+load waits, depthwise, MFMA, barrier]
+  (void)pslot;
 
   // tile schedule: same XCD-contiguous order as sepconv_kernel, one tile per workgroup
   const int ntiles = p.tiles_x * p.tiles_y * p.nchunks * p.B;
@@ -1013,7 +1019,7 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(kWideThreads, 2) sepconv_wide_kernel(const
   for (int j = 0; j < NB; ++j) {
     const int i = tid + j * kWideThreads;
     const int plane = i / (NT * NSLOT), rem = i % (NT * NSLOT);
-    boff[j] = (unsigned)(((plane * p.CO + n0 + rem / NSLOT) * p.CI) + (rem % NSLOT) * 8);
+    boff[j] = (unsigned)(plane * p.CO * p.CI + (n0 + rem / NSLOT) * KC + (rem % NSLOT) * 8);
   }
   const float* __restrict__ xb = gx_ + (size_t)b0 * p.H * p.W * p.CI;
   f4 rin[NI], rb[NB], rw;
@@ -1024,7 +1030,7 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(kWideThreads, 2) sepconv_wide_kernel(const
     else if (tid < NW4) rw = ld4(p.bdw + k0 + (unsigned)((tid - KC * 9 / 4) * 4));
   };
   auto load_b = [&](int k0) {                      // fp16 planes of the 1x1 weights of one chunk
-    const unsigned short* __restrict__ wk = p.wsplit + k0;
+    const unsigned short* __restrict__ wk = p.wsplit + (size_t)k0 * p.CO;
 #pragma unroll
     for (int j = 0; j < NB; ++j) rb[j] = ld4(reinterpret_cast<const float*>(wk + boff[j]));
   };
@@ -1072,17 +1078,26 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(kWideThreads, 2) sepconv_wide_kernel(const
     for (int tap = 0; tap < 9; ++tap) w[tap] = ld4(w_s + tap * KC + c4 * 4);
     const f4 bias = ld4(w_s + KC * 9 + c4 * 4);
     const float* ip = in_s + (r0 * IGW + gx) * KC + c4 * 4;
-    f4 win[3][3];
+    // The input row an output needs last is read one output ahead (`nxt`) and pinned there: its LDS latency
+    // runs under the previous output's 18 packed FMAs + activation + split (these waves are alone in this
+    // stage: nothing else would hide it).
+    f4 win[3][3], nxt[3];
 #pragma unroll
     for (int rr = 0; rr < 2; ++rr) {
       win[rr][0] = ld4(ip); win[rr][1] = ld4(ip + KC); win[rr][2] = ld4(ip + 2 * KC);
       ip += IGW * KC;
     }
+    nxt[0] = ld4(ip); nxt[1] = ld4(ip + KC); nxt[2] = ld4(ip + 2 * KC);
+    ip += IGW * KC;
 #pragma unroll
     for (int o = 0; o < SEGH; ++o) {
       const int nr = (o + 2) % 3;
-      win[nr][0] = ld4(ip); win[nr][1] = ld4(ip + KC); win[nr][2] = ld4(ip + 2 * KC);
-      ip += IGW * KC;
+      win[nr][0] = nxt[0]; win[nr][1] = nxt[1]; win[nr][2] = nxt[2];
+      if (o + 1 < SEGH) {
+        nxt[0] = ld4(ip); nxt[1] = ld4(ip + KC); nxt[2] = ld4(ip + 2 * KC);
+        ip += IGW * KC;
+      }
+      MIGAN_SCHED_FENCE();
       f4 sacc = bias;
 #pragma unroll
       for (int ky = 0; ky < 3; ++ky)
@@ -1156,10 +1171,15 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(kWideThreads, 2) sepconv_wide_kernel(const
       load_b((c + 2) * KC);
     }
     if (c + 3 < nkc) load_in((c + 3) * KC);
+    PROF_MARK(pslot + 0);
     if (groupA && c + 1 < nkc) depthwise((c + 1) & 1, (c + 1) & 1);   // a_s[(c+1)&1] last read by the MFMAs of chunk c-1
+    PROF_MARK(pslot + 1);
     mfma_chunk(c & 1);
+    PROF_MARK(pslot + 2);
     __syncthreads();
+    PROF_MARK(pslot + 3);
   }
+  PROF_END_WIDE();
 
   // ======================================= epilogue ========================================
   int tide = tid;
@@ -1438,6 +1458,7 @@ struct SplitArgs {
   const float* src[40];
   unsigned long long dst_off[40];   // element (16-bit) offset of plane 0 inside `dst`; a 16-byte header precedes it
   unsigned count[40];               // CO*CI
+  unsigned ci[40];                  // CI (the planes are written chunk-major: [plane][CI/32][CO][32])
   unsigned short* dst;
   int n;
   int f16;                          // 0: three bf16 planes; 1: two fp16 planes of the scaled weights
@@ -1476,18 +1497,23 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, 2) split_weights_kernel(const SplitAr
   const float* __restrict__ src = p.src[t];
   unsigned short* __restrict__ dst = p.dst + p.dst_off[t];
   const float sw = p.f16 ? reinterpret_cast<const float*>(dst - kSplitHeader)[2] : 1.0f;
+  const unsigned ci = p.ci[t], co = cnt / ci;
   for (unsigned i = (blk * kThreads + threadIdx.x) * 4; i < cnt; i += kSplitBlocksPerTensor * kThreads * 4) {
+    // source element (n, k) of [CO][CI] -> chunk-major position: the 32-channel K chunk of a row is 64 contiguous
+    // bytes and the rows of a chunk follow each other, so a workgroup's weight tile is one contiguous, fully used run
+    const unsigned n = i / ci, k = i % ci;
+    const unsigned o = (k >> 5) * (co * 32u) + n * 32u + (k & 31u);
     if (p.f16) {
       u2v h1, h2;
       split2_f16(ld4(src + i) * sw, h1, h2);
-      *reinterpret_cast<u2v*>(dst + i) = h1;
-      *reinterpret_cast<u2v*>(dst + cnt + i) = h2;
+      *reinterpret_cast<u2v*>(dst + o) = h1;
+      *reinterpret_cast<u2v*>(dst + cnt + o) = h2;
     } else {
       u2v h1, h2, h3;
       split3_bf16(ld4(src + i), h1, h2, h3);
-      *reinterpret_cast<u2v*>(dst + i) = h1;
-      *reinterpret_cast<u2v*>(dst + cnt + i) = h2;
-      *reinterpret_cast<u2v*>(dst + 2 * (size_t)cnt + i) = h3;
+      *reinterpret_cast<u2v*>(dst + o) = h1;
+      *reinterpret_cast<u2v*>(dst + cnt + o) = h2;
+      *reinterpret_cast<u2v*>(dst + 2 * (size_t)cnt + o) = h3;
     }
   }
 }

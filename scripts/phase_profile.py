@@ -36,5 +36,10 @@ for i, (L, t) in enumerate(zip(launches, ms)):
     if lib.migan_prof_layer(i, out) != 0:
         continue
     n = max(1, out[8])
+    if "wide" in L["kernel"]:
+        cyc = [out[k] / n for k in range(8)]
+        print(f"{L['layer']:26s} {t:8.3f} {out[8]:7d}  wide A[store/wait, depthwise, mfma, barrier] " + " ".join(f"{c:8.0f}" for c in cyc[:4])
+              + "   B: " + " ".join(f"{c:8.0f}" for c in cyc[4:]))
+        continue
     cyc = [out[k] / n for k in range(6)]
     print(f"{L['layer']:26s} {t:8.3f} {out[8]:7d} " + " ".join(f"{c:8.0f}" for c in cyc) + f"   {sum(cyc):9.0f}")
