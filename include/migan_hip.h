@@ -122,6 +122,18 @@ typedef struct migan_sepconv_desc {
 } migan_sepconv_desc;
 int migan_sepconv_forward(const migan_sepconv_desc* d, void* stream);
 
+/* ---- either side of the forward ---------------------------------- */
+
+/* preprocess() of reference scripts/demo.py:56-66 at network resolution: uint8 RGB image [batch][R][R][3]
+ * (HWC, np.array(PIL image)) and uint8 mask [batch][R][R] (255 = known pixel, everything else = hole,
+ * demo.py:44,60) -> x = cat([mask - 0.5, (img * 2 / 255 - 1) * mask]) as [batch][4][R][R] fp32, bit-exact.
+ * Pointers: uint8 tensors 4-byte aligned, fp32 tensors 16-byte aligned. */
+int migan_pack_input(const void* img_hwc_u8, const void* mask_u8, void* x_nchw, int batch, int resolution, void* stream);
+/* reference scripts/demo.py:135-140 at network resolution: (y * 0.5 + 0.5).clamp(0, 1) * 255 -> uint8,
+ * composed = img * mask + result * (1 - mask); y [batch][3][R][R] fp32 -> out [batch][R][R][3] uint8, bit-exact. */
+int migan_compose_output(const void* y_nchw, const void* img_hwc_u8, const void* mask_u8, void* out_hwc_u8,
+                         int batch, int resolution, void* stream);
+
 const char* migan_last_error(void);
 /* "hip:gfx950" for the product library. */
 const char* migan_backend(void);

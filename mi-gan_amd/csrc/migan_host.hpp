@@ -1013,6 +1013,35 @@ int migan_sepconv_forward(const migan_sepconv_desc* d, void* stream) {
   MIGAN_API_END
 }
 
+static int migan_prepost_launch(bool pack, const void* y, const void* img, const void* mask, void* x, void* out, int batch,
+                                int resolution, void* stream) {
+  MIGAN_API_BEGIN
+  using namespace migan;
+  MIGAN_CHECK(img && mask && (pack ? x != nullptr : (y != nullptr && out != nullptr)), MIGAN_EINVAL, "null tensor");
+  MIGAN_CHECK(batch > 0, MIGAN_EINVAL, "empty batch");
+  MIGAN_CHECK(resolution >= 8 && (resolution & (resolution - 1)) == 0, MIGAN_EINVAL, "resolution must be a power of two >= 8");
+  MIGAN_CHECK(((uintptr_t)img % 4) == 0 && ((uintptr_t)mask % 4) == 0 && (out == nullptr || ((uintptr_t)out % 4) == 0) &&
+              (x == nullptr || ((uintptr_t)x % 16) == 0) && (y == nullptr || ((uintptr_t)y % 16) == 0), MIGAN_EINVAL,
+              "pointers must be 4-byte (uint8 tensors) / 16-byte (fp32 tensors) aligned");
+  PrePostArgs a{};
+  a.img = (const unsigned char*)img; a.mask = (const unsigned char*)mask; a.y = (const float*)y; a.x = (float*)x; a.out = (unsigned char*)out;
+  a.plane = (unsigned)(resolution * resolution);
+  const size_t quads = (size_t)batch * a.plane / 4;
+  MIGAN_CHECK(quads < (1ull << 30), MIGAN_EINVAL, "batch too large for one launch");
+  a.nquads = (unsigned)quads;
+  const unsigned grid = (unsigned)((quads + kThreads - 1) / kThreads);
+  if (pack) rt_check(rt::launch(pack_input_kernel, a, grid, kThreads, 0, (rt::stream_t)stream), "migan::pack_input_kernel");
+  else rt_check(rt::launch(compose_output_kernel, a, grid, kThreads, 0, (rt::stream_t)stream), "migan::compose_output_kernel");
+  MIGAN_API_END
+}
+int migan_pack_input(const void* img_hwc_u8, const void* mask_u8, void* x_nchw, int batch, int resolution, void* stream) {
+  return migan_prepost_launch(true, nullptr, img_hwc_u8, mask_u8, x_nchw, nullptr, batch, resolution, stream);
+}
+int migan_compose_output(const void* y_nchw, const void* img_hwc_u8, const void* mask_u8, void* out_hwc_u8, int batch, int resolution,
+                         void* stream) {
+  return migan_prepost_launch(false, y_nchw, img_hwc_u8, mask_u8, nullptr, out_hwc_u8, batch, resolution, stream);
+}
+
 #ifdef MIGAN_PHASE_PROF
 // debug builds only: cumulative cycles of thread 0 per phase [prologue, S1, S2, MFMA, acc->LDS, epilogue, -, -, #workgroups]
 int migan_prof_read(unsigned long long out[16], int reset) {

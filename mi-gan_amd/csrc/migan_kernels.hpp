@@ -1559,4 +1559,85 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, 2) torgb_kernel(const RgbArgs p) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The steps either side of Generator.forward in the reference's scripts/demo.py, at network resolution
+// (SURVEY section 8f row N2): uint8 image + mask -> network input, network output -> composited uint8.
+// Pure HBM streaming kernels: one thread per 4 horizontally adjacent pixels (12 + 4 bytes in as four
+// 32-bit words, one float4 store per plane; resp. three float4 loads and 12 bytes out).
+struct PrePostArgs {
+  const unsigned char* img;    // [N][R][R][3] uint8, HWC (np.array(PIL RGB image))
+  const unsigned char* mask;   // [N][R][R] uint8, 255 = keep the pixel, anything else = hole (demo.py:44,60)
+  const float* y;              // compose: network output [N][3][R][R]
+  float* x;                    // pack: network input [N][4][R][R] = cat([mask - 0.5, img * mask]) (demo.py:65)
+  unsigned char* out;          // compose: [N][R][R][3] uint8
+  unsigned nquads;             // N * R * R / 4
+  unsigned plane;              // R * R
+};
+MIGAN_DEVICE MIGAN_INLINE float unit_image(unsigned b) {
+  // demo.py:61: torch.Tensor(img).float() * 2 / 255 - 1, three fp32 roundings in that order
+  float v = (float)b;
+  v = v * 2.0f;
+  v = v / 255.0f;
+  return v - 1.0f;
+}
+MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, 2) pack_input_kernel(const PrePostArgs p) {
+  const unsigned q = blockIdx.x * kThreads + threadIdx.x;
+  if (q >= p.nquads) return;
+  const unsigned pix = q * 4u;                       // first pixel of the quad (flat over N*R*R)
+  const unsigned n = pix / p.plane, r = pix % p.plane;
+  const unsigned* ip = reinterpret_cast<const unsigned*>(p.img + (size_t)pix * 3);
+  const unsigned w0 = ip[0], w1 = ip[1], w2 = ip[2];
+  const unsigned mw = *reinterpret_cast<const unsigned*>(p.mask + pix);
+  unsigned char rgb[12];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { rgb[i] = (unsigned char)(w0 >> (8 * i)); rgb[4 + i] = (unsigned char)(w1 >> (8 * i)); rgb[8 + i] = (unsigned char)(w2 >> (8 * i)); }
+  f4 m, c0, c1, c2;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float mk = (((mw >> (8 * i)) & 0xffu) == 255u) ? 1.0f : 0.0f;     // demo.py:60: np.array(mask) // 255
+    m[i] = mk;
+    c0[i] = unit_image(rgb[3 * i + 0]) * mk;                                 // demo.py:65: img * mask
+    c1[i] = unit_image(rgb[3 * i + 1]) * mk;
+    c2[i] = unit_image(rgb[3 * i + 2]) * mk;
+  }
+  float* xb = p.x + (size_t)n * 4 * p.plane + r;
+  st4(xb, m - 0.5f);                                                         // demo.py:65: mask - 0.5
+  st4(xb + p.plane, c0);
+  st4(xb + 2 * (size_t)p.plane, c1);
+  st4(xb + 3 * (size_t)p.plane, c2);
+}
+MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, 2) compose_output_kernel(const PrePostArgs p) {
+  const unsigned q = blockIdx.x * kThreads + threadIdx.x;
+  if (q >= p.nquads) return;
+  const unsigned pix = q * 4u;
+  const unsigned n = pix / p.plane, r = pix % p.plane;
+  const float* yb = p.y + (size_t)n * 3 * p.plane + r;
+  const f4 y0 = ld4(yb), y1 = ld4(yb + p.plane), y2 = ld4(yb + 2 * (size_t)p.plane);
+  const unsigned* ip = reinterpret_cast<const unsigned*>(p.img + (size_t)pix * 3);
+  const unsigned w0 = ip[0], w1 = ip[1], w2 = ip[2];
+  const unsigned mw = *reinterpret_cast<const unsigned*>(p.mask + pix);
+  unsigned char rgb[12], o[12];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { rgb[i] = (unsigned char)(w0 >> (8 * i)); rgb[4 + i] = (unsigned char)(w1 >> (8 * i)); rgb[8 + i] = (unsigned char)(w2 >> (8 * i)); }
+  auto to_u8 = [](float v) {
+    // demo.py:135-136: (y * 0.5 + 0.5).clamp(0, 1) * 255 -> .to(torch.uint8) (truncation)
+    float t = v * 0.5f + 0.5f;                       // y * 0.5 is exact, so a contracted FMA rounds identically
+    t = fminf(fmaxf(t, 0.0f), 1.0f);
+    return (unsigned char)(int)(t * 255.0f);
+  };
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const bool keep = ((mw >> (8 * i)) & 0xffu) == 255u;
+    // demo.py:139-140: img * mask + result * (1 - mask) with mask in {0, 1}
+    o[3 * i + 0] = keep ? rgb[3 * i + 0] : to_u8(y0[i]);
+    o[3 * i + 1] = keep ? rgb[3 * i + 1] : to_u8(y1[i]);
+    o[3 * i + 2] = keep ? rgb[3 * i + 2] : to_u8(y2[i]);
+  }
+  unsigned* op = reinterpret_cast<unsigned*>(p.out + (size_t)pix * 3);
+#pragma unroll
+  for (int wd = 0; wd < 3; ++wd)
+    op[wd] = (unsigned)o[4 * wd] | ((unsigned)o[4 * wd + 1] << 8) | ((unsigned)o[4 * wd + 2] << 16) | ((unsigned)o[4 * wd + 3] << 24);
+}
+
+
 }  // namespace migan

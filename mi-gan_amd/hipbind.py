@@ -41,6 +41,7 @@ EXPORTS = (
     "migan_create", "migan_destroy", "migan_num_weights", "migan_weight_info", "migan_set_weight",
     "migan_commit", "migan_workspace_bytes", "migan_forward", "migan_num_launches", "migan_launch_info",
     "migan_forward_timed", "migan_set_debug", "migan_debug_tensor", "migan_sepconv_forward",
+    "migan_pack_input", "migan_compose_output",
     "migan_last_error", "migan_backend", "migan_gemm_variant", "migan_version",
 )
 
@@ -79,6 +80,8 @@ class MiganLib:
         L.migan_set_debug.argtypes = [vp, ci]
         L.migan_debug_tensor.argtypes = [vp, ci, C.c_char_p, C.POINTER(C.c_size_t), C.POINTER(C.c_int64)]
         L.migan_sepconv_forward.argtypes = [C.POINTER(SepConvDesc), vp]
+        L.migan_pack_input.argtypes = [vp, vp, vp, ci, ci, vp]
+        L.migan_compose_output.argtypes = [vp, vp, vp, vp, ci, ci, vp]
         L.migan_last_error.restype = C.c_char_p
         L.migan_backend.restype = C.c_char_p
         L.migan_gemm_variant.restype = C.c_char_p
@@ -104,6 +107,15 @@ class MiganLib:
 
     def gemm_variant(self) -> str:
         return self.lib.migan_gemm_variant().decode()
+
+    def pack_input(self, img_ptr: int, mask_ptr: int, x_ptr: int, batch: int, resolution: int, stream: int = 0) -> None:
+        self.check(self.lib.migan_pack_input(C.c_void_p(img_ptr), C.c_void_p(mask_ptr), C.c_void_p(x_ptr), int(batch),
+                                             int(resolution), C.c_void_p(stream)))
+
+    def compose_output(self, y_ptr: int, img_ptr: int, mask_ptr: int, out_ptr: int, batch: int, resolution: int,
+                       stream: int = 0) -> None:
+        self.check(self.lib.migan_compose_output(C.c_void_p(y_ptr), C.c_void_p(img_ptr), C.c_void_p(mask_ptr),
+                                                 C.c_void_p(out_ptr), int(batch), int(resolution), C.c_void_p(stream)))
 
     def sepconv_forward(self, stream: int = 0, **kw) -> None:
         d = SepConvDesc()
