@@ -63,6 +63,7 @@ def _run(lib, pkg, *, cin, cout, res_in, batch, down=1, up=1, noise=False, skip=
 
 @pytest.mark.parametrize("cin,cout,res,batch,noise,skip", [
     (64, 64, 16, 1, False, False),     # NT=64, one n-chunk, 2 tiles
+    (64, 64, 32, 3, True, True),       # NT=64, 24 tiles: under the persistent re-run 3 tiles per workgroup, resident weight tiles
     (32, 128, 16, 2, True, True),      # NT=128, single K chunk
     (64, 256, 32, 1, True, False),     # wide kernel (8 waves, 128 x 256 tile), 2 K chunks, 8 tiles
     (96, 512, 16, 3, True, True),      # wide kernel, two n-chunks, 3 K chunks, skip, ragged XCD split
@@ -88,6 +89,7 @@ def test_down(lib, pkg, cin, cout, res_in, batch):
 
 @pytest.mark.parametrize("cin,cout,res_in,batch,noise,skip", [
     (64, 64, 16, 1, True, True),      # out 32: 3x2 ragged tiles
+    (128, 64, 16, 2, True, True),     # 4 K chunks, 12 tiles: persistent re-run keeps all four weight tiles resident
     (32, 128, 32, 1, False, False),   # out 64: 6x3 tiles
     (64, 64, 8, 2, True, False),      # out 16: 2x1 tiles
     (32, 128, 4, 3, True, True),      # out 8: 2 images per tile, ragged batch
@@ -96,9 +98,9 @@ def test_up(lib, pkg, cin, cout, res_in, batch, noise, skip):
     _run(lib, pkg, cin=cin, cout=cout, res_in=res_in, batch=batch, up=2, noise=noise, skip=skip)
 
 
-def test_fromrgb_fused(lib, pkg):
+@pytest.mark.parametrize("res,batch", [(16, 2), (32, 3)])     # (32, 3): 24 tiles, several per workgroup in the persistent re-run
+def test_fromrgb_fused(lib, pkg, res, batch):
     cin = cout = 64
-    res, batch = 16, 2
     sd = _weights(pkg, cin, cout, 7, res, False)
     fw = (pkg.synth.normal((cin, 4, 1, 1), 7, "fw") * 0.7).astype(np.float32)
     fb = (pkg.synth.normal((cin,), 7, "fb") * 0.3).astype(np.float32)
@@ -108,8 +110,9 @@ def test_fromrgb_fused(lib, pkg):
     x = aligned(img)                                                   # NCHW network input
     y = aligned(np.full((batch, res, res, cout), np.nan, dtype=np.float32))
     arrs = [aligned(a) for a in (sd["m.conv1.weight"], sd["m.conv1.bias"], sd["m.conv2.weight"], fw, fb)]
+    wsp = aligned(np.full((3 * cin * cout + 1) // 2 + 8, np.nan, dtype=np.float32))
     lib.sepconv_forward(x=ptr(x), y=ptr(y), conv1_weight=ptr(arrs[0]), conv1_bias=ptr(arrs[1]), conv2_weight=ptr(arrs[2]),
-                        fromrgb_weight=ptr(arrs[3]), fromrgb_bias=ptr(arrs[4]),
+                        fromrgb_weight=ptr(arrs[3]), fromrgb_bias=ptr(arrs[4]), wsplit=ptr(wsp), wsplit_bytes=wsp.nbytes,
                         batch=batch, cin=cin, cout=cout, res_in=res)
     np.testing.assert_allclose(nchw(y), want, rtol=0, atol=2e-5 * max(1.0, float(np.abs(want).max())))
 
