@@ -44,6 +44,8 @@ __device__ __forceinline__ float migan_swizzle_xor(float v) {
 }
 #define MIGAN_SWIZZLE_XOR(v, m) migan_swizzle_xor<(m)>(v)
 #define MIGAN_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#define MIGAN_STORE_NT(ptr, v) __builtin_nontemporal_store((v), (ptr))
+#define MIGAN_LOAD_NT(ptr) __builtin_nontemporal_load(ptr)
 #define MIGAN_OPAQUE(x) asm volatile("" : "+v"(x))
 #define MIGAN_CLOCK() __builtin_readcyclecounter()
 #define MIGAN_ATOMIC_ADD_U64(p, v) atomicAdd((p), (v))
