@@ -9,8 +9,8 @@ The directory name contains a dash, so import it with
 ``importlib.import_module("mi-gan_amd")`` or through the ``migan_amd`` alias
 module at the repository root.
 """
-from . import distributed, hipbind, pipeline, schema, synth  # noqa: F401
+from . import convert, distributed, hipbind, pipeline, schema, synth  # noqa: F401
 from .migan_inference import Generator  # noqa: F401
 from .hipbind import MiganLib, MiganError, load_library, library_path  # noqa: F401
 
-__all__ = ["Generator", "MiganLib", "MiganError", "load_library", "library_path", "schema", "synth", "pipeline"]
+__all__ = ["Generator", "MiganLib", "MiganError", "load_library", "library_path", "schema", "synth", "pipeline", "convert"]
