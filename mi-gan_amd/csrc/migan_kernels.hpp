@@ -162,6 +162,14 @@ MIGAN_DEVICE MIGAN_INLINE void st4(float* p, f4 v) { *reinterpret_cast<f4*>(p) =
 // (nontemporal: measured +1.5 % end to end, profiles/)
 MIGAN_DEVICE MIGAN_INLINE void st4o(float* p, f4 v) { MIGAN_STORE_NT(reinterpret_cast<f4*>(p), v); }
 // load of a tensor that is read exactly once (the skip connection in the epilogue)
+// uniform base pointer (SGPR pair) + 32-bit lane BYTE offset: the form the global_load/store saddr + voffset
+// encoding takes directly, so no 64-bit VALU address add per access
+MIGAN_DEVICE MIGAN_INLINE float* at_bytes(float* base, unsigned byte_off) {
+  return reinterpret_cast<float*>(reinterpret_cast<char*>(base) + byte_off);
+}
+MIGAN_DEVICE MIGAN_INLINE const float* at_bytes(const float* base, unsigned byte_off) {
+  return reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + byte_off);
+}
 MIGAN_DEVICE MIGAN_INLINE f4 ld4once(const float* p) { return MIGAN_LOAD_NT(reinterpret_cast<const f4*>(p)); }
 
 // XCD-aware workgroup order (MI355X: block b runs on XCD b%8, each XCD has a private 4 MiB L2):
@@ -359,7 +367,7 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, MINW) sepconv_kernel(const SepArgs p)
 
   // per-thread descriptors of its input items (constant across the K chunks of a tile).  Item
   // i = tid + j*256 is float4 number i of the LDS tile ([pixel][KC/4]); goff = element offset of
-  // its source inside image group b0 (0 when the pixel is padding: loaded anyway, zeroed on the way
+  // its source (in BYTES) inside image group b0 (0 when the pixel is padding: loaded anyway, zeroed on the way
   // to LDS, which is the conv zero padding of reference :126); bit j of `vmask` = real pixel, of
   // `emask` = item exists.
   unsigned emask = 0;
@@ -381,7 +389,7 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, MINW) sepconv_kernel(const SepArgs p)
         const int yy = gy0_ - HALO + iy, xx = gx0_ - HALO + ix;
         if (yy >= 0 && yy < p.H && xx >= 0 && xx < p.W && (b0_ + img) < p.B) {
           vmask_ |= 1u << j;
-          g = FROMRGB ? 0u : (unsigned)(((img * p.H + yy) * p.W + xx) * p.CI + c4 * 4);
+          g = FROMRGB ? 0u : (unsigned)(((img * p.H + yy) * p.W + xx) * p.CI + c4 * 4) * 4u;     // bytes
         }
       }
       goff_[j] = g;
@@ -396,9 +404,9 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, MINW) sepconv_kernel(const SepArgs p)
         // item = (plane, row n, 16-byte slot of 8 pieces); offset in 16-bit elements inside one K chunk of the
         // chunk-major planes [NPL][CI/KC][CO][KC] (a workgroup's weight tile of a chunk is one contiguous run)
         const int plane = i / (NT * NSLOT), rem = i % (NT * NSLOT);
-        boff_[j] = (unsigned)(plane * p.CO * p.CI + (n0_ + rem / NSLOT) * KC + (rem % NSLOT) * 8);
+        boff_[j] = (unsigned)(plane * p.CO * p.CI + (n0_ + rem / NSLOT) * KC + (rem % NSLOT) * 8) * 2u;    // bytes
       } else {
-        boff_[j] = (unsigned)((n0_ + (i >> LG_QC)) * p.CI + (i & (QC - 1)) * 4);
+        boff_[j] = (unsigned)((n0_ + (i >> LG_QC)) * p.CI + (i & (QC - 1)) * 4) * 4u;                      // bytes
       }
     }
   };
@@ -437,17 +445,17 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, MINW) sepconv_kernel(const SepArgs p)
         for (int j = 0; j < NI; ++j) rin[j] = f4{0.5f, 0.25f, -0.5f, 1.0f};
       } else {
 #pragma unroll
-        for (int j = 0; j < NI; ++j) rin[j] = ld4(xk + goff_[j]);
+        for (int j = 0; j < NI; ++j) rin[j] = ld4(at_bytes(xk, goff_[j]));
       }
     }
     if constexpr (BF) {
       const unsigned short* __restrict__ wk = p.wsplit + (size_t)k0 * p.CO;       // chunk k0/KC starts at (k0/KC) * CO * KC
 #pragma unroll
-      for (int j = 0; j < NB; ++j) rb[j] = ld4(reinterpret_cast<const float*>(wk + boff_[j]));
+      for (int j = 0; j < NB; ++j) rb[j] = ld4(at_bytes(reinterpret_cast<const float*>(wk), boff_[j]));
     } else {
       const float* __restrict__ wk = gwpw + k0;
 #pragma unroll
-      for (int j = 0; j < NB; ++j) rb[j] = ld4(wk + boff_[j]);
+      for (int j = 0; j < NB; ++j) rb[j] = ld4(at_bytes(wk, boff_[j]));
     }
     // depthwise taps of channels [k0,k0+KC) are KC*9 contiguous floats of conv1.weight, then the bias
     if constexpr (MODE != MODE_PW) {
@@ -782,7 +790,7 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, MINW) sepconv_kernel(const SepArgs p)
     for (int it0 = 0; it0 < ITEMS; it0 += UB) {
       f4 val[UB], sk[UB];
       float nz[UB];
-      unsigned loff[UB];     // lane part of the element offset
+      unsigned loff[UB];     // lane part of the offset, in BYTES
       int upix[UB];          // uniform part, in pixels
       bool ok[UB];
 #pragma unroll
@@ -792,18 +800,18 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, MINW) sepconv_kernel(const SepArgs p)
         val[u] = ld4(g_s + m * GS + c4 * 4);
         if constexpr (MAINGEO) {
           upix[u] = (dm >> lgGW) * p.WO + (dm & (GW - 1));
-          loff[u] = off_t;
+          loff[u] = off_t * 4u;
           ok[u] = true;
-          if constexpr (HN) nz[u] = (gnoise + upix[u])[pix_t];
+          if constexpr (HN) nz[u] = *at_bytes(gnoise + upix[u], pix_t * 4u);
         } else {
           const int gx = m & (GW - 1), gy = (m >> lgGW) & (GH - 1), img = m >> (lgGW + lgGH);
           ok[u] = (b0 + img) < p.B;
           const unsigned pix = (unsigned)((gy0 + gy) * p.WO + gx0 + gx);
           upix[u] = 0;
-          loff[u] = (unsigned)(ok[u] ? img : 0) * (unsigned)img_elems + pix * (unsigned)p.CO + (unsigned)(n0 + c4 * 4);
+          loff[u] = ((unsigned)(ok[u] ? img : 0) * (unsigned)img_elems + pix * (unsigned)p.CO + (unsigned)(n0 + c4 * 4)) * 4u;
           if constexpr (HN) nz[u] = gnoise[pix];
         }
-        if constexpr (HS) sk[u] = ld4once(sb + (size_t)upix[u] * p.CO + loff[u]);
+        if constexpr (HS) sk[u] = ld4once(at_bytes(sb + (size_t)upix[u] * p.CO, loff[u]));
       }
 #pragma unroll
       for (int u = 0; u < UB; ++u) {
@@ -817,7 +825,7 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, MINW) sepconv_kernel(const SepArgs p)
         }
         f4 outv = v;
         if constexpr (HS) outv = v + sk[u];
-        if (ok[u] && !MIGAN_ABL(1)) st4o(yb + (size_t)upix[u] * p.CO + loff[u], outv);
+        if (ok[u] && !MIGAN_ABL(1)) st4o(at_bytes(yb + (size_t)upix[u] * p.CO, loff[u]), outv);
         if constexpr (do_rgb) {
           // ToRGB (reference :312): this lane's share of the 3 dot products over the CO channels of the pixel
           // goes into the g_s slot the item just consumed; the per-pixel sums are formed in the tail pass below.
@@ -1015,7 +1023,7 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(kWideThreads, 2) sepconv_wide_kernel(const
       const int yy = gy0 - 1 + iy, xx = gx0 - 1 + ix;
       if (yy >= 0 && yy < p.H && xx >= 0 && xx < p.W) {
         vmask |= 1u << j;
-        g = (unsigned)((yy * p.W + xx) * p.CI + c4 * 4);
+        g = (unsigned)((yy * p.W + xx) * p.CI + c4 * 4) * 4u;      // bytes
       }
     }
     goff[j] = g;
@@ -1024,20 +1032,20 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(kWideThreads, 2) sepconv_wide_kernel(const
   for (int j = 0; j < NB; ++j) {
     const int i = tid + j * kWideThreads;
     const int plane = i / (NT * NSLOT), rem = i % (NT * NSLOT);
-    boff[j] = (unsigned)(plane * p.CO * p.CI + (n0 + rem / NSLOT) * KC + (rem % NSLOT) * 8);
+    boff[j] = (unsigned)(plane * p.CO * p.CI + (n0 + rem / NSLOT) * KC + (rem % NSLOT) * 8) * 2u;    // bytes
   }
   const float* __restrict__ xb = gx_ + (size_t)b0 * p.H * p.W * p.CI;
   f4 rin[NI], rb[NB], rw;
   auto load_in = [&](int k0) {                     // input tile + depthwise taps of one chunk
 #pragma unroll
-    for (int j = 0; j < NI; ++j) rin[j] = ld4(xb + k0 + goff[j]);
+    for (int j = 0; j < NI; ++j) rin[j] = ld4(at_bytes(xb + k0, goff[j]));
     if (tid < KC * 9 / 4) rw = ld4(p.wdw + (size_t)k0 * 9 + (unsigned)(tid * 4));
     else if (tid < NW4) rw = ld4(p.bdw + k0 + (unsigned)((tid - KC * 9 / 4) * 4));
   };
   auto load_b = [&](int k0) {                      // fp16 planes of the 1x1 weights of one chunk
     const unsigned short* __restrict__ wk = p.wsplit + (size_t)k0 * p.CO;
 #pragma unroll
-    for (int j = 0; j < NB; ++j) rb[j] = ld4(reinterpret_cast<const float*>(wk + boff[j]));
+    for (int j = 0; j < NB; ++j) rb[j] = ld4(at_bytes(reinterpret_cast<const float*>(wk), boff[j]));
   };
   auto store_in = [&](int buf) {
     float* in_s = smem + OFF_IN + buf * IN_SZ;
@@ -1235,7 +1243,7 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(kWideThreads, 2) sepconv_wide_kernel(const
     }
   }
   const unsigned pix_t = (unsigned)((gy0 + gyt) * p.WO + gx0 + gxt);
-  const unsigned off_t = pix_t * (unsigned)p.CO + (unsigned)(n0 + c4 * 4);
+  const unsigned off_t = (pix_t * (unsigned)p.CO + (unsigned)(n0 + c4 * 4)) * 4u;      // lane byte offset
   auto epi_items = [&](auto hn_, auto hs_) {
     constexpr bool HN = decltype(hn_)::value, HS = decltype(hs_)::value;
 #pragma unroll
@@ -1248,8 +1256,8 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(kWideThreads, 2) sepconv_wide_kernel(const
         const int dm = (it0 + u) * STEP;
         val[u] = ld4(g_s + (m0 + dm) * GS + c4 * 4);
         upix[u] = (dm >> lgGW) * p.WO + (dm & (GW - 1));
-        if constexpr (HN) nz[u] = (gnoise + upix[u])[pix_t];
-        if constexpr (HS) sk[u] = ld4(sb + (size_t)upix[u] * p.CO + off_t);
+        if constexpr (HN) nz[u] = *at_bytes(gnoise + upix[u], pix_t * 4u);
+        if constexpr (HS) sk[u] = ld4once(at_bytes(sb + (size_t)upix[u] * p.CO, off_t));
       }
 #pragma unroll
       for (int u = 0; u < UB; ++u) {
@@ -1262,7 +1270,7 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(kWideThreads, 2) sepconv_wide_kernel(const
         }
         f4 outv = v;
         if constexpr (HS) outv = v + sk[u];
-        st4o(yb + (size_t)upix[u] * p.CO + off_t, outv);
+        st4o(at_bytes(yb + (size_t)upix[u] * p.CO, off_t), outv);
         if constexpr (TORGB) {
           const float r0 = v.x * tw0.x + v.y * tw0.y + v.z * tw0.z + v.w * tw0.w;
           const float r1 = v.x * tw1.x + v.y * tw1.y + v.z * tw1.z + v.w * tw1.w;
