@@ -52,3 +52,47 @@ def sharded_forward(forward: Callable[[torch.Tensor], torch.Tensor], x_global: t
     lo, hi = shard_range(x_global.shape[0], rank, world)
     y = forward(x_global[lo:hi])
     return gather_outputs(y, x_global.shape[0], group) if gather else y
+
+
+class OutputGather:
+    """Double-buffered asynchronous all-gather of equal-size output shards.
+
+    ``submit(y_local)`` starts the gather of one batch on the backend's communication stream (RCCL: its own HIP
+    stream, ordered after the kernels that produced ``y_local``) and returns a slot; the caller goes on to compute
+    the next batch, so at N > 1 the collective (100 MB per GPU and batch at 32 x 3 x 512 x 512 fp32) overlaps the
+    next forward instead of adding to it.  ``result(slot)`` waits for that gather and returns the gathered tensor
+    (valid until the slot is reused, ``depth`` submits later); ``drain()`` waits for everything in flight.
+    """
+
+    def __init__(self, shard_shape, dtype, device, group=None, depth: int = 2):
+        if not dist.is_initialized():
+            raise RuntimeError("OutputGather needs an initialised process group")
+        self.group = group
+        self.world = dist.get_world_size(group)
+        shard_shape = tuple(shard_shape)
+        self.bufs = [torch.empty((self.world * shard_shape[0],) + shard_shape[1:], dtype=dtype, device=device)
+                     for _ in range(max(1, depth))]
+        self.works = [None] * len(self.bufs)
+        self.keep = [None] * len(self.bufs)          # the local shard must stay alive until its gather completed
+        self.next = 0
+
+    def submit(self, y_local: torch.Tensor) -> int:
+        slot = self.next
+        self.next = (slot + 1) % len(self.bufs)
+        if self.works[slot] is not None:             # the buffer is about to be overwritten
+            self.works[slot].wait()
+        y_local = y_local.contiguous()
+        self.keep[slot] = y_local
+        self.works[slot] = dist.all_gather_into_tensor(self.bufs[slot], y_local, group=self.group, async_op=True)
+        return slot
+
+    def result(self, slot: int) -> torch.Tensor:
+        if self.works[slot] is not None:
+            self.works[slot].wait()
+            self.works[slot] = None
+            self.keep[slot] = None
+        return self.bufs[slot]
+
+    def drain(self) -> None:
+        for slot in range(len(self.bufs)):
+            self.result(slot)

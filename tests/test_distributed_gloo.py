@@ -75,3 +75,41 @@ def test_shard_range_partitions(pkg):
             assert cover == list(range(total))
     with pytest.raises(ValueError):
         d.shard_range(4, 2, 2)
+
+
+def _pipe_worker(rank, world, port, steps, out_dir):
+    sys.path.insert(0, ROOT)
+    import importlib
+    pkg = importlib.import_module("mi-gan_amd")
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    shard = (3, 3, 8, 8)
+    pipe = pkg.distributed.OutputGather(shard, torch.float32, torch.device("cpu"))
+    got = []
+    slots = []
+    for i in range(steps):                              # the bench.py loop: submit every step, never wait in the loop
+        y = torch.full(shard, float(100 * i + rank))
+        y[:, 0, 0, 0] = torch.arange(3, dtype=torch.float32) + 10 * rank
+        slots.append(pipe.submit(y))
+        if i >= 1:                                      # a consumer one step behind sees the previous batch intact
+            got.append(pipe.result(slots[i - 1]).clone())
+    pipe.drain()
+    got.append(pipe.result(slots[-1]).clone())
+    np.save(os.path.join(out_dir, f"pipe_{rank}.npy"), torch.stack(got).numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_output_gather_pipeline_world2_gloo(tmp_path):
+    """bench.py's N > 1 step: asynchronous, double-buffered all-gather of every step's output shards."""
+    world, steps = 2, 5
+    mp.spawn(_pipe_worker, args=(world, _free_port(), steps, str(tmp_path)), nprocs=world, join=True)
+    a, b = np.load(tmp_path / "pipe_0.npy"), np.load(tmp_path / "pipe_1.npy")
+    np.testing.assert_array_equal(a, b)                 # every rank holds the same gathered batches
+    assert a.shape == (steps, world * 3, 3, 8, 8)
+    for i in range(steps):
+        for r in range(world):
+            blk = a[i, 3 * r:3 * r + 3]
+            assert np.all(blk[:, 1:] == 100 * i + r)    # rank r's shard of step i, in rank order
+            np.testing.assert_array_equal(blk[:, 0, 0, 0], np.arange(3) + 10 * r)
