@@ -253,11 +253,13 @@ def test_every_layer_matches_oracle_taps(pkg, dev):
     np.testing.assert_allclose(y.cpu().numpy(), want, rtol=0, atol=TOL)
 
 
-def test_batch32_at_512_properties(pkg, dev):
-    """BASELINE configs[2] full size (migan-512, batch 32, fp32) through size-independent properties:
+@pytest.mark.parametrize("res", [512, 256])
+def test_batch32_full_size_properties(pkg, dev, res):
+    """BASELINE configs[2] (migan-512, batch 32, fp32) and the shape of configs[1] (migan-256, batch 32; computed in
+    fp32 here, the bf16 storage mode of that config is not built) at full size through size-independent properties:
     images are independent (a batch of repeated images reproduces the small-batch result bit for bit,
     whatever tile/batch grouping the kernels use) and the forward is deterministic."""
-    res, seed = 512, 51
+    seed = 51
     m, sd = _model(pkg, res, seed, dev)
     x4 = torch.from_numpy(pkg.synth.make_input(4, res, seed=seed)).to(dev)
     with torch.no_grad():
