@@ -138,6 +138,28 @@ def test_state_errors(pkg, lib):
             pkg.hipbind.MiganHandle(lib, r)
 
 
+def test_forward_argument_errors(pkg, lib):
+    """Empty batch, undersized workspace and null pointers are refused with MIGAN_EINVAL, nothing is launched."""
+    h, sd, keep = _bind(pkg, lib, 8, 2)
+    x = aligned(pkg.synth.make_input(2, 8, seed=2))
+    y = aligned(np.full((2, 3, 8, 8), np.nan, np.float32))
+    need = h.workspace_bytes(2)
+    ws = np.zeros(need // 4 + 64, np.float32)
+    with pytest.raises(ValueError):
+        h.workspace_bytes(0)
+    with pytest.raises(ValueError, match="batch"):
+        h.forward(x.ctypes.data, y.ctypes.data, 0, ws.ctypes.data, need)
+    with pytest.raises(ValueError, match="workspace"):
+        h.forward(x.ctypes.data, y.ctypes.data, 2, ws.ctypes.data, need - 16)
+    with pytest.raises(ValueError):
+        h.forward(None, y.ctypes.data, 2, ws.ctypes.data, need)
+    with pytest.raises(ValueError):
+        h.forward(x.ctypes.data, y.ctypes.data, 2, None, need)
+    assert np.isnan(y).all()                                     # none of the refused calls wrote anything
+    h.forward(x.ctypes.data, y.ctypes.data, 2, ws.ctypes.data, need)
+    np.testing.assert_allclose(y, orc.generator(x, sd, 8), rtol=0, atol=2e-5)
+
+
 def test_persistent_workgroups_and_both_gemm_variants():
     """Large launches run persistent workgroups that walk several tiles and prefetch the next tile's
     first K chunk during the epilogue; the 1x1 convs run on exact fp32 MFMA, on the bf16x3-split MFMA or

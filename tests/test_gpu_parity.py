@@ -336,6 +336,21 @@ def test_cpu_tensor_is_refused(pkg, dev):
         m(torch.zeros(1, 4, 16, 16))
 
 
+def test_bad_inputs_are_refused_like_the_reference_module(pkg, dev):
+    """Empty batch, wrong channel count / resolution / dtype raise (the reference's conv layers raise for the same
+    inputs); a non-contiguous input is accepted and gives the same result as its contiguous copy."""
+    m, _ = _model(pkg, 16, 5, dev)
+    for bad in (torch.zeros(0, 4, 16, 16), torch.zeros(1, 3, 16, 16), torch.zeros(1, 4, 32, 32), torch.zeros(1, 4, 16, 8),
+                torch.zeros(4, 16, 16), torch.zeros(1, 4, 16, 16, dtype=torch.float16)):
+        with pytest.raises(RuntimeError):
+            m(bad.to(dev))
+    x = torch.from_numpy(pkg.synth.make_input(3, 16, seed=5)).to(dev)
+    xt = x.permute(0, 1, 3, 2).contiguous().permute(0, 1, 3, 2)            # same values, non-contiguous strides
+    assert not xt.is_contiguous()
+    with torch.no_grad():
+        assert torch.equal(m(xt), m(x))
+
+
 @pytest.mark.parametrize("gemm", ["f32", "bf16x3"])
 def test_other_gemm_variants_also_pass(pkg, dev, gemm):
     """The default GEMM variant is the f16x2-split MFMA; the exact fp32-MFMA kernels and the bf16x3-split
