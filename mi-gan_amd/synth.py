@@ -128,3 +128,43 @@ def make_input(batch: int, resolution: int, seed: int = 0, kind: str = "demo") -
     img = (img_u8.astype(np.float32) * 2.0 / 255.0 - 1.0).astype(np.float32)
     mask = make_masks(batch, r, seed)
     return np.concatenate([mask - 0.5, img * mask], axis=1).astype(np.float32)
+
+
+# ---- Co-Mod-GAN -------------------------------------------------------
+
+def make_comodgan_state_dict(cfg, seed: int = 0) -> Dict[str, np.ndarray]:
+    """Reference-shaped state_dict (numpy float32) for the Co-Mod-GAN generator of ``cfg``
+    (comodgan_schema.Config).  Weights ~N(0,1) like the constructors (stylegan.py:79,213; the mapping's
+    are divided by lr_multiplier=0.01, :79,:366), biases, noise strengths and w_avg non-zero so every
+    term of the forward is exercised; affine biases around 1 (stylegan.py:273)."""
+    from . import comodgan_schema as cs
+    out: Dict[str, np.ndarray] = {}
+    for e in cs.entries(cfg):
+        shp, tag = e.shape, "cm/" + e.name
+        mapping = e.name.startswith("mapping.")
+        if e.role in ("conv_w", "rgb_w", "affine_w"):
+            out[e.name] = normal(shp, seed, tag).astype(np.float32)
+        elif e.role == "dense_w":
+            out[e.name] = (normal(shp, seed, tag) * (100.0 if mapping else 1.0)).astype(np.float32)
+        elif e.role in ("conv_b", "rgb_b"):
+            out[e.name] = (normal(shp, seed, tag) * 0.3).astype(np.float32)
+        elif e.role == "dense_b":
+            out[e.name] = (normal(shp, seed, tag) * (30.0 if mapping else 0.3)).astype(np.float32)
+        elif e.role == "affine_b":
+            out[e.name] = (1.0 + normal(shp, seed, tag) * 0.3).astype(np.float32)
+        elif e.role == "noise_strength":
+            out[e.name] = np.asarray(normal((1,), seed, tag)[0] * 0.3, dtype=np.float32).reshape(())
+        elif e.role == "noise_const":
+            out[e.name] = normal(shp, seed, tag).astype(np.float32)
+        elif e.role == "w_avg":
+            out[e.name] = (normal(shp, seed, tag) * 0.3).astype(np.float32)
+        elif e.role == "fir":
+            out[e.name] = np.asarray(cs.fir_kernel_2d(), dtype=np.float32)
+        else:  # pragma: no cover
+            raise AssertionError(e.role)
+    return out
+
+
+def make_latent(batch: int, z_dim: int = 512, seed: int = 0) -> np.ndarray:
+    """z [N, z_dim] ~ N(0,1) (comodgan.py:438-439 draws it with torch.randn; parity needs it explicit)."""
+    return normal((batch, z_dim), seed, f"z{z_dim}").astype(np.float32)
