@@ -14,8 +14,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 ROOT = os.path.dirname(HERE)
 OUT = os.path.join(CSRC, "libmigan_hip.so")
-SOURCES = [os.path.join(CSRC, f) for f in ("migan_hip.hip", "migan_kernels.hpp", "migan_host.hpp", "migan_rt_hip.h")] + [
-    os.path.join(ROOT, "include", "migan_hip.h")]
+SOURCES = [os.path.join(CSRC, f) for f in ("migan_hip.hip", "migan_kernels.hpp", "migan_host.hpp", "migan_rt_hip.h",
+                                            "comodgan_kernels.hpp", "comodgan_host.hpp")] + [
+    os.path.join(ROOT, "include", "migan_hip.h"), os.path.join(ROOT, "include", "comodgan_hip.h")]
 ARCH = "gfx950"
 
 

@@ -1,0 +1,589 @@
+// Co-Mod-GAN generator forward: gfx950 (MI355X / CDNA4) device kernels.
+//
+// Reference being replaced: lib/model_zoo/comodgan.py::Generator.forward (:435-455) = Mapping (stylegan.py:396-439),
+// Encoder (comodgan.py:192-204), Synthesis (comodgan.py:395-420); layers stylegan.py: dense :64-99,
+// modulated_conv2d :102-195, conv2d_layer :197-244, synthesis_layer :247-309, torgb_layer :312-344;
+// resampling torch_utils/ops/conv2d_resample.py and upfirdn2d.py.
+//
+// Everything that is a dense contraction (the 3x3 convolutions, 99 % of the 240 GFLOP per 512x512 image) runs
+// on the matrix cores as an implicit GEMM (cm_conv_kernel); the rest are streaming kernels:
+//
+//   cm_conv_kernel      3x3 convolution, NHWC, M = 8x16 output-grid pixels, N = 64/128 output channels, K = taps x Cin.
+//                       A operand: the input halo tile of a 32-channel chunk is staged ONCE in LDS (scaled by the
+//                       per-sample style = the "scale activations" form of weight modulation, stylegan.py:171-182,
+//                       split into two fp16 planes) and re-read at 1..9 shifted positions, one per filter tap.
+//                       B operand: per (tap, chunk) weight tile, pre-split fp16 planes, double-buffered in LDS.
+//                       v_mfma_f32_32x32x16_f16 x 3 per fp32 product (error-compensated, fp32 accumulate), same
+//                       scheme as the MI-GAN 1x1 GEMM (migan_kernels.hpp, GEMMV 2).
+//                       Epilogue: per-(sample, channel) demodulation coefficient, noise, bias, lrelu*sqrt2, clamp, skip.
+//                       The tap list is data: plain 3x3 (9 taps, stride 1), stride-2 on the FIR-filtered input
+//                       (encoder down path), and the four output phases of the stride-2 transposed convolution
+//                       (synthesis up path: 4 + 2 + 2 + 1 taps, no multiplications by inserted zeros).
+//   cm_blur_kernel      upfirdn2d [1,3,3,1] FIR with pad 2 in front of the strided convolution (conv2d_resample down path)
+//   cm_upfir_kernel     upfirdn2d FIR (gain 4) behind the transposed convolution + noise/bias/activation/skip epilogue
+//   cm_fromrgb_kernel   1x1 conv 4 -> C with bias and activation, NCHW planes -> NHWC
+//   cm_torgb_kernel     modulated 1x1 conv C -> 3 (no demodulation) + bias + 2x FIR upsample of the running image
+//   cm_dense_kernel     fully connected layers (mapping, affine, encoder fc, synthesis fc): weight streaming, fp32 FMA
+//   cm_wsq_kernel       per-tensor demodulation statistics (sum over taps of w^2, per-output-channel normalisation)
+//   cm_style_kernel     styles -> normalised input scales (with the per-sample power-of-two fp16 range scale) and
+//                       demodulation coefficients, or (ToRGB) the per-sample modulated 1x1 weights
+//   cm_split_conv_kernel  3x3 weights -> two fp16 planes, [plane][tap][Cin/32][Cout][32]
+//
+// Compiled twice like migan_kernels.hpp: by hipcc for gfx950 and by the host compiler against tests/emu/hip_emu.h.
+#pragma once
+
+namespace migan {
+
+constexpr int kCmMaxTaps = 9;
+constexpr float kCmInBound = 512.0f;        // |conv input| <= 256 (lrelu_agc clamp) + 256 (skip added after the activation)
+constexpr float kCmF16Top = 32768.0f;       // scaled A operands stay below 2^15 (fp16 max 65504)
+
+struct CmConvArgs {
+  const float* x;               // NHWC [B][H][W][CI]
+  float* y;                     // NHWC [B][HO][WO][CO]
+  const float* skip;            // NHWC like y, added after the activation, or null
+  const unsigned short* wsplit; // fp16 planes [2][9][CI/32][CO][32] behind a 16-byte header (weight_absmax_kernel)
+  const float* sa;              // [B][CI] per-sample input scale (normalised style x 2^e) or null -> a_scale
+  const float* coef;            // [B][CO] per-sample output coefficient or null -> cgain
+  const float* bias;            // [CO]
+  const float* noise;           // [HO][WO] (+ noise_bstride floats per image) or null
+  const float* noise_strength;  // scalar
+  long long noise_bstride;
+  float a_scale, cgain;
+  int B, H, W, CI, CO, HO, WO;
+  int stride;                   // input pixels per output-grid pixel (1, or 2 for the strided convolution)
+  int ntaps;
+  int dy[kCmMaxTaps], dx[kCmMaxTaps], wtap[kCmMaxTaps];   // input offset of each tap (relative to grid*stride), weight tap plane
+  int dymin, dxmin, IH, IW;     // input tile origin offset and extent for an 8x16 grid tile
+  int oy_mul, oy_add, ox_mul, ox_add;   // output pixel of grid pixel (gy, gx)
+  int GHn, GWn;                 // grid extent; grid pixels beyond are not stored
+  int tiles_x, tiles_y, nchunks;
+  int raw;                      // 1: store acc * coef only (transposed-convolution phases; cm_upfir_kernel finishes the layer)
+  int off_b, off_g;             // LDS carve in bytes: B tile buffers; the result tile aliases everything
+};
+
+// fp32 x 4 -> LDS A/B plane position: 64-byte rows (32 fp16), 16-byte slots XOR-swizzled by (row >> 2) & 3 so that
+// 16 consecutive rows of one slot cover all 64 banks
+MIGAN_DEVICE MIGAN_INLINE int cm_slot_off(int row, int slot) { return row * 64 + ((slot ^ ((row >> 2) & 3)) << 4); }
+
+template <int NT>
+MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, 2) cm_conv_kernel(const CmConvArgs p) {
+  MIGAN_DYN_SMEM(smem);
+  constexpr int MT = 128, KC = 32, GW = 16;
+  constexpr int WCOLS = NT / 2, NTI = WCOLS / 32, MTI = 2;
+  constexpr int GS = NT + 4;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, half = lane >> 5;
+
+  // logical tile: Cout chunk fastest, then x, y, image (XCD-contiguous ranges share halo rows and weight tiles in L2)
+  int t = xcd_remap((int)blockIdx.x, (int)gridDim.x);
+  const int nc = t % p.nchunks; t /= p.nchunks;
+  const int tx = t % p.tiles_x; t /= p.tiles_x;
+  const int ty = t % p.tiles_y; t /= p.tiles_y;
+  const int b = t;
+  const int co0 = nc * NT;
+  const int gy0 = ty * 8, gx0 = tx * GW;
+  const int iy0 = gy0 * p.stride + p.dymin, ix0 = gx0 * p.stride + p.dxmin;
+  const int npix = p.IH * p.IW;
+  const int nck = p.CI / KC;
+
+  char* a_s = reinterpret_cast<char*>(smem);                  // [2 planes][npix][64 B]
+  char* b_s = reinterpret_cast<char*>(smem) + p.off_b;        // [2 buffers][2 planes][NT][64 B]
+  float* g_s = smem;                                          // [MT][GS] after the K loop
+  const int a_plane = npix * 64;
+  constexpr int b_plane = NT * 64, b_buf = 2 * b_plane;
+
+  const float* __restrict__ xb = p.x + (size_t)b * p.H * p.W * p.CI;
+  const float* __restrict__ sab = p.sa ? p.sa + (size_t)b * p.CI : nullptr;
+  const size_t w_plane = (size_t)9 * p.CI * p.CO;             // 16-bit elements per weight plane
+  const int total = nck * p.ntaps;
+
+  f16v acc[MTI][NTI];
+#pragma unroll
+  for (int i = 0; i < MTI; ++i)
+#pragma unroll
+    for (int j = 0; j < NTI; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+  // B tile of iteration `it` (chunk-major over taps): rows co0..co0+NT-1 of [tap][chunk][CO][32], both planes
+  constexpr int BPIECES = 2 * NT * 4 / 256;                   // 16-byte pieces per thread
+  f4 breg[BPIECES];
+  auto load_b = [&](int it) {
+    const int c = it / p.ntaps, tp = p.wtap[it % p.ntaps];
+    const unsigned short* src = p.wsplit + ((size_t)(tp * nck + c) * p.CO + co0) * 32;
+#pragma unroll
+    for (int k = 0; k < BPIECES; ++k) {
+      const int piece = tid + k * 256;                        // [plane][row][slot]
+      const int pl = piece / (NT * 4), rs = piece % (NT * 4);
+      breg[k] = ld4(reinterpret_cast<const float*>(src + pl * w_plane + rs * 8));
+    }
+  };
+  auto store_b = [&](int buf) {
+#pragma unroll
+    for (int k = 0; k < BPIECES; ++k) {
+      const int piece = tid + k * 256;
+      const int pl = piece / (NT * 4), rs = piece % (NT * 4);
+      const int row = rs >> 2, slot = rs & 3;
+      st4(reinterpret_cast<float*>(b_s + buf * b_buf + pl * b_plane + cm_slot_off(row, slot)), breg[k]);
+    }
+  };
+
+  load_b(0);
+  store_b(0);
+  for (int c = 0; c < nck; ++c) {
+    // ---- stage the input halo tile of channel chunk c: global fp32 -> x style scale -> two fp16 planes in LDS
+    for (int item = tid; item < npix * 8; item += 256) {
+      const int q = item >> 3, c4 = item & 7;
+      const int py = q / p.IW, px = q - py * p.IW;
+      const int iy = iy0 + py, ix = ix0 + px;
+      f4 v = f4{0.f, 0.f, 0.f, 0.f};
+      if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) {
+        v = ld4(xb + ((size_t)iy * p.W + ix) * p.CI + c * KC + c4 * 4);
+        if (sab) v = v * ld4(sab + c * KC + c4 * 4);
+        else v = v * p.a_scale;
+      }
+      u2v h1, h2;
+      split2_f16(v, h1, h2);
+      char* dst = a_s + cm_slot_off(q, c4 >> 1) + (c4 & 1) * 8;
+      *reinterpret_cast<u2v*>(dst) = h1;
+      *reinterpret_cast<u2v*>(dst + a_plane) = h2;
+    }
+    __syncthreads();
+    for (int tp = 0; tp < p.ntaps; ++tp) {
+      const int it = c * p.ntaps + tp;
+      if (it + 1 < total) load_b(it + 1);
+      const char* bb = b_s + (it & 1) * b_buf;
+      const int oy = p.dy[tp] - p.dymin, ox = p.dx[tp] - p.dxmin;
+#pragma unroll
+      for (int ks = 0; ks < KC / 16; ++ks) {
+        f4 av[MTI][2], bv[NTI][2];
+#pragma unroll
+        for (int i = 0; i < MTI; ++i) {
+          const int m = wm * 64 + i * 32 + l31;
+          const int q = ((m >> 4) * p.stride + oy) * p.IW + (m & 15) * p.stride + ox;
+          const char* qa = a_s + cm_slot_off(q, 2 * ks + half);
+          av[i][0] = ld4(reinterpret_cast<const float*>(qa));
+          av[i][1] = ld4(reinterpret_cast<const float*>(qa + a_plane));
+        }
+#pragma unroll
+        for (int j = 0; j < NTI; ++j) {
+          const int row = wn * WCOLS + j * 32 + l31;
+          const char* qb = bb + cm_slot_off(row, 2 * ks + half);
+          bv[j][0] = ld4(reinterpret_cast<const float*>(qb));
+          bv[j][1] = ld4(reinterpret_cast<const float*>(qb + b_plane));
+        }
+#pragma unroll
+        for (int i = 0; i < MTI; ++i)
+#pragma unroll
+          for (int j = 0; j < NTI; ++j) {
+            acc[i][j] = MIGAN_MFMA_F16_32X32X16(av[i][1], bv[j][0], acc[i][j]);
+            acc[i][j] = MIGAN_MFMA_F16_32X32X16(av[i][0], bv[j][1], acc[i][j]);
+            acc[i][j] = MIGAN_MFMA_F16_32X32X16(av[i][0], bv[j][0], acc[i][j]);
+          }
+      }
+      if (it + 1 < total) store_b((it + 1) & 1);
+      __syncthreads();
+    }
+  }
+
+  // ---- epilogue: accumulators -> LDS result tile -> per float4: coefficient, noise, bias, activation, skip
+#pragma unroll
+  for (int i = 0; i < MTI; ++i)
+#pragma unroll
+    for (int j = 0; j < NTI; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        const int col = wn * WCOLS + j * 32 + l31;
+        g_s[row * GS + col] = acc[i][j][r];
+      }
+  __syncthreads();
+  const float inv_wscale = 1.0f / reinterpret_cast<const float*>(p.wsplit)[-2];      // power of two (weight_absmax_kernel)
+  const float ns = p.noise ? p.noise_strength[0] : 0.0f;
+  constexpr int QN = NT / 4;
+  for (int item = tid; item < MT * QN; item += 256) {
+    const int c4 = item % QN, m = item / QN;
+    const int gy = gy0 + (m >> 4), gx = gx0 + (m & 15);
+    if (gy >= p.GHn || gx >= p.GWn) continue;
+    const int oy = gy * p.oy_mul + p.oy_add, ox = gx * p.ox_mul + p.ox_add;
+    const int co = co0 + c4 * 4;
+    f4 cf = p.coef ? ld4(p.coef + (size_t)b * p.CO + co) : f4{p.cgain, p.cgain, p.cgain, p.cgain};
+    cf = cf * inv_wscale;
+    f4 v = ld4(g_s + m * GS + c4 * 4) * cf;
+    const size_t o = (((size_t)b * p.HO + oy) * p.WO + ox) * p.CO + co;
+    if (!p.raw) {
+      if (p.noise) v = v + MIGAN_FMUL_RN(p.noise[(size_t)b * p.noise_bstride + (size_t)oy * p.WO + ox], ns);
+      v = act4(v + ld4(p.bias + co));
+      if (p.skip) v = v + ld4(p.skip + o);
+    }
+    st4(p.y + o, v);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// 3x3 weights [CO][CI][3][3] fp32 -> two fp16 planes [plane][tap][CI/32][CO][32] of w * wscale (wscale: the power of
+// two in the header that weight_absmax_kernel wrote, max|w| -> [2^13, 2^14)).
+struct CmSplitArgs {
+  const float* src;
+  unsigned short* dst;        // plane 0; a 16-byte header precedes it
+  int CO, CI;
+};
+MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, 2) cm_split_conv_kernel(const CmSplitArgs p) {
+  const float sw = reinterpret_cast<const float*>(p.dst)[-2];
+  const size_t plane = (size_t)9 * p.CI * p.CO;
+  const size_t n = (size_t)p.CO * p.CI;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const int co = (int)(i / p.CI), ci = (int)(i % p.CI);
+    const float* s = p.src + i * 9;
+#pragma unroll
+    for (int tp = 0; tp < 9; ++tp) {
+      const float v = s[tp] * sw;
+      const unsigned pk = MIGAN_PACK_F16(v, 0.0f);
+      const float r = v - MIGAN_F16LO_F32(pk);
+      const unsigned pk2 = MIGAN_PACK_F16(r, 0.0f);
+      const size_t o = ((size_t)(tp * (p.CI / 32) + (ci >> 5)) * p.CO + co) * 32 + (ci & 31);
+      p.dst[o] = (unsigned short)(pk & 0xffffu);
+      p.dst[plane + o] = (unsigned short)(pk2 & 0xffffu);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Demodulation statistics of one 3x3 weight tensor (stylegan.py:138,147): wsq[co][ci] = sum_k w^2,
+// wn2[co] = 1 / mean_{ci,k} w^2.  One workgroup per output channel.
+struct CmWsqArgs {
+  const float* w;      // [CO][CI][3][3]
+  float* wsq;          // [CO][CI]
+  float* wn2;          // [CO]
+  int CO, CI;
+};
+MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, 2) cm_wsq_kernel(const CmWsqArgs p) {
+  MIGAN_DYN_SMEM(red);
+  const int co = (int)blockIdx.x;
+  float tot = 0.0f;
+  for (int ci = threadIdx.x; ci < p.CI; ci += 256) {
+    const float* s = p.w + ((size_t)co * p.CI + ci) * 9;
+    float a = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) a += s[k] * s[k];
+    p.wsq[(size_t)co * p.CI + ci] = a;
+    tot += a;
+  }
+#pragma unroll
+  for (int sft = 32; sft >= 1; sft >>= 1) tot += __shfl_xor(tot, sft);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = tot;
+  __syncthreads();
+  if (threadIdx.x == 0) p.wn2[co] = (float)(p.CI * 9) / (red[0] + red[1] + red[2] + red[3]);
+}
+
+// ------------------------------------------------------------------------------------------------
+// styles [B][CI] (output of the affine dense layer) ->
+//   demod = 1 (synthesis_layer): s~ = styles * rsqrt(mean over batch and channels of styles^2)   (stylegan.py:139)
+//             sa[b][ci]   = s~ * 2^e_b, e_b the largest power of two keeping |x * sa| < 2^15 for |x| <= kCmInBound
+//             coef[b][co] = wn[co] * rsqrt(wn2[co] * sum_ci s~^2 wsq[co][ci] + 1e-8) / 2^e_b           (stylegan.py:138-147,161)
+//   demod = 0 (torgb_layer): wm[b][3][ci] = w[c][ci] * styles[b][ci] * wgain                             (stylegan.py:337-338)
+// One workgroup per sample.
+struct CmStyleArgs {
+  const float* styles;  // [B][CI]
+  const float* wsq;     // [CO][CI]   (demod)
+  const float* wn2;     // [CO]       (demod)
+  const float* w;       // [3][CI]    (torgb)
+  float* sa;            // [B][CI]    (demod)
+  float* coef;          // [B][CO]    (demod)
+  float* wm;            // [B][3][CI] (torgb)
+  float wgain;
+  int B, CI, CO, demod;
+};
+MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, 2) cm_style_kernel(const CmStyleArgs p) {
+  MIGAN_DYN_SMEM(sm);            // [CI] s~^2 of this sample, then 8 floats of reduction scratch
+  const int b = (int)blockIdx.x, tid = threadIdx.x;
+  const float* st = p.styles + (size_t)b * p.CI;
+  if (!p.demod) {
+    for (int i = tid; i < 3 * p.CI; i += 256) {
+      const int ci = i % p.CI;
+      p.wm[(size_t)b * 3 * p.CI + i] = p.w[i] * (st[ci] * p.wgain);
+    }
+    return;
+  }
+  float* red = sm + p.CI;
+  float ss = 0.0f;
+  for (int i = tid; i < p.B * p.CI; i += 256) ss += p.styles[i] * p.styles[i];
+#pragma unroll
+  for (int sft = 32; sft >= 1; sft >>= 1) ss += __shfl_xor(ss, sft);
+  if ((tid & 63) == 0) red[tid >> 6] = ss;
+  __syncthreads();
+  const float g = 1.0f / sqrtf((red[0] + red[1] + red[2] + red[3]) / (float)(p.B * p.CI));
+  float mx = 0.0f;
+  for (int ci = tid; ci < p.CI; ci += 256) {
+    const float s = st[ci] * g;
+    sm[ci] = s * s;
+    mx = fmaxf(mx, fabsf(s));
+  }
+#pragma unroll
+  for (int sft = 32; sft >= 1; sft >>= 1) mx = fmaxf(mx, __shfl_xor(mx, sft));
+  if ((tid & 63) == 0) red[4 + (tid >> 6)] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(red[4], red[5]), fmaxf(red[6], red[7]));
+  // 2^e <= kCmF16Top / (kCmInBound * mx): e = 6 - ceil(log2 mx); exponent arithmetic on the float bits
+  int ex = (int)((__builtin_bit_cast(unsigned, mx) >> 23) & 0xffu) - 127;          // floor(log2 mx)
+  ex = ex < -60 ? -60 : (ex > 60 ? 60 : ex);
+  const int e = 6 - (ex + 1);                                                      // mx < 2^(ex+1)
+  const float up = __builtin_bit_cast(float, (unsigned)(127 + e) << 23);
+  const float dn = __builtin_bit_cast(float, (unsigned)(127 - e) << 23);
+  for (int ci = tid; ci < p.CI; ci += 256) p.sa[(size_t)b * p.CI + ci] = st[ci] * g * up;
+  // one wave per output channel: sum_ci s~^2 wsq[co][ci]
+  const int lane = tid & 63, wave = tid >> 6;
+  for (int co = wave; co < p.CO; co += 4) {
+    const float* wq = p.wsq + (size_t)co * p.CI;
+    float a = 0.0f;
+    for (int ci = lane; ci < p.CI; ci += 64) a += sm[ci] * wq[ci];
+#pragma unroll
+    for (int sft = 32; sft >= 1; sft >>= 1) a += __shfl_xor(a, sft);
+    if (lane == 0) {
+      const float n2 = p.wn2[co];
+      p.coef[(size_t)b * p.CO + co] = sqrtf(n2) * (1.0f / sqrtf(n2 * a + 1e-8f)) * dn;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// dense (stylegan.py:64-99): y[n][o] = act((sum_k x[n][k] W[o][k]) * wgain + b[o] * bgain)
+// Optional: per-row input normalisation x * rsqrt(mean(x^2) + 1e-8) (normalize_2nd_moment, stylegan.py:351-352),
+// NHWC<->NCHW index permutations of the 4x4 bottleneck (in_c / out_c = channel count, 0 = none), `add` (same layout
+// as the output, after the activation: comodgan.py:243), truncation lerp towards w_avg (stylegan.py:432-437),
+// row-concatenated input (x2 supplies columns >= K1: torch.cat([w, w0]) of comodgan.py:247).
+// One wave per 2 output features, 8 batch rows per pass.
+struct CmDenseArgs {
+  const float* x;      // [N][K1]
+  const float* x2;     // [N][K-K1] or null
+  const float* w;      // [O][K]
+  const float* b;      // [O]
+  const float* add;    // or null
+  const float* lerp0;  // w_avg [O] or null
+  float* y;            // [N][O]
+  float wgain, bgain, psi;
+  int N, K, K1, O;
+  int act, norm, in_c, out_c;
+};
+MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, 2) cm_dense_kernel(const CmDenseArgs p) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int o0 = ((int)blockIdx.x * 4 + wave) * 2;
+  if (o0 >= p.O) return;
+  const int no = (o0 + 1 < p.O) ? 2 : 1;
+  const int K2 = p.K - p.K1;
+  for (int n0 = 0; n0 < p.N; n0 += 8) {
+    float acc[2][8], nrm[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) { acc[0][r] = 0.0f; acc[1][r] = 0.0f; nrm[r] = 0.0f; }
+    for (int k = lane; k < p.K; k += 64) {
+      const float w0 = p.w[(size_t)o0 * p.K + k];
+      const float w1 = no > 1 ? p.w[(size_t)(o0 + 1) * p.K + k] : 0.0f;
+      int ks = k;
+      if (p.in_c) ks = (k & 15) * p.in_c + (k >> 4);        // NCHW flatten index c*16 + pos -> NHWC pos*C + c
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        const int n = n0 + r;
+        float xv = 0.0f;
+        if (n < p.N) xv = (ks < p.K1) ? p.x[(size_t)n * p.K1 + ks] : p.x2[(size_t)n * K2 + (ks - p.K1)];
+        acc[0][r] += xv * w0;
+        acc[1][r] += xv * w1;
+        nrm[r] += xv * xv;
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+#pragma unroll
+      for (int sft = 32; sft >= 1; sft >>= 1) {
+        acc[0][r] += __shfl_xor(acc[0][r], sft);
+        acc[1][r] += __shfl_xor(acc[1][r], sft);
+        if (p.norm) nrm[r] += __shfl_xor(nrm[r], sft);
+      }
+    }
+    if (lane < 16) {
+      const int r = lane & 7, j = lane >> 3;
+      const int n = n0 + r, o = o0 + j;
+      if (n < p.N && j < no) {
+        // select without dynamic register indexing
+        float a = 0.0f, q = 0.0f;
+#pragma unroll
+        for (int rr = 0; rr < 8; ++rr)
+          if (rr == r) { a = j ? acc[1][rr] : acc[0][rr]; q = nrm[rr]; }
+        if (p.norm) a = a * (1.0f / sqrtf(q / (float)p.K + 1e-8f));
+        float v = a * p.wgain + p.b[o] * p.bgain;
+        if (p.act) v = act1(v);
+        const int oi = p.out_c ? (o & 15) * p.out_c + (o >> 4) : o;
+        if (p.add) v += p.add[(size_t)n * p.O + oi];
+        if (p.lerp0) {
+          const float s = p.lerp0[o];
+          v = (p.psi < 0.5f) ? s + p.psi * (v - s) : v - (v - s) * (1.0f - p.psi);     // torch.lerp
+        }
+        p.y[(size_t)n * p.O + oi] = v;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// conv2d_layer(4 -> C, kernel 1, bias, activation) of the first encoder block (comodgan.py:46-48, stylegan.py:231-244):
+// NCHW network input -> NHWC features.  One thread per pixel and channel quad.
+struct CmFromRgbArgs {
+  const float* x;      // [B][4][R][R]
+  const float* w;      // [C][4]
+  const float* b;      // [C]
+  float* y;            // [B][R][R][C]
+  float wgain;
+  int B, R, C;
+};
+MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, 2) cm_fromrgb_kernel(const CmFromRgbArgs p) {
+  const int qn = p.C >> 2;
+  const size_t plane = (size_t)p.R * p.R;
+  const size_t total = (size_t)p.B * plane * qn;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int c4 = (int)(i % qn);
+    const size_t pix = i / qn;
+    const size_t bi = pix / plane, rem = pix % plane;
+    const float* xp = p.x + bi * 4 * plane + rem;
+    const float x0 = xp[0], x1 = xp[plane], x2 = xp[2 * plane], x3 = xp[3 * plane];
+    f4 v;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const f4 w = ld4(p.w + (c4 * 4 + j) * 4) * p.wgain;
+      v[j] = (x0 * w.x + x1 * w.y + x2 * w.z + x3 * w.w) + p.b[c4 * 4 + j];
+    }
+    st4(p.y + pix * p.C + c4 * 4, act4(v));
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// upfirdn2d with the [1,3,3,1] x [1,3,3,1] / 64 filter, up = down = 1, zero padding `pad` on every side
+// (conv2d_resample.py down path: pad = conv padding + 1 = 2): NHWC [B][H][W][C] -> [B][H+2pad-3][W+2pad-3][C].
+struct CmBlurArgs {
+  const float* x;
+  float* y;
+  int B, H, W, C, HO, WO, pad;
+};
+MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, 2) cm_blur_kernel(const CmBlurArgs p) {
+  const int qn = p.C >> 2;
+  const size_t total = (size_t)p.B * p.HO * p.WO * qn;
+  const float f[4] = {0.125f, 0.375f, 0.375f, 0.125f};
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int c4 = (int)(i % qn);
+    size_t pix = i / qn;
+    const int ox = (int)(pix % p.WO); pix /= p.WO;
+    const int oy = (int)(pix % p.HO);
+    const int b = (int)(pix / p.HO);
+    f4 acc = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      const int iy = oy + a - p.pad;
+      if (iy < 0 || iy >= p.H) continue;
+      f4 row = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int ix = ox + c - p.pad;
+        if (ix < 0 || ix >= p.W) continue;
+        row = row + ld4(p.x + (((size_t)b * p.H + iy) * p.W + ix) * p.C + c4 * 4) * f[c];
+      }
+      acc = acc + row * f[a];
+    }
+    st4(p.y + i * 4, acc);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Second half of an up=2 synthesis_layer: upfirdn2d (filter x gain 4, pad 1) over the (2H+1)^2 output of the
+// transposed convolution (conv2d_resample.py up path), then noise, bias, activation, skip
+// (stylegan.py:300-309, comodgan.py:331-332).  The demodulation coefficient is already applied (cm_conv_kernel raw mode).
+struct CmUpFirArgs {
+  const float* raw;            // NHWC [B][HR][HR][C], HR = HO + 1
+  float* y;                    // NHWC [B][HO][HO][C]
+  const float* skip;
+  const float* bias;
+  const float* noise;
+  const float* noise_strength;
+  long long noise_bstride;
+  int B, HO, C;
+};
+MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, 2) cm_upfir_kernel(const CmUpFirArgs p) {
+  const int qn = p.C >> 2, HR = p.HO + 1;
+  const size_t total = (size_t)p.B * p.HO * p.HO * qn;
+  const float f[4] = {0.25f, 0.75f, 0.75f, 0.25f};
+  const float ns = p.noise ? p.noise_strength[0] : 0.0f;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int c4 = (int)(i % qn);
+    size_t pix = i / qn;
+    const int ox = (int)(pix % p.HO); pix /= p.HO;
+    const int oy = (int)(pix % p.HO);
+    const int b = (int)(pix / p.HO);
+    f4 acc = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      const int iy = oy + a - 1;
+      if (iy < 0 || iy >= HR) continue;
+      f4 row = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int ix = ox + c - 1;
+        if (ix < 0 || ix >= HR) continue;
+        row = row + ld4(p.raw + (((size_t)b * HR + iy) * HR + ix) * p.C + c4 * 4) * f[c];
+      }
+      acc = acc + row * f[a];
+    }
+    if (p.noise) acc = acc + MIGAN_FMUL_RN(p.noise[(size_t)b * p.noise_bstride + (size_t)oy * p.HO + ox], ns);
+    acc = act4(acc + ld4(p.bias + c4 * 4));
+    if (p.skip) acc = acc + ld4(p.skip + i * 4);
+    st4(p.y + i * 4, acc);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// torgb_layer (stylegan.py:330-344) with per-sample modulated weights wm [B][3][C] (cm_style_kernel) + bias +
+// upsample2d of the running image (comodgan.py:334-343).  16 lanes per pixel, wave-shuffle butterfly.
+struct CmRgbArgs {
+  const float* x;        // NHWC [B][H][W][C]
+  const float* wm;       // [B][3][C]
+  const float* bias;     // [3]
+  const float* img_prev; // planar [B][3][H/2][W/2] or null
+  float* img_out;        // planar [B][3][H][W]
+  int B, H, W, C;
+};
+MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, 2) cm_torgb_kernel(const CmRgbArgs p) {
+  const int sub = threadIdx.x & 15;
+  const size_t pixel = ((size_t)blockIdx.x * 256 + threadIdx.x) >> 4;
+  const size_t plane = (size_t)p.H * p.W;
+  const size_t npix = (size_t)p.B * plane;
+  const bool ok = pixel < npix;
+  float r0 = 0.f, r1 = 0.f, r2 = 0.f;
+  const int b = ok ? (int)(pixel / plane) : 0;
+  if (ok) {
+    const float* xp = p.x + pixel * p.C;
+    const float* w = p.wm + (size_t)b * 3 * p.C;
+    for (int q = sub; q < (p.C >> 2); q += 16) {
+      const f4 v = ld4(xp + q * 4);
+      const f4 w0 = ld4(w + q * 4), w1 = ld4(w + p.C + q * 4), w2 = ld4(w + 2 * p.C + q * 4);
+      r0 += v.x * w0.x + v.y * w0.y + v.z * w0.z + v.w * w0.w;
+      r1 += v.x * w1.x + v.y * w1.y + v.z * w1.z + v.w * w1.w;
+      r2 += v.x * w2.x + v.y * w2.y + v.z * w2.z + v.w * w2.w;
+    }
+  }
+#pragma unroll
+  for (int s = 8; s >= 1; s >>= 1) {
+    r0 += __shfl_xor(r0, s);
+    r1 += __shfl_xor(r1, s);
+    r2 += __shfl_xor(r2, s);
+  }
+  if (ok && sub == 0) {
+    const int rem = (int)(pixel % plane);
+    const int oy = rem / p.W, ox = rem % p.W;
+    const float rgb[3] = {r0 + p.bias[0], r1 + p.bias[1], r2 + p.bias[2]};
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) {
+      float up = 0.0f;
+      if (p.img_prev) up = up_prev3(p.img_prev + ((size_t)b * 3 + ch) * (plane >> 2), p.H >> 1, p.W >> 1, oy, ox);
+      p.img_out[((size_t)b * 3 + ch) * plane + rem] = up + rgb[ch];
+    }
+  }
+}
+
+}  // namespace migan

@@ -43,7 +43,19 @@ EXPORTS = (
     "migan_forward_timed", "migan_set_debug", "migan_debug_tensor", "migan_sepconv_forward",
     "migan_pack_input", "migan_compose_output",
     "migan_last_error", "migan_backend", "migan_gemm_variant", "migan_version",
+    # include/comodgan_hip.h
+    "comodgan_create", "comodgan_destroy", "comodgan_num_weights", "comodgan_weight_info", "comodgan_set_weight",
+    "comodgan_commit", "comodgan_workspace_bytes", "comodgan_noise_floats", "comodgan_forward", "comodgan_num_launches",
+    "comodgan_launch_info", "comodgan_forward_timed", "comodgan_set_debug", "comodgan_debug_tensor",
 )
+
+
+class CoModGANConfig(C.Structure):
+    """struct comodgan_config"""
+    _fields_ = [(n, C.c_int) for n in ("resolution", "ch_base", "ch_max", "z_dim", "w_dim", "w0_dim", "map_layers", "num_ws")]
+
+
+NOISE_MODES = {"none": 0, "const": 1, "random": 2}
 
 
 class MiganLib:
@@ -82,6 +94,22 @@ class MiganLib:
         L.migan_sepconv_forward.argtypes = [C.POINTER(SepConvDesc), vp]
         L.migan_pack_input.argtypes = [vp, vp, vp, ci, ci, vp]
         L.migan_compose_output.argtypes = [vp, vp, vp, vp, ci, ci, vp]
+        fp = C.POINTER(C.c_float)
+        L.comodgan_create.argtypes = [C.POINTER(CoModGANConfig), ci, C.POINTER(vp)]
+        L.comodgan_destroy.argtypes = [vp]
+        L.comodgan_num_weights.argtypes = [vp, C.POINTER(ci)]
+        L.comodgan_weight_info.argtypes = [vp, ci, C.POINTER(C.c_char_p), C.POINTER(C.c_int64), C.POINTER(ci), C.POINTER(ci)]
+        L.comodgan_set_weight.argtypes = [vp, C.c_char_p, vp, C.POINTER(C.c_int64), ci]
+        L.comodgan_commit.argtypes = [vp, vp]
+        L.comodgan_workspace_bytes.argtypes = [vp, ci, C.POINTER(C.c_size_t)]
+        L.comodgan_noise_floats.argtypes = [vp, C.POINTER(C.c_size_t)]
+        L.comodgan_forward.argtypes = [vp, vp, vp, vp, ci, C.c_float, ci, vp, vp, C.c_size_t, vp]
+        L.comodgan_forward_timed.argtypes = [vp, vp, vp, vp, ci, C.c_float, ci, vp, vp, C.c_size_t, vp, fp, ci]
+        L.comodgan_num_launches.argtypes = [vp, C.POINTER(ci)]
+        L.comodgan_launch_info.argtypes = [vp, ci, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.POINTER(C.c_double),
+                                           C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        L.comodgan_set_debug.argtypes = [vp, ci]
+        L.comodgan_debug_tensor.argtypes = [vp, ci, C.c_char_p, C.POINTER(C.c_size_t), C.POINTER(C.c_int64), C.POINTER(ci)]
         L.migan_last_error.restype = C.c_char_p
         L.migan_backend.restype = C.c_char_p
         L.migan_gemm_variant.restype = C.c_char_p
@@ -205,6 +233,95 @@ class MiganHandle:
         shape = (C.c_int64 * 4)()
         self.lib.check(self.lib.lib.migan_debug_tensor(self._h, int(batch), layer.encode(), C.byref(off), shape))
         return int(off.value), tuple(int(s) for s in shape)
+
+
+class CoModGANHandle:
+    """RAII wrapper of ``comodgan_handle*`` (one CoModGANGenerator(mapping, encoder, synthesis) instance)."""
+
+    def __init__(self, lib: MiganLib, resolution: int, num_ws: int, ch_base: int = 32768, ch_max: int = 512, z_dim: int = 512,
+                 w_dim: int = 512, w0_dim: int = 1024, map_layers: int = 8, device: int = 0):
+        self.lib = lib
+        self._h = C.c_void_p()
+        self.cfg = CoModGANConfig(int(resolution), int(ch_base), int(ch_max), int(z_dim), int(w_dim), int(w0_dim), int(map_layers),
+                                  int(num_ws))
+        lib.check(lib.lib.comodgan_create(C.byref(self.cfg), int(device), C.byref(self._h)))
+
+    def close(self) -> None:
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self.lib.lib.comodgan_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def weights(self) -> List[Tuple[str, Tuple[int, ...], bool]]:
+        n = C.c_int()
+        self.lib.check(self.lib.lib.comodgan_num_weights(self._h, C.byref(n)))
+        out = []
+        for i in range(n.value):
+            name = C.c_char_p()
+            shape = (C.c_int64 * 4)()
+            nd, isb = C.c_int(), C.c_int()
+            self.lib.check(self.lib.lib.comodgan_weight_info(self._h, i, C.byref(name), shape, C.byref(nd), C.byref(isb)))
+            out.append((name.value.decode(), tuple(int(shape[k]) for k in range(nd.value)), bool(isb.value)))
+        return out
+
+    def set_weight(self, name: str, ptr: int, shape: Sequence[int]) -> None:
+        arr = (C.c_int64 * max(1, len(shape)))(*[int(s) for s in shape])
+        self.lib.check(self.lib.lib.comodgan_set_weight(self._h, name.encode(), C.c_void_p(ptr), arr, len(shape)))
+
+    def commit(self, stream: int = 0) -> None:
+        self.lib.check(self.lib.lib.comodgan_commit(self._h, C.c_void_p(stream)))
+
+    def workspace_bytes(self, batch: int) -> int:
+        n = C.c_size_t()
+        self.lib.check(self.lib.lib.comodgan_workspace_bytes(self._h, int(batch), C.byref(n)))
+        return int(n.value)
+
+    def noise_floats(self) -> int:
+        n = C.c_size_t()
+        self.lib.check(self.lib.lib.comodgan_noise_floats(self._h, C.byref(n)))
+        return int(n.value)
+
+    def forward(self, x_ptr: int, z_ptr: int, y_ptr: int, batch: int, ws_ptr: int, ws_bytes: int, truncation_psi: float = 1.0,
+                noise_mode: str = "const", noise_ptr: Optional[int] = None, stream: int = 0, timed: bool = False):
+        if noise_mode not in NOISE_MODES:
+            raise AssertionError(noise_mode)             # stylegan.py:280
+        args = [self._h, C.c_void_p(x_ptr), C.c_void_p(z_ptr), C.c_void_p(y_ptr), int(batch), C.c_float(truncation_psi),
+                NOISE_MODES[noise_mode], C.c_void_p(noise_ptr), C.c_void_p(ws_ptr), C.c_size_t(ws_bytes), C.c_void_p(stream)]
+        if not timed:
+            self.lib.check(self.lib.lib.comodgan_forward(*args))
+            return None
+        n = len(self.launches())
+        ms = (C.c_float * n)()
+        self.lib.check(self.lib.lib.comodgan_forward_timed(*args, ms, n))
+        return [float(v) for v in ms]
+
+    def launches(self) -> List[Dict]:
+        n = C.c_int()
+        self.lib.check(self.lib.lib.comodgan_num_launches(self._h, C.byref(n)))
+        out = []
+        for i in range(n.value):
+            layer, kern = C.c_char_p(), C.c_char_p()
+            fl, mf, by = C.c_double(), C.c_double(), C.c_double()
+            self.lib.check(self.lib.lib.comodgan_launch_info(self._h, i, C.byref(layer), C.byref(kern), C.byref(fl), C.byref(mf),
+                                                             C.byref(by)))
+            out.append(dict(layer=layer.value.decode(), kernel=kern.value.decode(), flops=fl.value, mfma_flops=mf.value,
+                            bytes=by.value))
+        return out
+
+    def set_debug(self, keep: bool) -> None:
+        self.lib.check(self.lib.lib.comodgan_set_debug(self._h, 1 if keep else 0))
+
+    def debug_tensor(self, batch: int, layer: str) -> Tuple[int, Tuple[int, ...]]:
+        off = C.c_size_t()
+        shape = (C.c_int64 * 4)()
+        nd = C.c_int()
+        self.lib.check(self.lib.lib.comodgan_debug_tensor(self._h, int(batch), layer.encode(), C.byref(off), shape, C.byref(nd)))
+        return int(off.value), tuple(int(shape[k]) for k in range(nd.value))
 
 
 _LIB: Optional[MiganLib] = None

@@ -14,6 +14,9 @@ SOURCES = [
     os.path.join(ROOT, "mi-gan_amd", "csrc", "migan_kernels.hpp"),
     os.path.join(ROOT, "mi-gan_amd", "csrc", "migan_host.hpp"),
     os.path.join(ROOT, "include", "migan_hip.h"),
+    os.path.join(ROOT, "mi-gan_amd", "csrc", "comodgan_kernels.hpp"),
+    os.path.join(ROOT, "mi-gan_amd", "csrc", "comodgan_host.hpp"),
+    os.path.join(ROOT, "include", "comodgan_hip.h"),
 ]
 
 

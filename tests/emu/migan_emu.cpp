@@ -3,7 +3,9 @@
 #include "hip_emu.h"
 
 #include "../../mi-gan_amd/csrc/migan_kernels.hpp"
+#include "../../mi-gan_amd/csrc/comodgan_kernels.hpp"
 #include "../../mi-gan_amd/csrc/migan_host.hpp"
+#include "../../mi-gan_amd/csrc/comodgan_host.hpp"
 
 #include <mutex>
 
