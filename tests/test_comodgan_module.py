@@ -1,0 +1,54 @@
+"""comodgan.Generator (the nn.Module drop-in for lib.model_zoo.comodgan) on the CPU side: constructor API of the
+reference's scripts/demo.py:95-106, state_dict schema, load_state_dict, errors.  No GPU involved."""
+import importlib
+import json
+import os
+
+import pytest
+import torch
+
+pkg = importlib.import_module("mi-gan_amd")
+cm = pkg.comodgan
+cs = pkg.comodgan_schema
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def build(res, **kw):
+    return cm.Generator(cm.Mapping(num_ws=cs.default_num_ws(res)), cm.Encoder(resolution=res, **kw), cm.Synthesis(resolution=res, **kw))
+
+
+def test_state_dict_schema_equals_the_reference_constructors():
+    with open(os.path.join(GOLD, "comodgan_schema.json")) as f:
+        ref = json.load(f)
+    g = build(256)          # demo.py:95-100
+    params = {k for k, _ in g.named_parameters()}
+    mine = sorted([k, list(v.shape), "param" if k in params else "buffer"] for k, v in g.state_dict().items())
+    assert mine == ref["256"]
+    assert g.num_ws == 14 and g.z_dim == 512 and g.img_resolution == 256 and g.ic_n == 4
+
+
+def test_load_state_dict_strict_and_errors():
+    cfg = cs.Config(resolution=16, ch_base=1024, ch_max=64, num_ws=cs.default_num_ws(16))
+    g = build(16, ch_base=1024, ch_max=64)
+    sd = {k: torch.from_numpy(v.copy()) for k, v in pkg.synth.make_comodgan_state_dict(cfg, 1).items()}
+    g.load_state_dict(sd, strict=True)
+    bad = dict(sd)
+    bad.pop("encoder.b4.fc.bias")
+    with pytest.raises(RuntimeError):
+        g.load_state_dict(bad, strict=True)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        g(torch.zeros(1, 4, 16, 16), z=torch.zeros(1, 512), noise_mode="const")
+    with pytest.raises(RuntimeError):
+        g(torch.zeros(1, 4, 8, 8))
+    with pytest.raises(AssertionError):
+        g(torch.zeros(1, 4, 16, 16), noise_mode="bogus")
+
+
+def test_constructor_errors_follow_the_reference():
+    with pytest.raises(ValueError):
+        cm.Encoder(resolution=48)                       # comodgan.py:134-135
+    with pytest.raises(ValueError):
+        cm.Synthesis(resolution=100)                    # comodgan.py:358-359
+    with pytest.raises(ValueError):
+        cm.Generator(cm.Mapping(num_ws=14), cm.Encoder(resolution=16, ch_base=1024, ch_max=64),
+                     cm.Synthesis(resolution=16, ch_base=1024, ch_max=64))    # num_ws mismatch, stylegan.py:606-607

@@ -80,3 +80,68 @@ def test_generator_r16_layers_and_output():
         assert err <= 2e-4 * max(1.0, np.abs(w).max()), (name, err, np.abs(w).max())
     assert np.abs(y - want).max() <= 1e-3
     assert np.abs(y - g["y"]).max() <= 1e-3          # the reference module's own output
+
+
+@pytest.mark.parametrize("tag", ["r32_c128_psi", "r64_c64"])
+def test_generator_matches_reference_golden(tag):
+    """128-column tiles, batch 2, truncation (r32); several tiles per image and 64-column tiles (r64)."""
+    g, cfg, sd, x, z = case(tag)
+    y, _, info = run_emu(cfg, sd, x, z, psi=float(g["psi"]))
+    assert np.abs(y - g["y"]).max() <= 1e-3, np.abs(y - g["y"]).max()
+    kernels = {i["kernel"] for i in info}
+    assert ("migan::cm_conv_kernel<128>" if "c128" in tag else "migan::cm_conv_kernel<64>") in kernels
+
+
+@pytest.mark.parametrize("mode", ["none", "random"])
+def test_noise_modes(mode):
+    _, cfg, sd, x, z = case("r16_c64")
+    n = x.shape[0]
+    noise = None
+    if mode == "random":
+        per_image = 16 + 2 * (64 + 256)
+        noise = pkg.synth.normal((n * per_image,), 7, "drawn-noise").astype(np.float32)
+    y, _, _ = run_emu(cfg, sd, x, z, noise_mode=mode, noise=noise)
+    want = orc.generator(x, z, sd, cfg.resolution, cfg.num_ws, noise_mode=mode, noise=noise)
+    const = orc.generator(x, z, sd, cfg.resolution, cfg.num_ws)
+    assert np.abs(y - want).max() <= 1e-3
+    assert np.abs(want - const).max() > 0.05            # the mode really changes the image
+
+
+def test_c_abi_edge_cases():
+    lib = emu_lib()
+    _, cfg, sd, x, z = case("r16_c64")
+    with pytest.raises(ValueError):
+        hb.CoModGANHandle(lib, 24, 4, 1024, 64)                      # not a power of two (comodgan.py:134-135)
+    with pytest.raises(ValueError):
+        hb.CoModGANHandle(lib, 16, 6, 1024, 96)                      # channels not a multiple of 64
+    h = hb.CoModGANHandle(lib, 16, cfg.num_ws, cfg.ch_base, cfg.ch_max)
+    keep = {k: aligned(v) for k, v in sd.items()}
+    with pytest.raises(ValueError):
+        h.set_weight("encoder.b16.conv0.weight", keep["encoder.b16.conv0.weight"].ctypes.data, (64, 64, 1, 1))   # size mismatch
+    with pytest.raises(ValueError):
+        h.set_weight("encoder.b16.conv9.weight", keep["encoder.b16.conv0.weight"].ctypes.data, (64, 64, 3, 3))   # unexpected key
+    with pytest.raises(hb.MiganError):
+        h.commit()                                                    # missing keys
+    fir = keep["synthesis.b8.resample_filter"].copy()
+    for name, shape, _ in h.weights():
+        h.set_weight(name, keep[name].ctypes.data, shape)
+    bad = aligned(fir * 2.0)
+    h.set_weight("synthesis.b8.resample_filter", bad.ctypes.data, (4, 4))
+    with pytest.raises(NotImplementedError):
+        h.commit()                                                    # not setup_filter([1,3,3,1])
+    h.set_weight("synthesis.b8.resample_filter", keep["synthesis.b8.resample_filter"].ctypes.data, (4, 4))
+    h.commit()
+    nbytes = h.workspace_bytes(1)
+    ws = np.zeros(nbytes // 4 + 64, dtype=np.float32)
+    off = (256 - ws.ctypes.data % 256) % 256 // 4
+    y = aligned(np.zeros((1, 3, 16, 16), np.float32))
+    xa, za = aligned(x[:1]), aligned(z[:1])
+    with pytest.raises(ValueError):
+        h.forward(xa.ctypes.data, za.ctypes.data, y.ctypes.data, 1, ws[off:].ctypes.data, nbytes - 256)   # workspace too small
+    with pytest.raises(ValueError):
+        h.forward(xa.ctypes.data, za.ctypes.data, y.ctypes.data, 0, ws[off:].ctypes.data, nbytes)         # empty batch
+    with pytest.raises(ValueError):
+        h.forward(xa.ctypes.data, za.ctypes.data, y.ctypes.data, 1, ws[off:].ctypes.data, nbytes, noise_mode="random")   # no noise tensor
+    with pytest.raises(ValueError):
+        h.forward(None, za.ctypes.data, y.ctypes.data, 1, ws[off:].ctypes.data, nbytes)
+    h.close()
