@@ -41,8 +41,10 @@ struct CmDebugTensor {
 inline void cm_prepare_kernels() {
   static bool done = false;
   if (done) return;
-  rt_check(rt::allow_dynamic_lds((const void*)cm_conv_kernel<64>, 160 * 1024), "hipFuncSetAttribute");
-  rt_check(rt::allow_dynamic_lds((const void*)cm_conv_kernel<128>, 160 * 1024), "hipFuncSetAttribute");
+  rt_check(rt::allow_dynamic_lds((const void*)cm_conv_kernel<64, 32, 6>, 160 * 1024), "hipFuncSetAttribute");
+  rt_check(rt::allow_dynamic_lds((const void*)cm_conv_kernel<128, 32, 6>, 160 * 1024), "hipFuncSetAttribute");
+  rt_check(rt::allow_dynamic_lds((const void*)cm_conv_kernel<64, 16, 9>, 160 * 1024), "hipFuncSetAttribute");
+  rt_check(rt::allow_dynamic_lds((const void*)cm_conv_kernel<128, 16, 9>, 160 * 1024), "hipFuncSetAttribute");
   done = true;
 }
 
@@ -194,7 +196,7 @@ inline size_t comodgan_handle::walk(int batch, const float* x, const float* z, f
   auto grid1d = [](size_t items) -> unsigned { return (unsigned)std::min<size_t>((items + kThreads - 1) / kThreads, 1u << 20); };
 
   // ---------------------------------------------------------------- weight preparation (every forward: weights are read in place)
-  struct ConvW { std::string name; int co, ci; unsigned short* planes; float* wsq; float* wn2; bool mod; };
+  struct ConvW { std::string name; int co, ci; unsigned short* planes; float* amax; float* wsq; float* wn2; bool mod; };
   std::vector<ConvW> convs;
   auto add_conv = [&](const std::string& name, int co, int ci, bool mod) {
     ConvW c;
@@ -202,6 +204,7 @@ inline size_t comodgan_handle::walk(int batch, const float* x, const float* z, f
     const size_t plane_bytes = (size_t)2 * 9 * ci * co * sizeof(unsigned short);
     unsigned short* hdr = reinterpret_cast<unsigned short*>(alloc(16 + plane_bytes));
     c.planes = hdr + kSplitHeader;
+    c.amax = alloc((size_t)co * 4);
     c.wsq = mod ? alloc((size_t)co * ci * 4) : nullptr;
     c.wn2 = mod ? alloc((size_t)co * 4) : nullptr;
     convs.push_back(c);
@@ -221,32 +224,15 @@ inline size_t comodgan_handle::walk(int batch, const float* x, const float* z, f
       if (c.name == name) return c;
     throw Error(MIGAN_EINVAL, "internal: no conv " + name);
   };
-  {
-    MIGAN_CHECK(convs.size() <= 40, MIGAN_EINVAL, "internal: too many convolution tensors for the absmax table");
-    SplitArgs sa{};
-    sa.dst = reinterpret_cast<unsigned short*>(base);
-    sa.f16 = 1;
-    double wbytes = 0;
-    for (const auto& c : convs) {
-      sa.src[sa.n] = dry ? nullptr : W(c.name + ".weight");
-      sa.dst_off[sa.n] = (unsigned long long)(c.planes - reinterpret_cast<unsigned short*>(base));
-      sa.count[sa.n] = (unsigned)((size_t)c.co * c.ci * 9);
-      sa.ci[sa.n] = (unsigned)c.ci;
-      ++sa.n;
-      wbytes += 4.0 * c.co * c.ci * 9;
-    }
-    emit("weights.absmax", "migan::weight_absmax_kernel", 0, 0, wbytes / B, weight_absmax_kernel, sa, (unsigned)sa.n, 4 * sizeof(float));
-    for (const auto& c : convs) {
-      CmSplitArgs a{};
-      a.src = dry ? nullptr : W(c.name + ".weight"); a.dst = c.planes; a.CO = c.co; a.CI = c.ci;
-      emit(c.name + ".split", "migan::cm_split_conv_kernel", 0, 0, 8.0 * c.co * c.ci * 9 / B, cm_split_conv_kernel, a,
-           grid1d((size_t)c.co * c.ci), 0);
-      if (c.mod) {
-        CmWsqArgs q{};
-        q.w = a.src; q.wsq = c.wsq; q.wn2 = c.wn2; q.CO = c.co; q.CI = c.ci;
-        emit(c.name + ".wsq", "migan::cm_wsq_kernel", 0, 0, 4.0 * c.co * c.ci * 10 / B, cm_wsq_kernel, q, (unsigned)c.co, 4 * sizeof(float));
-      }
-    }
+  for (const auto& c : convs) {
+    CmWprepArgs q{};
+    q.w = dry ? nullptr : W(c.name + ".weight"); q.amax = c.amax; q.wsq = c.wsq; q.wn2 = c.wn2; q.CO = c.co; q.CI = c.ci;
+    emit(c.name + ".wprep", "migan::cm_wprep_kernel", 0, 0, 4.0 * c.co * c.ci * (c.mod ? 10 : 9) / B, cm_wprep_kernel, q, (unsigned)c.co,
+         8 * sizeof(float));
+    CmSplitArgs a{};
+    a.src = q.w; a.amax = c.amax; a.dst = c.planes; a.CO = c.co; a.CI = c.ci;
+    emit(c.name + ".split", "migan::cm_split_conv_kernel", 0, 0, 8.0 * c.co * c.ci * 9 / B, cm_split_conv_kernel, a,
+         grid1d((size_t)c.co * c.ci), 4 * sizeof(float));
   }
 
   // ---------------------------------------------------------------- helpers for the layers
@@ -293,16 +279,20 @@ inline size_t comodgan_handle::walk(int batch, const float* x, const float* z, f
       a.oy_mul = 2; a.ox_mul = 2; a.oy_add = ey; a.ox_add = ex;
     }
     const int NT = (cw.co % 128 == 0) ? 128 : 64;
+    const int KC = mode == CM_CONV_DOWN ? 16 : 32;          // the 17x33-pixel tile of the strided mode is staged 16 channels at a time
     a.tiles_y = cdiv(a.GHn, 8); a.tiles_x = cdiv(a.GWn, 16); a.nchunks = cw.co / NT;
-    const size_t a_bytes = (size_t)2 * a.IH * a.IW * 64;
+    const size_t a_bytes = (size_t)2 * a.IH * a.IW * KC * 2;
     a.off_b = (int)((a_bytes + 127) & ~(size_t)127);
-    const size_t lds = std::max<size_t>((size_t)a.off_b + (size_t)4 * NT * 64, (size_t)128 * (NT + 4) * 4);
+    const size_t lds = std::max<size_t>((size_t)a.off_b + (size_t)4 * NT * KC * 2, (size_t)128 * (NT + 4) * 4);
     MIGAN_CHECK(lds <= 160 * 1024, MIGAN_EINVAL, "internal: LDS tile exceeds 160 KiB");
+    MIGAN_CHECK(a.IH * a.IW * (KC / 4) <= 256 * (KC == 32 ? 6 : 9), MIGAN_EINVAL, "internal: input tile exceeds the prefetch registers");
     const unsigned grid = (unsigned)((size_t)a.tiles_x * a.tiles_y * B * a.nchunks);
     const double mf = 2.0 * cw.ci * cw.co * a.ntaps * (double)a.GHn * a.GWn;
     const double by = 4.0 * ((double)cw.ci * H * Wd + (double)cw.co * a.GHn * a.GWn * (skip ? 2 : 1));
-    if (NT == 128) emit(layer, "migan::cm_conv_kernel<128>", mf, mf, by, cm_conv_kernel<128>, a, grid, lds);
-    else emit(layer, "migan::cm_conv_kernel<64>", mf, mf, by, cm_conv_kernel<64>, a, grid, lds);
+    if (KC == 32 && NT == 128) emit(layer, "migan::cm_conv_kernel<128, 32, 6>", mf, mf, by, cm_conv_kernel<128, 32, 6>, a, grid, lds);
+    else if (KC == 32) emit(layer, "migan::cm_conv_kernel<64, 32, 6>", mf, mf, by, cm_conv_kernel<64, 32, 6>, a, grid, lds);
+    else if (NT == 128) emit(layer, "migan::cm_conv_kernel<128, 16, 9>", mf, mf, by, cm_conv_kernel<128, 16, 9>, a, grid, lds);
+    else emit(layer, "migan::cm_conv_kernel<64, 16, 9>", mf, mf, by, cm_conv_kernel<64, 16, 9>, a, grid, lds);
   };
 
   // ---------------------------------------------------------------- buffers
@@ -392,7 +382,7 @@ inline size_t comodgan_handle::walk(int batch, const float* x, const float* z, f
     CmStyleArgs a{};
     a.styles = styles; a.wsq = cw.wsq; a.wn2 = cw.wn2; a.sa = m.sa; a.coef = m.coef; a.B = B; a.CI = cw.ci; a.CO = cw.co; a.demod = 1;
     emit(p + ".style", "migan::cm_style_kernel", 2.0 * cw.ci * cw.co, 0, 4.0 * ((double)cw.ci * cw.co + cw.ci + cw.co), cm_style_kernel, a,
-         (unsigned)B, (size_t)(cw.ci + 8) * 4);
+         (unsigned)(B * cdiv(cw.co, kCmStyleSlice)), (size_t)(cw.ci + 8) * 4);
     return m;
   };
   auto noise_of = [&](const std::string& p, int res, const float*& nz, long long& bstride) {

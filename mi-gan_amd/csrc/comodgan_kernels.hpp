@@ -24,7 +24,7 @@
 //   cm_fromrgb_kernel   1x1 conv 4 -> C with bias and activation, NCHW planes -> NHWC
 //   cm_torgb_kernel     modulated 1x1 conv C -> 3 (no demodulation) + bias + 2x FIR upsample of the running image
 //   cm_dense_kernel     fully connected layers (mapping, affine, encoder fc, synthesis fc): weight streaming, fp32 FMA
-//   cm_wsq_kernel       per-tensor demodulation statistics (sum over taps of w^2, per-output-channel normalisation)
+//   cm_wprep_kernel     per-tensor statistics: max |w| per output channel (fp16 range scale), demodulation sums of w^2
 //   cm_style_kernel     styles -> normalised input scales (with the per-sample power-of-two fp16 range scale) and
 //                       demodulation coefficients, or (ToRGB) the per-sample modulated 1x1 weights
 //   cm_split_conv_kernel  3x3 weights -> two fp16 planes, [plane][tap][Cin/32][Cout][32]
@@ -42,7 +42,7 @@ struct CmConvArgs {
   const float* x;               // NHWC [B][H][W][CI]
   float* y;                     // NHWC [B][HO][WO][CO]
   const float* skip;            // NHWC like y, added after the activation, or null
-  const unsigned short* wsplit; // fp16 planes [2][9][CI/32][CO][32] behind a 16-byte header (weight_absmax_kernel)
+  const unsigned short* wsplit; // fp16 planes [2][9][CI/32][CO][32] behind a 16-byte header (cm_split_conv_kernel)
   const float* sa;              // [B][CI] per-sample input scale (normalised style x 2^e) or null -> a_scale
   const float* coef;            // [B][CO] per-sample output coefficient or null -> cgain
   const float* bias;            // [CO]
@@ -62,16 +62,26 @@ struct CmConvArgs {
   int off_b, off_g;             // LDS carve in bytes: B tile buffers; the result tile aliases everything
 };
 
-// fp32 x 4 -> LDS A/B plane position: 64-byte rows (32 fp16), 16-byte slots XOR-swizzled by (row >> 2) & 3 so that
-// 16 consecutive rows of one slot cover all 64 banks
-MIGAN_DEVICE MIGAN_INLINE int cm_slot_off(int row, int slot) { return row * 64 + ((slot ^ ((row >> 2) & 3)) << 4); }
+// LDS A/B plane position: rows of KC fp16 (64 or 32 bytes), 16-byte slots XOR-swizzled by the row index so that 16
+// consecutive rows of one slot spread over all 64 banks
+template <int KC>
+MIGAN_DEVICE MIGAN_INLINE int cm_slot_off(int row, int slot) {
+  if constexpr (KC == 32) return row * 64 + ((slot ^ ((row >> 2) & 3)) << 4);
+  else return row * 32 + ((slot ^ ((row >> 3) & 1)) << 4);
+}
 
-template <int NT>
+//   NT  : output channels per workgroup (64 / 128)
+//   KC  : input channels per K chunk (32; 16 for the strided mode, whose 17x33-pixel input tile would otherwise
+//         leave room for one workgroup per CU only)
+//   NIA : float4 input-tile items per thread per chunk = ceil(tile pixels * KC/4 / 256) (prefetch registers)
+template <int NT, int KC, int NIA>
 MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, 2) cm_conv_kernel(const CmConvArgs p) {
   MIGAN_DYN_SMEM(smem);
-  constexpr int MT = 128, KC = 32, GW = 16;
+  constexpr int MT = 128, GW = 16;
   constexpr int WCOLS = NT / 2, NTI = WCOLS / 32, MTI = 2;
   constexpr int GS = NT + 4;
+  constexpr int RB = KC * 2;                                  // bytes per LDS row (one plane)
+  constexpr int NSLOT = KC / 8, QK = KC / 4;                  // 16-byte slots / float4 quads per row
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, half = lane >> 5;
 
@@ -87,11 +97,11 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, 2) cm_conv_kernel(const CmConvArgs p)
   const int npix = p.IH * p.IW;
   const int nck = p.CI / KC;
 
-  char* a_s = reinterpret_cast<char*>(smem);                  // [2 planes][npix][64 B]
-  char* b_s = reinterpret_cast<char*>(smem) + p.off_b;        // [2 buffers][2 planes][NT][64 B]
+  char* a_s = reinterpret_cast<char*>(smem);                  // [2 planes][npix][RB]
+  char* b_s = reinterpret_cast<char*>(smem) + p.off_b;        // [2 buffers][2 planes][NT][RB]
   float* g_s = smem;                                          // [MT][GS] after the K loop
-  const int a_plane = npix * 64;
-  constexpr int b_plane = NT * 64, b_buf = 2 * b_plane;
+  const int a_plane = npix * RB;
+  constexpr int b_plane = NT * RB, b_buf = 2 * b_plane;
 
   const float* __restrict__ xb = p.x + (size_t)b * p.H * p.W * p.CI;
   const float* __restrict__ sab = p.sa ? p.sa + (size_t)b * p.CI : nullptr;
@@ -106,85 +116,119 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, 2) cm_conv_kernel(const CmConvArgs p)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-  // B tile of iteration `it` (chunk-major over taps): rows co0..co0+NT-1 of [tap][chunk][CO][32], both planes
-  constexpr int BPIECES = 2 * NT * 4 / 256;                   // 16-byte pieces per thread
+  // ---- input-tile items of this thread: item = tid + k*256 -> pixel q = item / QK, channel quad c4 = item % QK
+  // (c4 is the same for every k).  goff = element offset of the pixel's channel 0 in the image, -1 = zero padding / no item.
+  const int c4 = tid & (QK - 1);
+  int goff[NIA];
+#pragma unroll
+  for (int k = 0; k < NIA; ++k) {
+    const int q = (tid + k * 256) / QK;
+    const int py = q / p.IW, px = q - py * p.IW;
+    const int iy = iy0 + py, ix = ix0 + px;
+    goff[k] = (q < npix && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) ? (iy * p.W + ix) * p.CI + c4 * 4 : -1;
+  }
+  f4 areg[NIA];
+  auto load_a = [&](int c) {
+#pragma unroll
+    for (int k = 0; k < NIA; ++k) {
+      areg[k] = f4{0.f, 0.f, 0.f, 0.f};
+      if (goff[k] >= 0) areg[k] = ld4(xb + (size_t)(unsigned)goff[k] + c * KC);
+    }
+  };
+  auto store_a = [&](int c) {
+    f4 sc = f4{p.a_scale, p.a_scale, p.a_scale, p.a_scale};
+    if (sab) sc = ld4(sab + c * KC + c4 * 4);
+#pragma unroll
+    for (int k = 0; k < NIA; ++k) {
+      const int q = (tid + k * 256) / QK;
+      if (q < npix) {
+        u2v h1, h2;
+        split2_f16(areg[k] * sc, h1, h2);
+        char* dst = a_s + cm_slot_off<KC>(q, c4 >> 1) + (c4 & 1) * 8;
+        *reinterpret_cast<u2v*>(dst) = h1;
+        *reinterpret_cast<u2v*>(dst + a_plane) = h2;
+      }
+    }
+  };
+
+  // B tile of iteration `it` (chunk-major over taps): rows co0..co0+NT-1 of [tap][CI/32][CO][32], both planes
+  constexpr int BPIECES = 2 * NT * NSLOT / 256;               // 16-byte pieces per thread
   f4 breg[BPIECES];
   auto load_b = [&](int it) {
     const int c = it / p.ntaps, tp = p.wtap[it % p.ntaps];
-    const unsigned short* src = p.wsplit + ((size_t)(tp * nck + c) * p.CO + co0) * 32;
+    const int c32 = (c * KC) >> 5, hc = ((c * KC) & 31) >> 3;  // 32-channel chunk of the planes, first 16-byte slot inside it
+    const unsigned short* src = p.wsplit + ((size_t)(tp * (p.CI >> 5) + c32) * p.CO + co0) * 32;
 #pragma unroll
     for (int k = 0; k < BPIECES; ++k) {
       const int piece = tid + k * 256;                        // [plane][row][slot]
-      const int pl = piece / (NT * 4), rs = piece % (NT * 4);
-      breg[k] = ld4(reinterpret_cast<const float*>(src + pl * w_plane + rs * 8));
+      const int pl = piece / (NT * NSLOT), rs = piece % (NT * NSLOT);
+      const int row = rs / NSLOT, slot = rs % NSLOT;
+      breg[k] = ld4(reinterpret_cast<const float*>(src + pl * w_plane + row * 32 + (hc + slot) * 8));
     }
   };
   auto store_b = [&](int buf) {
 #pragma unroll
     for (int k = 0; k < BPIECES; ++k) {
       const int piece = tid + k * 256;
-      const int pl = piece / (NT * 4), rs = piece % (NT * 4);
-      const int row = rs >> 2, slot = rs & 3;
-      st4(reinterpret_cast<float*>(b_s + buf * b_buf + pl * b_plane + cm_slot_off(row, slot)), breg[k]);
+      const int pl = piece / (NT * NSLOT), rs = piece % (NT * NSLOT);
+      const int row = rs / NSLOT, slot = rs % NSLOT;
+      st4(reinterpret_cast<float*>(b_s + buf * b_buf + pl * b_plane + cm_slot_off<KC>(row, slot)), breg[k]);
     }
   };
 
-  load_b(0);
-  store_b(0);
-  for (int c = 0; c < nck; ++c) {
-    // ---- stage the input halo tile of channel chunk c: global fp32 -> x style scale -> two fp16 planes in LDS
-    for (int item = tid; item < npix * 8; item += 256) {
-      const int q = item >> 3, c4 = item & 7;
-      const int py = q / p.IW, px = q - py * p.IW;
-      const int iy = iy0 + py, ix = ix0 + px;
-      f4 v = f4{0.f, 0.f, 0.f, 0.f};
-      if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) {
-        v = ld4(xb + ((size_t)iy * p.W + ix) * p.CI + c * KC + c4 * 4);
-        if (sab) v = v * ld4(sab + c * KC + c4 * 4);
-        else v = v * p.a_scale;
+  // One filter tap of channel chunk c: issue the next weight tile's loads (and, on the last tap of the chunk, the next
+  // chunk's input-tile loads: they fly under this tap's MFMAs and are consumed by store_a right after the barrier),
+  // MFMAs of this tap from LDS, next weight tile -> LDS, barrier.  The prefetches are unconditional (the last ones
+  // re-load the last tile) so that no branch sits between a load and its use.
+  auto tap_body = [&](int c, int tp, auto prefetch_a) {
+    const int it = c * p.ntaps + tp;
+    load_b(it + 1 < total ? it + 1 : it);
+    if constexpr (decltype(prefetch_a)::value) load_a(c + 1 < nck ? c + 1 : c);
+    MIGAN_SCHED_FENCE();        // keep the loads ahead of the MFMAs (the scheduler otherwise sinks them to their use)
+    const char* bb = b_s + (it & 1) * b_buf;
+    const int oy = p.dy[tp] - p.dymin, ox = p.dx[tp] - p.dxmin;
+#pragma unroll
+    for (int ks = 0; ks < KC / 16; ++ks) {
+      f4 av[MTI][2], bv[NTI][2];
+#pragma unroll
+      for (int i = 0; i < MTI; ++i) {
+        const int m = wm * 64 + i * 32 + l31;
+        const int q = ((m >> 4) * p.stride + oy) * p.IW + (m & 15) * p.stride + ox;
+        const char* qa = a_s + cm_slot_off<KC>(q, 2 * ks + half);
+        av[i][0] = ld4(reinterpret_cast<const float*>(qa));
+        av[i][1] = ld4(reinterpret_cast<const float*>(qa + a_plane));
       }
-      u2v h1, h2;
-      split2_f16(v, h1, h2);
-      char* dst = a_s + cm_slot_off(q, c4 >> 1) + (c4 & 1) * 8;
-      *reinterpret_cast<u2v*>(dst) = h1;
-      *reinterpret_cast<u2v*>(dst + a_plane) = h2;
-    }
-    __syncthreads();
-    for (int tp = 0; tp < p.ntaps; ++tp) {
-      const int it = c * p.ntaps + tp;
-      if (it + 1 < total) load_b(it + 1);
-      const char* bb = b_s + (it & 1) * b_buf;
-      const int oy = p.dy[tp] - p.dymin, ox = p.dx[tp] - p.dxmin;
 #pragma unroll
-      for (int ks = 0; ks < KC / 16; ++ks) {
-        f4 av[MTI][2], bv[NTI][2];
+      for (int j = 0; j < NTI; ++j) {
+        const int row = wn * WCOLS + j * 32 + l31;
+        const char* qb = bb + cm_slot_off<KC>(row, 2 * ks + half);
+        bv[j][0] = ld4(reinterpret_cast<const float*>(qb));
+        bv[j][1] = ld4(reinterpret_cast<const float*>(qb + b_plane));
+      }
+      // product-major order: consecutive MFMAs write different accumulators (a dependent MFMA issued straight after
+      // its producer waits out the 16-pass latency), smallest products first
 #pragma unroll
-        for (int i = 0; i < MTI; ++i) {
-          const int m = wm * 64 + i * 32 + l31;
-          const int q = ((m >> 4) * p.stride + oy) * p.IW + (m & 15) * p.stride + ox;
-          const char* qa = a_s + cm_slot_off(q, 2 * ks + half);
-          av[i][0] = ld4(reinterpret_cast<const float*>(qa));
-          av[i][1] = ld4(reinterpret_cast<const float*>(qa + a_plane));
-        }
-#pragma unroll
-        for (int j = 0; j < NTI; ++j) {
-          const int row = wn * WCOLS + j * 32 + l31;
-          const char* qb = bb + cm_slot_off(row, 2 * ks + half);
-          bv[j][0] = ld4(reinterpret_cast<const float*>(qb));
-          bv[j][1] = ld4(reinterpret_cast<const float*>(qb + b_plane));
-        }
+      for (int pr = 0; pr < 3; ++pr)
 #pragma unroll
         for (int i = 0; i < MTI; ++i)
 #pragma unroll
-          for (int j = 0; j < NTI; ++j) {
-            acc[i][j] = MIGAN_MFMA_F16_32X32X16(av[i][1], bv[j][0], acc[i][j]);
-            acc[i][j] = MIGAN_MFMA_F16_32X32X16(av[i][0], bv[j][1], acc[i][j]);
-            acc[i][j] = MIGAN_MFMA_F16_32X32X16(av[i][0], bv[j][0], acc[i][j]);
-          }
-      }
-      if (it + 1 < total) store_b((it + 1) & 1);
-      __syncthreads();
+          for (int j = 0; j < NTI; ++j)
+            acc[i][j] = MIGAN_MFMA_F16_32X32X16(av[i][pr == 0 ? 1 : 0], bv[j][pr == 1 ? 1 : 0], acc[i][j]);
     }
+    MIGAN_SCHED_FENCE();
+    store_b((it + 1) & 1);
+    __syncthreads();
+  };
+
+  load_a(0);
+  load_b(0);
+  store_b(0);
+  for (int c = 0; c < nck; ++c) {
+    // input halo tile of channel chunk c: registers -> x style scale -> two fp16 planes in LDS
+    store_a(c);
+    __syncthreads();
+    for (int tp = 0; tp + 1 < p.ntaps; ++tp) tap_body(c, tp, FalseT{});
+    tap_body(c, p.ntaps - 1, TrueT{});
   }
 
   // ---- epilogue: accumulators -> LDS result tile -> per float4: coefficient, noise, bias, activation, skip
@@ -199,38 +243,95 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, 2) cm_conv_kernel(const CmConvArgs p)
         g_s[row * GS + col] = acc[i][j][r];
       }
   __syncthreads();
-  const float inv_wscale = 1.0f / reinterpret_cast<const float*>(p.wsplit)[-2];      // power of two (weight_absmax_kernel)
+  const float inv_wscale = 1.0f / reinterpret_cast<const float*>(p.wsplit)[-2];      // power of two (cm_split_conv_kernel)
   const float ns = p.noise ? p.noise_strength[0] : 0.0f;
   constexpr int QN = NT / 4;
   for (int item = tid; item < MT * QN; item += 256) {
-    const int c4 = item % QN, m = item / QN;
+    const int q4 = item % QN, m = item / QN;
     const int gy = gy0 + (m >> 4), gx = gx0 + (m & 15);
     if (gy >= p.GHn || gx >= p.GWn) continue;
     const int oy = gy * p.oy_mul + p.oy_add, ox = gx * p.ox_mul + p.ox_add;
-    const int co = co0 + c4 * 4;
+    const int co = co0 + q4 * 4;
     f4 cf = p.coef ? ld4(p.coef + (size_t)b * p.CO + co) : f4{p.cgain, p.cgain, p.cgain, p.cgain};
     cf = cf * inv_wscale;
-    f4 v = ld4(g_s + m * GS + c4 * 4) * cf;
+    f4 v = ld4(g_s + m * GS + q4 * 4) * cf;
     const size_t o = (((size_t)b * p.HO + oy) * p.WO + ox) * p.CO + co;
     if (!p.raw) {
       if (p.noise) v = v + MIGAN_FMUL_RN(p.noise[(size_t)b * p.noise_bstride + (size_t)oy * p.WO + ox], ns);
       v = act4(v + ld4(p.bias + co));
-      if (p.skip) v = v + ld4(p.skip + o);
+      if (p.skip) v = v + ld4once(p.skip + o);
     }
-    st4(p.y + o, v);
+    st4o(p.y + o, v);
   }
 }
 
 // ------------------------------------------------------------------------------------------------
-// 3x3 weights [CO][CI][3][3] fp32 -> two fp16 planes [plane][tap][CI/32][CO][32] of w * wscale (wscale: the power of
-// two in the header that weight_absmax_kernel wrote, max|w| -> [2^13, 2^14)).
+// Per-tensor statistics of one 3x3 weight tensor, one workgroup per output channel:
+//   amax[co]     = max |w[co]|                       (fp16 range scale of the split GEMM operands)
+//   wsq[co][ci]  = sum_k w^2, wn2[co] = 1 / mean_{ci,k} w^2    (demodulation, stylegan.py:138,147; modulated layers only)
+struct CmWprepArgs {
+  const float* w;      // [CO][CI][3][3]
+  float* amax;         // [CO]
+  float* wsq;          // [CO][CI] or null
+  float* wn2;          // [CO] or null
+  int CO, CI;
+};
+MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, 2) cm_wprep_kernel(const CmWprepArgs p) {
+  MIGAN_DYN_SMEM(red);
+  const int co = (int)blockIdx.x;
+  float tot = 0.0f, mx = 0.0f;
+  for (int ci = threadIdx.x; ci < p.CI; ci += 256) {
+    const float* s = p.w + ((size_t)co * p.CI + ci) * 9;
+    float a = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+      a += s[k] * s[k];
+      mx = fmaxf(mx, fabsf(s[k]));
+    }
+    if (p.wsq) p.wsq[(size_t)co * p.CI + ci] = a;
+    tot += a;
+  }
+#pragma unroll
+  for (int sft = 32; sft >= 1; sft >>= 1) {
+    tot += __shfl_xor(tot, sft);
+    mx = fmaxf(mx, __shfl_xor(mx, sft));
+  }
+  if ((threadIdx.x & 63) == 0) {
+    red[threadIdx.x >> 6] = tot;
+    red[4 + (threadIdx.x >> 6)] = mx;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    if (p.wn2) p.wn2[co] = (float)(p.CI * 9) / (red[0] + red[1] + red[2] + red[3]);
+    p.amax[co] = fmaxf(fmaxf(red[4], red[5]), fmaxf(red[6], red[7]));
+  }
+}
+
+// 3x3 weights [CO][CI][3][3] fp32 -> two fp16 planes [plane][tap][CI/32][CO][32] of w * wscale, wscale = the power of
+// two that maps max|w| into [2^13, 2^14) (every workgroup derives it from amax[]; workgroup 0 also writes it to the
+// 16-byte header in front of plane 0, float [2], where cm_conv_kernel reads it).
 struct CmSplitArgs {
   const float* src;
+  const float* amax;          // [CO]
   unsigned short* dst;        // plane 0; a 16-byte header precedes it
   int CO, CI;
 };
 MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, 2) cm_split_conv_kernel(const CmSplitArgs p) {
-  const float sw = reinterpret_cast<const float*>(p.dst)[-2];
+  MIGAN_DYN_SMEM(red);
+  float m = 0.0f;
+  for (int i = threadIdx.x; i < p.CO; i += 256) m = fmaxf(m, p.amax[i]);
+#pragma unroll
+  for (int sft = 32; sft >= 1; sft >>= 1) m = fmaxf(m, __shfl_xor(m, sft));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  int e = (int)((__builtin_bit_cast(unsigned, m) >> 23) & 0xffu) - 127;       // floor(log2(max|w|))
+  e = e < -100 ? -100 : (e > 100 ? 100 : e);
+  const float sw = __builtin_bit_cast(float, (unsigned)(127 + 13 - e) << 23);
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    float* hdr = reinterpret_cast<float*>(p.dst) - 4;
+    hdr[0] = 1.0f / sw; hdr[1] = m; hdr[2] = sw; hdr[3] = 0.0f;
+  }
   const size_t plane = (size_t)9 * p.CI * p.CO;
   const size_t n = (size_t)p.CO * p.CI;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
@@ -247,34 +348,6 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, 2) cm_split_conv_kernel(const CmSplit
       p.dst[plane + o] = (unsigned short)(pk2 & 0xffffu);
     }
   }
-}
-
-// ------------------------------------------------------------------------------------------------
-// Demodulation statistics of one 3x3 weight tensor (stylegan.py:138,147): wsq[co][ci] = sum_k w^2,
-// wn2[co] = 1 / mean_{ci,k} w^2.  One workgroup per output channel.
-struct CmWsqArgs {
-  const float* w;      // [CO][CI][3][3]
-  float* wsq;          // [CO][CI]
-  float* wn2;          // [CO]
-  int CO, CI;
-};
-MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, 2) cm_wsq_kernel(const CmWsqArgs p) {
-  MIGAN_DYN_SMEM(red);
-  const int co = (int)blockIdx.x;
-  float tot = 0.0f;
-  for (int ci = threadIdx.x; ci < p.CI; ci += 256) {
-    const float* s = p.w + ((size_t)co * p.CI + ci) * 9;
-    float a = 0.0f;
-#pragma unroll
-    for (int k = 0; k < 9; ++k) a += s[k] * s[k];
-    p.wsq[(size_t)co * p.CI + ci] = a;
-    tot += a;
-  }
-#pragma unroll
-  for (int sft = 32; sft >= 1; sft >>= 1) tot += __shfl_xor(tot, sft);
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = tot;
-  __syncthreads();
-  if (threadIdx.x == 0) p.wn2[co] = (float)(p.CI * 9) / (red[0] + red[1] + red[2] + red[3]);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -295,17 +368,22 @@ struct CmStyleArgs {
   float wgain;
   int B, CI, CO, demod;
 };
+constexpr int kCmStyleSlice = 16;       // output channels per workgroup (demod); grid = B * ceil(CO / 16)
 MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, 2) cm_style_kernel(const CmStyleArgs p) {
   MIGAN_DYN_SMEM(sm);            // [CI] s~^2 of this sample, then 8 floats of reduction scratch
-  const int b = (int)blockIdx.x, tid = threadIdx.x;
-  const float* st = p.styles + (size_t)b * p.CI;
+  const int tid = threadIdx.x;
   if (!p.demod) {
+    const int b = (int)blockIdx.x;
+    const float* st = p.styles + (size_t)b * p.CI;
     for (int i = tid; i < 3 * p.CI; i += 256) {
       const int ci = i % p.CI;
       p.wm[(size_t)b * 3 * p.CI + i] = p.w[i] * (st[ci] * p.wgain);
     }
     return;
   }
+  const int nsl = (p.CO + kCmStyleSlice - 1) / kCmStyleSlice;
+  const int b = (int)blockIdx.x / nsl, sl = (int)blockIdx.x % nsl;
+  const float* st = p.styles + (size_t)b * p.CI;
   float* red = sm + p.CI;
   float ss = 0.0f;
   for (int i = tid; i < p.B * p.CI; i += 256) ss += p.styles[i] * p.styles[i];
@@ -331,10 +409,13 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, 2) cm_style_kernel(const CmStyleArgs 
   const int e = 6 - (ex + 1);                                                      // mx < 2^(ex+1)
   const float up = __builtin_bit_cast(float, (unsigned)(127 + e) << 23);
   const float dn = __builtin_bit_cast(float, (unsigned)(127 - e) << 23);
-  for (int ci = tid; ci < p.CI; ci += 256) p.sa[(size_t)b * p.CI + ci] = st[ci] * g * up;
-  // one wave per output channel: sum_ci s~^2 wsq[co][ci]
+  if (sl == 0)
+    for (int ci = tid; ci < p.CI; ci += 256) p.sa[(size_t)b * p.CI + ci] = st[ci] * g * up;
+  // one wave per output channel of the slice: sum_ci s~^2 wsq[co][ci]
   const int lane = tid & 63, wave = tid >> 6;
-  for (int co = wave; co < p.CO; co += 4) {
+  for (int k = wave; k < kCmStyleSlice; k += 4) {
+    const int co = sl * kCmStyleSlice + k;
+    if (co >= p.CO) break;
     const float* wq = p.wsq + (size_t)co * p.CI;
     float a = 0.0f;
     for (int ci = lane; ci < p.CI; ci += 64) a += sm[ci] * wq[ci];
