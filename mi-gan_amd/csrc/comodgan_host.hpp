@@ -41,10 +41,12 @@ struct CmDebugTensor {
 inline void cm_prepare_kernels() {
   static bool done = false;
   if (done) return;
-  rt_check(rt::allow_dynamic_lds((const void*)cm_conv_kernel<64, 32, 6>, 160 * 1024), "hipFuncSetAttribute");
-  rt_check(rt::allow_dynamic_lds((const void*)cm_conv_kernel<128, 32, 6>, 160 * 1024), "hipFuncSetAttribute");
-  rt_check(rt::allow_dynamic_lds((const void*)cm_conv_kernel<64, 16, 9>, 160 * 1024), "hipFuncSetAttribute");
-  rt_check(rt::allow_dynamic_lds((const void*)cm_conv_kernel<128, 16, 9>, 160 * 1024), "hipFuncSetAttribute");
+  rt_check(rt::allow_dynamic_lds((const void*)cm_conv_kernel<64, 32, 6, false>, 160 * 1024), "hipFuncSetAttribute");
+  rt_check(rt::allow_dynamic_lds((const void*)cm_conv_kernel<128, 32, 6, false>, 160 * 1024), "hipFuncSetAttribute");
+  rt_check(rt::allow_dynamic_lds((const void*)cm_conv_kernel<64, 32, 6, true>, 160 * 1024), "hipFuncSetAttribute");
+  rt_check(rt::allow_dynamic_lds((const void*)cm_conv_kernel<128, 32, 6, true>, 160 * 1024), "hipFuncSetAttribute");
+  rt_check(rt::allow_dynamic_lds((const void*)cm_conv_kernel<64, 16, 9, true>, 160 * 1024), "hipFuncSetAttribute");
+  rt_check(rt::allow_dynamic_lds((const void*)cm_conv_kernel<128, 16, 9, true>, 160 * 1024), "hipFuncSetAttribute");
   done = true;
 }
 
@@ -281,18 +283,24 @@ inline size_t comodgan_handle::walk(int batch, const float* x, const float* z, f
     const int NT = (cw.co % 128 == 0) ? 128 : 64;
     const int KC = mode == CM_CONV_DOWN ? 16 : 32;          // the 17x33-pixel tile of the strided mode is staged 16 channels at a time
     a.tiles_y = cdiv(a.GHn, 8); a.tiles_x = cdiv(a.GWn, 16); a.nchunks = cw.co / NT;
-    const size_t a_bytes = (size_t)2 * a.IH * a.IW * KC * 2;
+    const size_t pitch = (size_t)4 * KC + 16;                // LDS row: both fp16 planes of KC channels + 16 bytes of padding
+    const size_t a_bytes = (size_t)a.IH * a.IW * pitch;
     a.off_b = (int)((a_bytes + 127) & ~(size_t)127);
-    const size_t lds = std::max<size_t>((size_t)a.off_b + (size_t)4 * NT * KC * 2, (size_t)128 * (NT + 4) * 4);
+    const size_t lds = std::max<size_t>((size_t)a.off_b + (size_t)2 * NT * pitch, (size_t)128 * (NT + 4) * 4);
     MIGAN_CHECK(lds <= 160 * 1024, MIGAN_EINVAL, "internal: LDS tile exceeds 160 KiB");
     MIGAN_CHECK(a.IH * a.IW * (KC / 4) <= 256 * (KC == 32 ? 6 : 9), MIGAN_EINVAL, "internal: input tile exceeds the prefetch registers");
     const unsigned grid = (unsigned)((size_t)a.tiles_x * a.tiles_y * B * a.nchunks);
     const double mf = 2.0 * cw.ci * cw.co * a.ntaps * (double)a.GHn * a.GWn;
     const double by = 4.0 * ((double)cw.ci * H * Wd + (double)cw.co * a.GHn * a.GWn * (skip ? 2 : 1));
-    if (KC == 32 && NT == 128) emit(layer, "migan::cm_conv_kernel<128, 32, 6>", mf, mf, by, cm_conv_kernel<128, 32, 6>, a, grid, lds);
-    else if (KC == 32) emit(layer, "migan::cm_conv_kernel<64, 32, 6>", mf, mf, by, cm_conv_kernel<64, 32, 6>, a, grid, lds);
-    else if (NT == 128) emit(layer, "migan::cm_conv_kernel<128, 16, 9>", mf, mf, by, cm_conv_kernel<128, 16, 9>, a, grid, lds);
-    else emit(layer, "migan::cm_conv_kernel<64, 16, 9>", mf, mf, by, cm_conv_kernel<64, 16, 9>, a, grid, lds);
+    const bool nine = a.ntaps == 9;
+    MIGAN_CHECK(!nine || (cw.ci / KC) % 2 == 0, MIGAN_EINVAL, "internal: the nine-tap kernel walks channel chunks in pairs");
+    MIGAN_CHECK(nine || KC == 32, MIGAN_EINVAL, "internal: no generic-tap-list kernel with 16-channel chunks");
+    if (nine && KC == 32 && NT == 128) emit(layer, "migan::cm_conv_kernel<128, 32, 6, true>", mf, mf, by, cm_conv_kernel<128, 32, 6, true>, a, grid, lds);
+    else if (nine && KC == 32) emit(layer, "migan::cm_conv_kernel<64, 32, 6, true>", mf, mf, by, cm_conv_kernel<64, 32, 6, true>, a, grid, lds);
+    else if (nine && NT == 128) emit(layer, "migan::cm_conv_kernel<128, 16, 9, true>", mf, mf, by, cm_conv_kernel<128, 16, 9, true>, a, grid, lds);
+    else if (nine) emit(layer, "migan::cm_conv_kernel<64, 16, 9, true>", mf, mf, by, cm_conv_kernel<64, 16, 9, true>, a, grid, lds);
+    else if (NT == 128) emit(layer, "migan::cm_conv_kernel<128, 32, 6, false>", mf, mf, by, cm_conv_kernel<128, 32, 6, false>, a, grid, lds);
+    else emit(layer, "migan::cm_conv_kernel<64, 32, 6, false>", mf, mf, by, cm_conv_kernel<64, 32, 6, false>, a, grid, lds);
   };
 
   // ---------------------------------------------------------------- buffers
@@ -352,10 +360,10 @@ inline size_t comodgan_handle::walk(int batch, const float* x, const float* z, f
       conv(b + ".conv0", CM_CONV_NORMAL, 0, 0, cur, f, nullptr, w0c, nullptr, nullptr, 1.0f / std::sqrt(9.0f * c),
            dry ? nullptr : W(b + ".conv0.bias"), nullptr, nullptr, 0, res, res, res, res, false);
       {
-        CmBlurArgs a{};
-        a.x = f; a.y = tmp; a.B = B; a.H = res; a.W = res; a.C = c; a.HO = res + 1; a.WO = res + 1; a.pad = 2;
-        emit(b + ".conv1.fir", "migan::cm_blur_kernel", 2.0 * 16 * c * (res + 1) * (res + 1), 0, 4.0 * c * (2.0 * res * res + 2 * res + 1),
-             cm_blur_kernel, a, grid1d((size_t)B * (res + 1) * (res + 1) * (c / 4)), 0);
+        CmFirArgs a{};
+        a.x = f; a.y = tmp; a.B = B; a.H = res; a.W = res; a.C = c; a.HO = res + 1; a.WO = res + 1; a.pad = 2; a.fs = 0.125f;
+        emit(b + ".conv1.fir", "migan::cm_fir_kernel<0>", 2.0 * 16 * c * (res + 1) * (res + 1), 0, 4.0 * c * (2.0 * res * res + 2 * res + 1),
+             cm_fir_kernel<0>, a, grid1d((size_t)B * cdiv(res + 1, 2) * cdiv(res + 1, 4) * (c / 4)), 0);
       }
       float* out = act_out(b + ".conv1", bufA, res / 2, cn);
       conv(b + ".conv1", CM_CONV_DOWN, 0, 0, tmp, out, nullptr, w1c, nullptr, nullptr, 1.0f / std::sqrt(9.0f * c),
@@ -374,10 +382,42 @@ inline size_t comodgan_handle::walk(int batch, const float* x, const float* z, f
   // ---------------------------------------------------------------- synthesis (comodgan.py:395-420)
   const int wl = cfg.w_dim + cfg.w0_dim;
   size_t noise_off = 0;                     // floats per image into the caller's random-noise blob
+  // every affine layer (styles = affine(cat([w, w0])), stylegan.py:282,337) in one launch, ahead of the synthesis blocks
+  struct Affine { std::string name; int c; float* styles; };
+  std::vector<Affine> affines;
+  {
+    auto add_aff = [&](const std::string& p, int c) { affines.push_back({p, c, alloc((size_t)B * c * 4)}); };
+    add_aff("synthesis.b4.conv", channels(4));
+    add_aff("synthesis.b4.torgb", channels(4));
+    for (int res = 8; res <= R; res *= 2) {
+      add_aff(bname("synthesis", res) + ".conv0", channels(res / 2));
+      add_aff(bname("synthesis", res) + ".conv1", channels(res));
+      add_aff(bname("synthesis", res) + ".torgb", channels(res));
+    }
+    MIGAN_CHECK((int)affines.size() <= kCmMaxAffine, MIGAN_EINVAL, "internal: too many affine layers");
+    CmDenseMultiArgs a{};
+    double fl = 0;
+    int blk = 0;
+    for (const auto& af : affines) {
+      a.w[a.njobs] = dry ? nullptr : W(af.name + ".affine.weight");
+      a.b[a.njobs] = dry ? nullptr : W(af.name + ".affine.bias");
+      a.y[a.njobs] = af.styles; a.O[a.njobs] = af.c; a.blk0[a.njobs] = blk;
+      blk += cdiv(af.c, 8);
+      fl += 2.0 * wl * af.c;
+      ++a.njobs;
+    }
+    a.blk0[a.njobs] = blk;
+    a.x = wlat; a.x2 = w0; a.wgain = 1.0f / std::sqrt((float)wl); a.N = B; a.K = wl; a.K1 = cfg.w_dim;
+    emit("synthesis.affine", "migan::cm_dense_multi_kernel", fl, 0, 2.0 * fl / B, cm_dense_multi_kernel, a, (unsigned)blk, 0);
+  }
+  auto styles_of = [&](const std::string& p) -> float* {
+    for (const auto& af : affines)
+      if (af.name == p) return af.styles;
+    throw Error(MIGAN_EINVAL, "internal: no affine " + p);
+  };
   struct Mod { float* sa; float* coef; };
   auto style_demod = [&](const std::string& p, const ConvW& cw) -> Mod {
-    float* styles = alloc((size_t)B * cw.ci * 4);
-    dense(p + ".affine", wlat, w0, wl, cfg.w_dim, p + ".affine", cw.ci, styles, 1.0f, false, false, 0, 0, nullptr, nullptr);
+    float* styles = styles_of(p);
     Mod m{alloc((size_t)B * cw.ci * 4), alloc((size_t)B * cw.co * 4)};
     CmStyleArgs a{};
     a.styles = styles; a.wsq = cw.wsq; a.wn2 = cw.wn2; a.sa = m.sa; a.coef = m.coef; a.B = B; a.CI = cw.ci; a.CO = cw.co; a.demod = 1;
@@ -392,8 +432,7 @@ inline size_t comodgan_handle::walk(int batch, const float* x, const float* z, f
     noise_off += (size_t)res * res;
   };
   auto torgb = [&](const std::string& p, const float* xin, int res, int c, const float* prev, float* out) {
-    float* styles = alloc((size_t)B * c * 4);
-    dense(p + ".affine", wlat, w0, wl, cfg.w_dim, p + ".affine", c, styles, 1.0f, false, false, 0, 0, nullptr, nullptr);
+    float* styles = styles_of(p);
     float* wm = alloc((size_t)B * 3 * c * 4);
     CmStyleArgs s{};
     s.styles = styles; s.w = dry ? nullptr : W(p + ".weight"); s.wm = wm; s.wgain = 1.0f / std::sqrt((float)c); s.B = B; s.CI = c; s.CO = 3; s.demod = 0;
@@ -433,11 +472,12 @@ inline size_t comodgan_handle::walk(int batch, const float* x, const float* z, f
       noise_of(b + ".conv0", res, nz, nbs);
       float* x0 = act_out(b + ".conv0", bufA, res, co);
       {
-        CmUpFirArgs a{};
-        a.raw = tmp; a.y = x0; a.skip = feat[ilog2(res)]; a.bias = dry ? nullptr : W(b + ".conv0.bias"); a.noise = nz;
-        a.noise_strength = dry ? nullptr : W(b + ".conv0.noise_strength"); a.noise_bstride = nbs; a.B = B; a.HO = res; a.C = co;
-        emit(b + ".conv0.fir", "migan::cm_upfir_kernel", 2.0 * 16 * co * res * res, 0, 4.0 * co * ((res + 1.0) * (res + 1.0) + 2.0 * res * res),
-             cm_upfir_kernel, a, grid1d((size_t)B * res * res * (co / 4)), 0);
+        CmFirArgs a{};
+        a.x = tmp; a.y = x0; a.skip = feat[ilog2(res)]; a.bias = dry ? nullptr : W(b + ".conv0.bias"); a.noise = nz;
+        a.noise_strength = dry ? nullptr : W(b + ".conv0.noise_strength"); a.noise_bstride = nbs;
+        a.B = B; a.H = res + 1; a.W = res + 1; a.C = co; a.HO = res; a.WO = res; a.pad = 1; a.fs = 0.25f;
+        emit(b + ".conv0.fir", "migan::cm_fir_kernel<1>", 2.0 * 16 * co * res * res, 0, 4.0 * co * ((res + 1.0) * (res + 1.0) + 2.0 * res * res),
+             cm_fir_kernel<1>, a, grid1d((size_t)B * (res / 2) * cdiv(res, 4) * (co / 4)), 0);
       }
       (void)ci;
       // conv1

@@ -19,8 +19,8 @@
 //                       The tap list is data: plain 3x3 (9 taps, stride 1), stride-2 on the FIR-filtered input
 //                       (encoder down path), and the four output phases of the stride-2 transposed convolution
 //                       (synthesis up path: 4 + 2 + 2 + 1 taps, no multiplications by inserted zeros).
-//   cm_blur_kernel      upfirdn2d [1,3,3,1] FIR with pad 2 in front of the strided convolution (conv2d_resample down path)
-//   cm_upfir_kernel     upfirdn2d FIR (gain 4) behind the transposed convolution + noise/bias/activation/skip epilogue
+//   cm_fir_kernel<0>    upfirdn2d [1,3,3,1] FIR with pad 2 in front of the strided convolution (conv2d_resample down path)
+//   cm_fir_kernel<1>    upfirdn2d FIR (gain 4) behind the transposed convolution + noise/bias/activation/skip epilogue
 //   cm_fromrgb_kernel   1x1 conv 4 -> C with bias and activation, NCHW planes -> NHWC
 //   cm_torgb_kernel     modulated 1x1 conv C -> 3 (no demodulation) + bias + 2x FIR upsample of the running image
 //   cm_dense_kernel     fully connected layers (mapping, affine, encoder fc, synthesis fc): weight streaming, fp32 FMA
@@ -62,26 +62,42 @@ struct CmConvArgs {
   int off_b, off_g;             // LDS carve in bytes: B tile buffers; the result tile aliases everything
 };
 
-// LDS A/B plane position: rows of KC fp16 (64 or 32 bytes), 16-byte slots XOR-swizzled by the row index so that 16
-// consecutive rows of one slot spread over all 64 banks
-template <int KC>
-MIGAN_DEVICE MIGAN_INLINE int cm_slot_off(int row, int slot) {
-  if constexpr (KC == 32) return row * 64 + ((slot ^ ((row >> 2) & 3)) << 4);
-  else return row * 32 + ((slot ^ ((row >> 3) & 1)) << 4);
+// LDS layout of the A (input tile) and B (weight tile) operands: one row per pixel / output channel holding both fp16
+// planes of the KC channels back to back plus 16 bytes of padding: pitch = 2 * KC * 2 + 16 bytes (144 for KC = 32, 80 for
+// KC = 16).  16 consecutive rows of one 16-byte slot then fall into 16 different bank quads (pitch / 4 mod 64 = 36 resp. 20
+// generates all multiples of 4), and -- unlike an XOR swizzle -- the address of a shifted row is the address of the row plus
+// a constant, so one filter tap costs two VALU adds of address arithmetic and every other offset is an immediate.
+// (Every VALU instruction in the tap loop costs matrix-core time on gfx950: MFMA and VALU issue cycles add up.)
+template <int V>
+struct IntT { static constexpr int value = V; };
+
+// GEMM row r (0..127 of the workgroup tile; MFMA row = r % 32 of its 32-row tile) -> grid pixel gy * 16 + gx of the
+// 8 x 16 tile.  ds_read_b128 is served in lane groups {0-3,12-15,20-27} and {4-11,16-19,28-31} (and the same + 32): with
+// the identity map and the 18-pixel tile rows of the plain 3x3 mode, lanes 12,13 and 26,27 of a group read pixels 16
+// rows apart = the same banks.  Swapping which pixels of the second tile row the lanes 16-31 take (16-19 -> columns
+// 0,1,10,11; 20-27 -> 2..9; 28-31 -> 12..15) gives every group 16 pixels that are distinct modulo 16.
+MIGAN_DEVICE MIGAN_INLINE int cm_pixel_of_row(int r) {
+  const int k = r & 15;
+  int col = k;
+  if (r & 16) col = k < 2 ? k : (k < 4 ? k + 8 : (k < 12 ? k - 2 : k));
+  return (r & ~15) | col;
 }
 
 //   NT  : output channels per workgroup (64 / 128)
 //   KC  : input channels per K chunk (32; 16 for the strided mode, whose 17x33-pixel input tile would otherwise
 //         leave room for one workgroup per CU only)
 //   NIA : float4 input-tile items per thread per chunk = ceil(tile pixels * KC/4 / 256) (prefetch registers)
-template <int NT, int KC, int NIA>
+//   NINE: the tap list has exactly nine entries and CI / KC is even (plain and strided 3x3): K loop unrolled over two
+//         chunks, two weight tiles in flight
+template <int NT, int KC, int NIA, bool NINE>
 MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, 2) cm_conv_kernel(const CmConvArgs p) {
   MIGAN_DYN_SMEM(smem);
   constexpr int MT = 128, GW = 16;
   constexpr int WCOLS = NT / 2, NTI = WCOLS / 32, MTI = 2;
   constexpr int GS = NT + 4;
-  constexpr int RB = KC * 2;                                  // bytes per LDS row (one plane)
-  constexpr int NSLOT = KC / 8, QK = KC / 4;                  // 16-byte slots / float4 quads per row
+  constexpr int RB = KC * 2;                                  // bytes of one plane of one row
+  constexpr int PB = 2 * RB + 16;                             // LDS row pitch in bytes (both planes + pad)
+  constexpr int NSLOT = KC / 8, QK = KC / 4;                  // 16-byte slots / float4 quads per row and plane
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, half = lane >> 5;
 
@@ -97,15 +113,14 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, 2) cm_conv_kernel(const CmConvArgs p)
   const int npix = p.IH * p.IW;
   const int nck = p.CI / KC;
 
-  char* a_s = reinterpret_cast<char*>(smem);                  // [2 planes][npix][RB]
-  char* b_s = reinterpret_cast<char*>(smem) + p.off_b;        // [2 buffers][2 planes][NT][RB]
+  char* a_s = reinterpret_cast<char*>(smem);                  // [npix][PB]
+  char* b_s = reinterpret_cast<char*>(smem) + p.off_b;        // [2 buffers][NT][PB]
   float* g_s = smem;                                          // [MT][GS] after the K loop
-  const int a_plane = npix * RB;
-  constexpr int b_plane = NT * RB, b_buf = 2 * b_plane;
+  constexpr int b_buf = NT * PB;
 
   const float* __restrict__ xb = p.x + (size_t)b * p.H * p.W * p.CI;
   const float* __restrict__ sab = p.sa ? p.sa + (size_t)b * p.CI : nullptr;
-  const size_t w_plane = (size_t)9 * p.CI * p.CO;             // 16-bit elements per weight plane
+  const unsigned w_plane_bytes = (unsigned)(9 * p.CI * p.CO) * 2u;     // bytes of one weight plane (< 2^23)
   const int total = nck * p.ntaps;
 
   f16v acc[MTI][NTI];
@@ -144,66 +159,70 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, 2) cm_conv_kernel(const CmConvArgs p)
       if (q < npix) {
         u2v h1, h2;
         split2_f16(areg[k] * sc, h1, h2);
-        char* dst = a_s + cm_slot_off<KC>(q, c4 >> 1) + (c4 & 1) * 8;
+        char* dst = a_s + q * PB + c4 * 8;
         *reinterpret_cast<u2v*>(dst) = h1;
-        *reinterpret_cast<u2v*>(dst + a_plane) = h2;
+        *reinterpret_cast<u2v*>(dst + RB) = h2;
       }
     }
   };
 
-  // B tile of iteration `it` (chunk-major over taps): rows co0..co0+NT-1 of [tap][CI/32][CO][32], both planes
+  // ---- weight tile of (tap plane wt, channel chunk c): rows co0..co0+NT-1 of [tap][CI/32][CO][32], both planes.
+  // Per-thread pieces (16 bytes each): the lane byte offset inside the tile and the LDS destination are constants of the
+  // thread; the tile's base address is wave-uniform (SGPR pair + 32-bit lane offset: no 64-bit VALU address adds).
   constexpr int BPIECES = 2 * NT * NSLOT / 256;               // 16-byte pieces per thread
-  f4 breg[BPIECES];
-  auto load_b = [&](int it) {
-    const int c = it / p.ntaps, tp = p.wtap[it % p.ntaps];
+  unsigned bsrc[BPIECES];
+  int bdst[BPIECES];
+#pragma unroll
+  for (int k = 0; k < BPIECES; ++k) {
+    const int piece = tid + k * 256;                          // [plane][row][slot]
+    const int pl = piece / (NT * NSLOT), rs = piece % (NT * NSLOT);
+    const int row = rs / NSLOT, slot = rs % NSLOT;
+    bsrc[k] = (unsigned)pl * w_plane_bytes + (unsigned)(row * 64 + slot * 16);
+    bdst[k] = row * PB + pl * RB + slot * 16;
+  }
+  f4 breg[2][BPIECES];                                        // two register sets: the NINE path keeps two tiles in flight
+  auto load_b = [&](int c, int tp, auto set) {
+    constexpr int S = decltype(set)::value;
     const int c32 = (c * KC) >> 5, hc = ((c * KC) & 31) >> 3;  // 32-channel chunk of the planes, first 16-byte slot inside it
-    const unsigned short* src = p.wsplit + ((size_t)(tp * (p.CI >> 5) + c32) * p.CO + co0) * 32;
+    const float* src = reinterpret_cast<const float*>(p.wsplit + ((size_t)(p.wtap[tp] * (p.CI >> 5) + c32) * p.CO + co0) * 32 + hc * 8);
 #pragma unroll
-    for (int k = 0; k < BPIECES; ++k) {
-      const int piece = tid + k * 256;                        // [plane][row][slot]
-      const int pl = piece / (NT * NSLOT), rs = piece % (NT * NSLOT);
-      const int row = rs / NSLOT, slot = rs % NSLOT;
-      breg[k] = ld4(reinterpret_cast<const float*>(src + pl * w_plane + row * 32 + (hc + slot) * 8));
-    }
+    for (int k = 0; k < BPIECES; ++k) breg[S][k] = ld4(at_bytes(src, bsrc[k]));
   };
-  auto store_b = [&](int buf) {
+  auto store_b = [&](int buf, auto set) {
+    constexpr int S = decltype(set)::value;
 #pragma unroll
-    for (int k = 0; k < BPIECES; ++k) {
-      const int piece = tid + k * 256;
-      const int pl = piece / (NT * NSLOT), rs = piece % (NT * NSLOT);
-      const int row = rs / NSLOT, slot = rs % NSLOT;
-      st4(reinterpret_cast<float*>(b_s + buf * b_buf + pl * b_plane + cm_slot_off<KC>(row, slot)), breg[k]);
-    }
+    for (int k = 0; k < BPIECES; ++k) st4(reinterpret_cast<float*>(b_s + buf * b_buf + bdst[k]), breg[S][k]);
   };
-
-  // One filter tap of channel chunk c: issue the next weight tile's loads (and, on the last tap of the chunk, the next
-  // chunk's input-tile loads: they fly under this tap's MFMAs and are consumed by store_a right after the barrier),
-  // MFMAs of this tap from LDS, next weight tile -> LDS, barrier.  The prefetches are unconditional (the last ones
-  // re-load the last tile) so that no branch sits between a load and its use.
-  auto tap_body = [&](int c, int tp, auto prefetch_a) {
-    const int it = c * p.ntaps + tp;
-    load_b(it + 1 < total ? it + 1 : it);
-    if constexpr (decltype(prefetch_a)::value) load_a(c + 1 < nck ? c + 1 : c);
-    MIGAN_SCHED_FENCE();        // keep the loads ahead of the MFMAs (the scheduler otherwise sinks them to their use)
-    const char* bb = b_s + (it & 1) * b_buf;
-    const int oy = p.dy[tp] - p.dymin, ox = p.dx[tp] - p.dxmin;
+  // ---- MFMA operand addresses: lane (l31, half) supplies row l31 of a 32-row tile, k = 8 * half .. + 7 of a 16-k step
+  int a_off[MTI], b_off[NTI];
+#pragma unroll
+  for (int i = 0; i < MTI; ++i) {
+    const int m = cm_pixel_of_row(wm * 64 + i * 32 + l31);
+    a_off[i] = (((m >> 4) * p.stride) * p.IW + (m & 15) * p.stride) * PB + half * 16;
+  }
+#pragma unroll
+  for (int j = 0; j < NTI; ++j) b_off[j] = (wn * WCOLS + j * 32 + l31) * PB + half * 16;
+  // MFMAs of one filter tap: A rows = the staged input tile shifted by the tap's offset, B = weight tile in LDS buffer `buf`
+  auto mfma_tap = [&](int tp, int buf) {
+    const int delta = ((p.dy[tp] - p.dymin) * p.IW + (p.dx[tp] - p.dxmin)) * PB;       // wave-uniform
+    const char* aa[MTI];
+    const char* bb[NTI];
+#pragma unroll
+    for (int i = 0; i < MTI; ++i) aa[i] = a_s + (a_off[i] + delta);
+#pragma unroll
+    for (int j = 0; j < NTI; ++j) bb[j] = b_s + (b_off[j] + buf * b_buf);
 #pragma unroll
     for (int ks = 0; ks < KC / 16; ++ks) {
       f4 av[MTI][2], bv[NTI][2];
 #pragma unroll
       for (int i = 0; i < MTI; ++i) {
-        const int m = wm * 64 + i * 32 + l31;
-        const int q = ((m >> 4) * p.stride + oy) * p.IW + (m & 15) * p.stride + ox;
-        const char* qa = a_s + cm_slot_off<KC>(q, 2 * ks + half);
-        av[i][0] = ld4(reinterpret_cast<const float*>(qa));
-        av[i][1] = ld4(reinterpret_cast<const float*>(qa + a_plane));
+        av[i][0] = ld4(reinterpret_cast<const float*>(aa[i] + ks * 32));
+        av[i][1] = ld4(reinterpret_cast<const float*>(aa[i] + ks * 32 + RB));
       }
 #pragma unroll
       for (int j = 0; j < NTI; ++j) {
-        const int row = wn * WCOLS + j * 32 + l31;
-        const char* qb = bb + cm_slot_off<KC>(row, 2 * ks + half);
-        bv[j][0] = ld4(reinterpret_cast<const float*>(qb));
-        bv[j][1] = ld4(reinterpret_cast<const float*>(qb + b_plane));
+        bv[j][0] = ld4(reinterpret_cast<const float*>(bb[j] + ks * 32));
+        bv[j][1] = ld4(reinterpret_cast<const float*>(bb[j] + ks * 32 + RB));
       }
       // product-major order: consecutive MFMAs write different accumulators (a dependent MFMA issued straight after
       // its producer waits out the 16-pass latency), smallest products first
@@ -215,20 +234,74 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, 2) cm_conv_kernel(const CmConvArgs p)
           for (int j = 0; j < NTI; ++j)
             acc[i][j] = MIGAN_MFMA_F16_32X32X16(av[i][pr == 0 ? 1 : 0], bv[j][pr == 1 ? 1 : 0], acc[i][j]);
     }
-    MIGAN_SCHED_FENCE();
-    store_b((it + 1) & 1);
-    __syncthreads();
   };
 
-  load_a(0);
-  load_b(0);
-  store_b(0);
-  for (int c = 0; c < nck; ++c) {
-    // input halo tile of channel chunk c: registers -> x style scale -> two fp16 planes in LDS
-    store_a(c);
-    __syncthreads();
-    for (int tp = 0; tp + 1 < p.ntaps; ++tp) tap_body(c, tp, FalseT{});
-    tap_body(c, p.ntaps - 1, TrueT{});
+  if constexpr (!NINE) {
+    // ---- generic tap list (the 1/2/4-tap phases of the transposed convolution): weight tile prefetched one tap ahead.
+    // One filter tap of channel chunk c: issue the next weight tile's loads (and, on the last tap of the chunk, the next
+    // chunk's input-tile loads: they fly under this tap's MFMAs and are consumed by store_a right after the barrier),
+    // MFMAs of this tap from LDS, next weight tile -> LDS, barrier.  The prefetches are unconditional (the last ones
+    // re-load the last tile) so that no branch sits between a load and its use.
+    auto tap_body = [&](int c, int tp, auto prefetch_a) {
+      const int it = c * p.ntaps + tp;
+      int cn = c, tn = tp + 1;
+      if (tn == p.ntaps) { tn = 0; ++cn; }
+      if (cn == nck) { cn = c; tn = tp; }
+      load_b(cn, tn, IntT<0>{});
+      if constexpr (decltype(prefetch_a)::value) load_a(c + 1 < nck ? c + 1 : c);
+      MIGAN_SCHED_FENCE();        // keep the loads ahead of the MFMAs (the scheduler otherwise sinks them to their use)
+      mfma_tap(tp, it & 1);
+      MIGAN_SCHED_FENCE();
+      store_b((it + 1) & 1, IntT<0>{});
+      __syncthreads();
+    };
+    load_a(0);
+    load_b(0, 0, IntT<0>{});
+    store_b(0, IntT<0>{});
+    for (int c = 0; c < nck; ++c) {
+      // input halo tile of channel chunk c: registers -> x style scale -> two fp16 planes in LDS
+      store_a(c);
+      __syncthreads();
+      for (int tp = 0; tp + 1 < p.ntaps; ++tp) tap_body(c, tp, FalseT{});
+      tap_body(c, p.ntaps - 1, TrueT{});
+    }
+  } else {
+    // ---- nine taps (plain and strided 3x3): two weight tiles are kept in flight in two register sets.  The K loop is
+    // straight-line code over two channel chunks (18 taps: the register set of a tile is its global tap index mod 2, a
+    // compile-time constant), which also lets the compiler count outstanding loads exactly (no s_waitcnt vmcnt(0) at
+    // control-flow joins).
+    //   tap `it`:  issue loads of tile it+2 -> set it%2 | MFMAs of tap it from LDS buffer it%2 |
+    //              tile it+1 (set (it+1)%2, in flight since tap it-1) -> LDS buffer (it+1)%2 | barrier
+    // The next chunk's input tile is loaded two taps before the chunk ends, ahead of that tap's weight loads, so waiting
+    // for it at the chunk boundary leaves the newer weight loads in flight.
+    auto tap9 = [&](int c, auto tpc, auto parc) {
+      constexpr int TP = decltype(tpc)::value, PAR = decltype(parc)::value;
+      constexpr int TN = (TP + 2) % 9, CN = (TP + 2) / 9;      // tile two taps ahead
+      if constexpr (TP == 7) load_a(c + 1 < nck ? c + 1 : c);
+      const bool inside = c + CN < nck;                        // beyond the end: re-load the last tile (never used)
+      load_b(inside ? c + CN : nck - 1, inside ? TN : 8, IntT<PAR>{});
+      MIGAN_SCHED_FENCE();
+      mfma_tap(TP, PAR);
+      MIGAN_SCHED_FENCE();
+      store_b(PAR ^ 1, IntT<PAR ^ 1>{});
+      __syncthreads();
+    };
+    auto chunk9 = [&](int c, auto cpar) {
+      constexpr int CP = decltype(cpar)::value;         // parity of the chunk's first global tap index
+      store_a(c);
+      __syncthreads();
+      tap9(c, IntT<0>{}, IntT<CP>{});     tap9(c, IntT<1>{}, IntT<CP ^ 1>{}); tap9(c, IntT<2>{}, IntT<CP>{});
+      tap9(c, IntT<3>{}, IntT<CP ^ 1>{}); tap9(c, IntT<4>{}, IntT<CP>{});     tap9(c, IntT<5>{}, IntT<CP ^ 1>{});
+      tap9(c, IntT<6>{}, IntT<CP>{});     tap9(c, IntT<7>{}, IntT<CP ^ 1>{}); tap9(c, IntT<8>{}, IntT<CP>{});
+    };
+    load_a(0);
+    load_b(0, 0, IntT<0>{});
+    load_b(0, 1, IntT<1>{});
+    store_b(0, IntT<0>{});
+    for (int c = 0; c < nck; c += 2) {      // nck is even (host check)
+      chunk9(c, IntT<0>{});
+      chunk9(c + 1, IntT<1>{});
+    }
   }
 
   // ---- epilogue: accumulators -> LDS result tile -> per float4: coefficient, noise, bias, activation, skip
@@ -238,7 +311,7 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, 2) cm_conv_kernel(const CmConvArgs p)
     for (int j = 0; j < NTI; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int row = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        const int row = cm_pixel_of_row(wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half);
         const int col = wn * WCOLS + j * 32 + l31;
         g_s[row * GS + col] = acc[i][j][r];
       }
@@ -447,9 +520,9 @@ struct CmDenseArgs {
   int N, K, K1, O;
   int act, norm, in_c, out_c;
 };
-MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, 2) cm_dense_kernel(const CmDenseArgs p) {
+MIGAN_DEVICE MIGAN_INLINE void cm_dense_block(const CmDenseArgs& p, int block) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int o0 = ((int)blockIdx.x * 4 + wave) * 2;
+  const int o0 = (block * 4 + wave) * 2;
   if (o0 >= p.O) return;
   const int no = (o0 + 1 < p.O) ? 2 : 1;
   const int K2 = p.K - p.K1;
@@ -505,6 +578,31 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, 2) cm_dense_kernel(const CmDenseArgs 
   }
 }
 
+MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, 2) cm_dense_kernel(const CmDenseArgs p) { cm_dense_block(p, (int)blockIdx.x); }
+
+// All affine layers of the synthesis network in one launch (they depend only on the latent w and the global code w0,
+// stylegan.py:282): a table of (weight, bias, output, out_features); same input cat([w, w0]), no activation.
+constexpr int kCmMaxAffine = 48;
+struct CmDenseMultiArgs {
+  const float* w[kCmMaxAffine];
+  const float* b[kCmMaxAffine];
+  float* y[kCmMaxAffine];
+  int O[kCmMaxAffine];
+  int blk0[kCmMaxAffine + 1];     // first workgroup of each job
+  const float* x;
+  const float* x2;
+  float wgain;
+  int N, K, K1, njobs;
+};
+MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, 2) cm_dense_multi_kernel(const CmDenseMultiArgs p) {
+  int j = 0;
+  while (j + 1 < p.njobs && (int)blockIdx.x >= p.blk0[j + 1]) ++j;
+  CmDenseArgs a{};
+  a.x = p.x; a.x2 = p.x2; a.w = p.w[j]; a.b = p.b[j]; a.y = p.y[j];
+  a.wgain = p.wgain; a.bgain = 1.0f; a.psi = 1.0f; a.N = p.N; a.K = p.K; a.K1 = p.K1; a.O = p.O[j];
+  cm_dense_block(a, (int)blockIdx.x - p.blk0[j]);
+}
+
 // ------------------------------------------------------------------------------------------------
 // conv2d_layer(4 -> C, kernel 1, bias, activation) of the first encoder block (comodgan.py:46-48, stylegan.py:231-244):
 // NCHW network input -> NHWC features.  One thread per pixel and channel quad.
@@ -537,84 +635,83 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, 2) cm_fromrgb_kernel(const CmFromRgbA
 }
 
 // ------------------------------------------------------------------------------------------------
-// upfirdn2d with the [1,3,3,1] x [1,3,3,1] / 64 filter, up = down = 1, zero padding `pad` on every side
-// (conv2d_resample.py down path: pad = conv padding + 1 = 2): NHWC [B][H][W][C] -> [B][H+2pad-3][W+2pad-3][C].
-struct CmBlurArgs {
-  const float* x;
-  float* y;
-  int B, H, W, C, HO, WO, pad;
-};
-MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, 2) cm_blur_kernel(const CmBlurArgs p) {
-  const int qn = p.C >> 2;
-  const size_t total = (size_t)p.B * p.HO * p.WO * qn;
-  const float f[4] = {0.125f, 0.375f, 0.375f, 0.125f};
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-    const int c4 = (int)(i % qn);
-    size_t pix = i / qn;
-    const int ox = (int)(pix % p.WO); pix /= p.WO;
-    const int oy = (int)(pix % p.HO);
-    const int b = (int)(pix / p.HO);
-    f4 acc = f4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int a = 0; a < 4; ++a) {
-      const int iy = oy + a - p.pad;
-      if (iy < 0 || iy >= p.H) continue;
-      f4 row = f4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const int ix = ox + c - p.pad;
-        if (ix < 0 || ix >= p.W) continue;
-        row = row + ld4(p.x + (((size_t)b * p.H + iy) * p.W + ix) * p.C + c4 * 4) * f[c];
-      }
-      acc = acc + row * f[a];
-    }
-    st4(p.y + i * 4, acc);
-  }
-}
-
-// ------------------------------------------------------------------------------------------------
-// Second half of an up=2 synthesis_layer: upfirdn2d (filter x gain 4, pad 1) over the (2H+1)^2 output of the
-// transposed convolution (conv2d_resample.py up path), then noise, bias, activation, skip
-// (stylegan.py:300-309, comodgan.py:331-332).  The demodulation coefficient is already applied (cm_conv_kernel raw mode).
-struct CmUpFirArgs {
-  const float* raw;            // NHWC [B][HR][HR][C], HR = HO + 1
-  float* y;                    // NHWC [B][HO][HO][C]
-  const float* skip;
-  const float* bias;
-  const float* noise;
+// upfirdn2d with the separable [1,3,3,1] filter (taps [1,3,3,1] * fs per axis), up = down = 1, zero padding `pad` on
+// every side, NHWC: out[y][x] = sum_{a,b} f[a] f[b] in[y + a - pad][x + b - pad].  Each thread produces a 2 x 4 block of
+// output pixels for one channel quad from a 5 x 7 input window (4.4 loads per output instead of 16), one input row at
+// a time: horizontal taps into 4 row sums, which feed the two output rows.
+//   EPI = 0 (cm_blur): FIR in front of the strided convolution (conv2d_resample.py down path: pad = 2, gain 1, fs = 1/8),
+//                      [B][H][W][C] -> [B][H+1][W+1][C]
+//   EPI = 1 (cm_upfir): second half of an up=2 synthesis_layer: FIR (gain 4: fs = 1/4, pad 1) over the (2H+1)^2 output
+//                      of the transposed convolution (conv2d_resample.py up path), then noise, bias, activation, skip
+//                      (stylegan.py:300-309, comodgan.py:331-332); the demodulation coefficient is already applied
+//                      (cm_conv_kernel raw mode)
+struct CmFirArgs {
+  const float* x;              // NHWC [B][H][W][C]
+  float* y;                    // NHWC [B][HO][WO][C]
+  const float* skip;           // EPI 1: NHWC like y or null
+  const float* bias;           // EPI 1: [C]
+  const float* noise;          // EPI 1: [HO][WO] (+ noise_bstride per image) or null
   const float* noise_strength;
   long long noise_bstride;
-  int B, HO, C;
+  float fs;
+  int B, H, W, C, HO, WO, pad;
 };
-MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, 2) cm_upfir_kernel(const CmUpFirArgs p) {
-  const int qn = p.C >> 2, HR = p.HO + 1;
-  const size_t total = (size_t)p.B * p.HO * p.HO * qn;
-  const float f[4] = {0.25f, 0.75f, 0.75f, 0.25f};
-  const float ns = p.noise ? p.noise_strength[0] : 0.0f;
+template <int EPI>
+MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, 2) cm_fir_kernel(const CmFirArgs p) {
+  const int qn = p.C >> 2;
+  const int nbx = (p.WO + 3) >> 2, nby = (p.HO + 1) >> 1;
+  const size_t total = (size_t)p.B * nby * nbx * qn;
+  const float f0 = p.fs, f1 = 3.0f * p.fs;
+  const float ns = (EPI == 1 && p.noise) ? p.noise_strength[0] : 0.0f;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
     const int c4 = (int)(i % qn);
-    size_t pix = i / qn;
-    const int ox = (int)(pix % p.HO); pix /= p.HO;
-    const int oy = (int)(pix % p.HO);
-    const int b = (int)(pix / p.HO);
-    f4 acc = f4{0.f, 0.f, 0.f, 0.f};
+    size_t blk = i / qn;
+    const int bx = (int)(blk % nbx); blk /= nbx;
+    const int by = (int)(blk % nby);
+    const int b = (int)(blk / nby);
+    const int x0 = bx * 4, y0 = by * 2;
+    const float* xb = p.x + (size_t)b * p.H * p.W * p.C + c4 * 4;
+    f4 acc[2][4];
 #pragma unroll
-    for (int a = 0; a < 4; ++a) {
-      const int iy = oy + a - 1;
-      if (iy < 0 || iy >= HR) continue;
-      f4 row = f4{0.f, 0.f, 0.f, 0.f};
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) acc[r][c] = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int r = 0; r < 5; ++r) {
+      const int iy = y0 - p.pad + r;
+      const bool yok = iy >= 0 && iy < p.H;
+      f4 v[7];
+#pragma unroll
+      for (int c = 0; c < 7; ++c) {
+        const int ix = x0 - p.pad + c;
+        v[c] = f4{0.f, 0.f, 0.f, 0.f};
+        if (yok && ix >= 0 && ix < p.W) v[c] = ld4(xb + ((size_t)iy * p.W + ix) * p.C);
+      }
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
-        const int ix = ox + c - 1;
-        if (ix < 0 || ix >= HR) continue;
-        row = row + ld4(p.raw + (((size_t)b * HR + iy) * HR + ix) * p.C + c4 * 4) * f[c];
+        const f4 h = (v[c] + v[c + 3]) * f0 + (v[c + 1] + v[c + 2]) * f1;
+        if (r < 4) acc[0][c] = acc[0][c] + h * ((r == 0 || r == 3) ? f0 : f1);
+        if (r > 0) acc[1][c] = acc[1][c] + h * ((r == 1 || r == 4) ? f0 : f1);
       }
-      acc = acc + row * f[a];
     }
-    if (p.noise) acc = acc + MIGAN_FMUL_RN(p.noise[(size_t)b * p.noise_bstride + (size_t)oy * p.HO + ox], ns);
-    acc = act4(acc + ld4(p.bias + c4 * 4));
-    if (p.skip) acc = acc + ld4(p.skip + i * 4);
-    st4(p.y + i * 4, acc);
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const int oy = y0 + r;
+      if (oy >= p.HO) continue;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int ox = x0 + c;
+        if (ox >= p.WO) continue;
+        const size_t o = (((size_t)b * p.HO + oy) * p.WO + ox) * p.C + c4 * 4;
+        f4 v = acc[r][c];
+        if constexpr (EPI == 1) {
+          if (p.noise) v = v + MIGAN_FMUL_RN(p.noise[(size_t)b * p.noise_bstride + (size_t)oy * p.WO + ox], ns);
+          v = act4(v + ld4(p.bias + c4 * 4));
+          if (p.skip) v = v + ld4once(p.skip + o);
+        }
+        st4o(p.y + o, v);
+      }
+    }
   }
 }
 

@@ -89,7 +89,7 @@ def test_generator_matches_reference_golden(tag):
     y, _, info = run_emu(cfg, sd, x, z, psi=float(g["psi"]))
     assert np.abs(y - g["y"]).max() <= 1e-3, np.abs(y - g["y"]).max()
     kernels = {i["kernel"] for i in info}
-    assert ("migan::cm_conv_kernel<128, 32, 6>" if "c128" in tag else "migan::cm_conv_kernel<64, 32, 6>") in kernels
+    assert ("migan::cm_conv_kernel<128, 32, 6, true>" if "c128" in tag else "migan::cm_conv_kernel<64, 32, 6, true>") in kernels
 
 
 @pytest.mark.parametrize("mode", ["none", "random"])
