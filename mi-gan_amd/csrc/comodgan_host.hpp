@@ -46,6 +46,9 @@ inline void cm_prepare_kernels() {
   rt_check(rt::allow_dynamic_lds((const void*)cm_conv_kernel<64, 32, 6, true>, 160 * 1024), "hipFuncSetAttribute");
   rt_check(rt::allow_dynamic_lds((const void*)cm_conv_kernel<128, 32, 6, true>, 160 * 1024), "hipFuncSetAttribute");
   rt_check(rt::allow_dynamic_lds((const void*)cm_conv_kernel<64, 16, 9, true>, 160 * 1024), "hipFuncSetAttribute");
+  rt_check(rt::allow_dynamic_lds((const void*)cm_conv_kernel<256, 32, 6, true>, 160 * 1024), "hipFuncSetAttribute");
+  rt_check(rt::allow_dynamic_lds((const void*)cm_conv_kernel<256, 16, 9, true>, 160 * 1024), "hipFuncSetAttribute");
+  rt_check(rt::allow_dynamic_lds((const void*)cm_conv_kernel<256, 32, 6, false>, 160 * 1024), "hipFuncSetAttribute");
   rt_check(rt::allow_dynamic_lds((const void*)cm_conv_kernel<128, 16, 9, true>, 160 * 1024), "hipFuncSetAttribute");
   done = true;
 }
@@ -280,7 +283,10 @@ inline size_t comodgan_handle::walk(int batch, const float* x, const float* z, f
       a.GHn = H + (ey == 0); a.GWn = Wd + (ex == 0);
       a.oy_mul = 2; a.ox_mul = 2; a.oy_add = ey; a.ox_add = ex;
     }
-    const int NT = (cw.co % 128 == 0) ? 128 : 64;
+    const char* nt256_env = std::getenv("COMODGAN_NT256_MINRES");          // experiments / tests; 0 disables the 256-column tiles
+    const int nt256_min = nt256_env ? (std::atoi(nt256_env) > 0 ? std::atoi(nt256_env) : (1 << 30)) : 32;
+    // 256-column tiles (one workgroup per CU, 512-register waves) where Cout allows and the launch still fills the chip
+    const int NT = (cw.co % 256 == 0 && std::min(a.GHn, a.GWn) >= nt256_min) ? 256 : ((cw.co % 128 == 0) ? 128 : 64);
     const int KC = mode == CM_CONV_DOWN ? 16 : 32;          // the 17x33-pixel tile of the strided mode is staged 16 channels at a time
     a.tiles_y = cdiv(a.GHn, 8); a.tiles_x = cdiv(a.GWn, 16); a.nchunks = cw.co / NT;
     const size_t pitch = (size_t)4 * KC + 16;                // LDS row: both fp16 planes of KC channels + 16 bytes of padding
@@ -295,7 +301,10 @@ inline size_t comodgan_handle::walk(int batch, const float* x, const float* z, f
     const bool nine = a.ntaps == 9;
     MIGAN_CHECK(!nine || (cw.ci / KC) % 2 == 0, MIGAN_EINVAL, "internal: the nine-tap kernel walks channel chunks in pairs");
     MIGAN_CHECK(nine || KC == 32, MIGAN_EINVAL, "internal: no generic-tap-list kernel with 16-channel chunks");
-    if (nine && KC == 32 && NT == 128) emit(layer, "migan::cm_conv_kernel<128, 32, 6, true>", mf, mf, by, cm_conv_kernel<128, 32, 6, true>, a, grid, lds);
+    if (nine && KC == 32 && NT == 256) emit(layer, "migan::cm_conv_kernel<256, 32, 6, true>", mf, mf, by, cm_conv_kernel<256, 32, 6, true>, a, grid, lds);
+    else if (nine && NT == 256) emit(layer, "migan::cm_conv_kernel<256, 16, 9, true>", mf, mf, by, cm_conv_kernel<256, 16, 9, true>, a, grid, lds);
+    else if (NT == 256) emit(layer, "migan::cm_conv_kernel<256, 32, 6, false>", mf, mf, by, cm_conv_kernel<256, 32, 6, false>, a, grid, lds);
+    else if (nine && KC == 32 && NT == 128) emit(layer, "migan::cm_conv_kernel<128, 32, 6, true>", mf, mf, by, cm_conv_kernel<128, 32, 6, true>, a, grid, lds);
     else if (nine && KC == 32) emit(layer, "migan::cm_conv_kernel<64, 32, 6, true>", mf, mf, by, cm_conv_kernel<64, 32, 6, true>, a, grid, lds);
     else if (nine && NT == 128) emit(layer, "migan::cm_conv_kernel<128, 16, 9, true>", mf, mf, by, cm_conv_kernel<128, 16, 9, true>, a, grid, lds);
     else if (nine) emit(layer, "migan::cm_conv_kernel<64, 16, 9, true>", mf, mf, by, cm_conv_kernel<64, 16, 9, true>, a, grid, lds);

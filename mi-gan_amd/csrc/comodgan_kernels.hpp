@@ -83,14 +83,16 @@ MIGAN_DEVICE MIGAN_INLINE int cm_pixel_of_row(int r) {
   return (r & ~15) | col;
 }
 
-//   NT  : output channels per workgroup (64 / 128)
+//   NT  : output channels per workgroup (64 / 128 / 256)
 //   KC  : input channels per K chunk (32; 16 for the strided mode, whose 17x33-pixel input tile would otherwise
 //         leave room for one workgroup per CU only)
 //   NIA : float4 input-tile items per thread per chunk = ceil(tile pixels * KC/4 / 256) (prefetch registers)
 //   NINE: the tap list has exactly nine entries and CI / KC is even (plain and strided 3x3): K loop unrolled over two
 //         chunks, two weight tiles in flight
+//   NT = 256: one workgroup per CU, one wave per SIMD with the 512-register budget; each wave owns 64 x 128 (12 operand reads per
+//         24 MFMAs instead of 16, twice the MFMA work per barrier)
 template <int NT, int KC, int NIA, bool NINE>
-MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, 2) cm_conv_kernel(const CmConvArgs p) {
+MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, (NT == 256 ? 1 : 2)) cm_conv_kernel(const CmConvArgs p) {
   MIGAN_DYN_SMEM(smem);
   constexpr int MT = 128, GW = 16;
   constexpr int WCOLS = NT / 2, NTI = WCOLS / 32, MTI = 2;

@@ -145,3 +145,16 @@ def test_c_abi_edge_cases():
     with pytest.raises(ValueError):
         h.forward(None, za.ctypes.data, y.ctypes.data, 1, ws[off:].ctypes.data, nbytes)
     h.close()
+
+
+def test_256_column_tiles(monkeypatch):
+    """cm_conv_kernel<256, ...> (one wave per SIMD, 64 x 128 wave tiles) on a 256-channel geometry, all three modes, vs the oracle."""
+    monkeypatch.setenv("COMODGAN_NT256_MINRES", "4")
+    cfg = cs.Config(resolution=16, ch_base=8192, ch_max=256, num_ws=cs.default_num_ws(16))
+    sd = pkg.synth.make_comodgan_state_dict(cfg, 21)
+    x, z = pkg.synth.make_input(1, 16, 21), pkg.synth.make_latent(1, 512, 21)
+    y, _, info = run_emu(cfg, sd, x, z)
+    kernels = {i["kernel"] for i in info}
+    assert {"migan::cm_conv_kernel<256, 32, 6, true>", "migan::cm_conv_kernel<256, 16, 9, true>", "migan::cm_conv_kernel<256, 32, 6, false>"} <= kernels
+    want = orc.generator(x, z, sd, 16, cfg.num_ws)
+    assert np.abs(y - want).max() <= 1e-3, np.abs(y - want).max()
