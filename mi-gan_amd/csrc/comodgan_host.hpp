@@ -38,18 +38,33 @@ struct CmDebugTensor {
   int ndim = 0;
 };
 
+typedef void (*CmConvFn)(const CmConvArgs);
+struct CmConvEntry { int NT, KC, nine, MTI; CmConvFn fn; const char* name; };
+#define CM_CONV_ENTRY(NT, KC, NIA, NINE, MTI) {NT, KC, NINE, MTI, cm_conv_kernel<NT, KC, NIA, (NINE != 0), MTI>, "migan::cm_conv_kernel<" #NT ", " #KC ", " #NIA ", " #NINE ", " #MTI ">"}
+inline const std::vector<CmConvEntry>& cm_conv_table() {
+  static const std::vector<CmConvEntry> t = {
+      // 8 x 16 pixel tiles (MTI 2): nine-tap unrolled K loop (plain: 10x18-pixel tile, 6 items; strided: 17x33 at 16 channels, 9 items)
+      CM_CONV_ENTRY(64, 32, 6, 1, 2), CM_CONV_ENTRY(128, 32, 6, 1, 2), CM_CONV_ENTRY(256, 32, 6, 1, 2),
+      CM_CONV_ENTRY(64, 16, 9, 1, 2), CM_CONV_ENTRY(128, 16, 9, 1, 2), CM_CONV_ENTRY(256, 16, 9, 1, 2),
+      // generic tap list (transposed-convolution phases)
+      CM_CONV_ENTRY(64, 32, 6, 0, 2), CM_CONV_ENTRY(128, 32, 6, 0, 2), CM_CONV_ENTRY(256, 32, 6, 0, 2),
+      // 16 x 16 pixel tiles (MTI 4): plain 18x18 tile = 11 items; strided 33x33 at 16 channels = 18 items
+      CM_CONV_ENTRY(64, 32, 11, 1, 4), CM_CONV_ENTRY(128, 32, 11, 1, 4), CM_CONV_ENTRY(256, 32, 11, 1, 4),
+      CM_CONV_ENTRY(64, 16, 18, 1, 4), CM_CONV_ENTRY(128, 16, 18, 1, 4), CM_CONV_ENTRY(256, 16, 18, 1, 4),
+      CM_CONV_ENTRY(64, 32, 11, 0, 4), CM_CONV_ENTRY(128, 32, 11, 0, 4), CM_CONV_ENTRY(256, 32, 11, 0, 4),
+  };
+  return t;
+}
+inline const CmConvEntry& cm_pick_conv(int NT, int KC, bool nine, int MTI) {
+  for (const auto& e : cm_conv_table())
+    if (e.NT == NT && e.KC == KC && (e.nine != 0) == nine && e.MTI == MTI) return e;
+  throw Error(MIGAN_EINVAL, "internal: no cm_conv_kernel instantiation for this tile");
+}
+
 inline void cm_prepare_kernels() {
   static bool done = false;
   if (done) return;
-  rt_check(rt::allow_dynamic_lds((const void*)cm_conv_kernel<64, 32, 6, false>, 160 * 1024), "hipFuncSetAttribute");
-  rt_check(rt::allow_dynamic_lds((const void*)cm_conv_kernel<128, 32, 6, false>, 160 * 1024), "hipFuncSetAttribute");
-  rt_check(rt::allow_dynamic_lds((const void*)cm_conv_kernel<64, 32, 6, true>, 160 * 1024), "hipFuncSetAttribute");
-  rt_check(rt::allow_dynamic_lds((const void*)cm_conv_kernel<128, 32, 6, true>, 160 * 1024), "hipFuncSetAttribute");
-  rt_check(rt::allow_dynamic_lds((const void*)cm_conv_kernel<64, 16, 9, true>, 160 * 1024), "hipFuncSetAttribute");
-  rt_check(rt::allow_dynamic_lds((const void*)cm_conv_kernel<256, 32, 6, true>, 160 * 1024), "hipFuncSetAttribute");
-  rt_check(rt::allow_dynamic_lds((const void*)cm_conv_kernel<256, 16, 9, true>, 160 * 1024), "hipFuncSetAttribute");
-  rt_check(rt::allow_dynamic_lds((const void*)cm_conv_kernel<256, 32, 6, false>, 160 * 1024), "hipFuncSetAttribute");
-  rt_check(rt::allow_dynamic_lds((const void*)cm_conv_kernel<128, 16, 9, true>, 160 * 1024), "hipFuncSetAttribute");
+  for (const auto& e : cm_conv_table()) rt_check(rt::allow_dynamic_lds((const void*)e.fn, 160 * 1024), "hipFuncSetAttribute");
   done = true;
 }
 
@@ -195,6 +210,12 @@ inline size_t comodgan_handle::walk(int batch, const float* x, const float* z, f
       if (timed) rt_check(rt::event_record(events[2 * nlaunch], stream), "hipEventRecord");
       rt_check(rt::launch(kernel, args, grid, kThreads, lds, stream), kname);
       if (timed) rt_check(rt::event_record(events[2 * nlaunch + 1], stream), "hipEventRecord");
+#ifdef MIGAN_PHASE_PROF
+      if (timed) {
+        if ((int)prof_layers().size() <= nlaunch) prof_layers().resize(nlaunch + 1);
+        rt_check(rt::prof_read(prof_buffer(), prof_layers()[nlaunch].v, 16, true), "prof read");
+      }
+#endif
     }
     ++nlaunch;
   };
@@ -259,16 +280,27 @@ inline size_t comodgan_handle::walk(int batch, const float* x, const float* z, f
     a.a_scale = kCmF16Top / kCmInBound; a.cgain = cgain / a.a_scale;
     a.B = B; a.H = H; a.W = Wd; a.CI = cw.ci; a.CO = cw.co; a.HO = HO; a.WO = WO;
     a.oy_mul = 1; a.ox_mul = 1; a.oy_add = 0; a.ox_add = 0; a.raw = raw;
+    a.prof = prof_buffer();
+    // tile: 16 x 16 grid pixels (MTI 4) where the layer is large enough, else 8 x 16
+    const char* mti_env = std::getenv("COMODGAN_MTI");                     // experiments / tests: force 2 or 4
+    const int ghn = mode == CM_CONV_UP ? H + (ey == 0) : HO, gwn = mode == CM_CONV_UP ? Wd + (ex == 0) : WO;
+    // 16 x 16 pixels x 256 channels per workgroup (one wave per SIMD, 128 x 128 wave tiles) pays where Cout allows it and the
+    // launch still has two workgroups per CU (measured: +5..15 % at >= 64^2 with 256/512 channels, a loss on smaller launches
+    // and with 128- or 64-column tiles)
+    const size_t wgs16 = (size_t)cdiv(ghn, 16) * cdiv(gwn, 16) * B * (cw.co / 256);
+    int MTI = (cw.co % 256 == 0 && std::min(ghn, gwn) >= 16 && wgs16 >= 512) ? 4 : 2;
+    if (mti_env && (std::atoi(mti_env) == 2 || std::atoi(mti_env) == 4)) MTI = std::atoi(mti_env);
+    const int GH = 4 * MTI;
     if (mode == CM_CONV_NORMAL) {
       a.stride = 1;
       for (int ky = 0; ky < 3; ++ky)
         for (int kx = 0; kx < 3; ++kx) { a.dy[a.ntaps] = ky - 1; a.dx[a.ntaps] = kx - 1; a.wtap[a.ntaps] = ky * 3 + kx; ++a.ntaps; }
-      a.dymin = -1; a.dxmin = -1; a.IH = 10; a.IW = 18; a.GHn = HO; a.GWn = WO;
+      a.dymin = -1; a.dxmin = -1; a.IH = GH + 2; a.IW = 18; a.GHn = HO; a.GWn = WO;
     } else if (mode == CM_CONV_DOWN) {
       a.stride = 2;
       for (int ky = 0; ky < 3; ++ky)
         for (int kx = 0; kx < 3; ++kx) { a.dy[a.ntaps] = ky; a.dx[a.ntaps] = kx; a.wtap[a.ntaps] = ky * 3 + kx; ++a.ntaps; }
-      a.dymin = 0; a.dxmin = 0; a.IH = 17; a.IW = 33; a.GHn = HO; a.GWn = WO;
+      a.dymin = 0; a.dxmin = 0; a.IH = 2 * GH + 1; a.IW = 33; a.GHn = HO; a.GWn = WO;
     } else {
       // output phase (ey, ex) of conv_transpose2d(stride 2): raw[2g + e] = sum over taps k with k = e (mod 2) of x[g - (k - e) / 2] w[k]
       a.stride = 1;
@@ -279,37 +311,30 @@ inline size_t comodgan_handle::walk(int batch, const float* x, const float* z, f
           a.dy[a.ntaps] = -(ky - ey) / 2; a.dx[a.ntaps] = -(kx - ex) / 2; a.wtap[a.ntaps] = ky * 3 + kx; ++a.ntaps;
         }
       a.dymin = ey == 0 ? -1 : 0; a.dxmin = ex == 0 ? -1 : 0;
-      a.IH = 8 + (ey == 0); a.IW = 16 + (ex == 0);
+      a.IH = GH + (ey == 0); a.IW = 16 + (ex == 0);
       a.GHn = H + (ey == 0); a.GWn = Wd + (ex == 0);
       a.oy_mul = 2; a.ox_mul = 2; a.oy_add = ey; a.ox_add = ex;
     }
-    const char* nt256_env = std::getenv("COMODGAN_NT256_MINRES");          // experiments / tests; 0 disables the 256-column tiles
-    const int nt256_min = nt256_env ? (std::atoi(nt256_env) > 0 ? std::atoi(nt256_env) : (1 << 30)) : 32;
-    // 256-column tiles (one workgroup per CU, 512-register waves) where Cout allows and the launch still fills the chip
-    const int NT = (cw.co % 256 == 0 && std::min(a.GHn, a.GWn) >= nt256_min) ? 256 : ((cw.co % 128 == 0) ? 128 : 64);
-    const int KC = mode == CM_CONV_DOWN ? 16 : 32;          // the 17x33-pixel tile of the strided mode is staged 16 channels at a time
-    a.tiles_y = cdiv(a.GHn, 8); a.tiles_x = cdiv(a.GWn, 16); a.nchunks = cw.co / NT;
+    const char* nt256_env = std::getenv("COMODGAN_NT256");                 // experiments / tests: 0 disables the 256-column tiles
+    const bool nt256 = nt256_env ? std::atoi(nt256_env) != 0 : true;
+    const int NT = (cw.co % 256 == 0 && nt256 && MTI == 4) ? 256 : ((cw.co % 128 == 0) ? 128 : 64);
+    const int KC = mode == CM_CONV_DOWN ? 16 : 32;          // the (2GH+1)x33-pixel tile of the strided mode is staged 16 channels at a time
+    a.tiles_y = cdiv(a.GHn, GH); a.tiles_x = cdiv(a.GWn, 16); a.nchunks = cw.co / NT;
     const size_t pitch = (size_t)4 * KC + 16;                // LDS row: both fp16 planes of KC channels + 16 bytes of padding
     const size_t a_bytes = (size_t)a.IH * a.IW * pitch;
     a.off_b = (int)((a_bytes + 127) & ~(size_t)127);
-    const size_t lds = std::max<size_t>((size_t)a.off_b + (size_t)2 * NT * pitch, (size_t)128 * (NT + 4) * 4);
+    const size_t lds = std::max<size_t>((size_t)a.off_b + (size_t)2 * NT * pitch, (size_t)64 * (NT + 4) * 4);
     MIGAN_CHECK(lds <= 160 * 1024, MIGAN_EINVAL, "internal: LDS tile exceeds 160 KiB");
-    MIGAN_CHECK(a.IH * a.IW * (KC / 4) <= 256 * (KC == 32 ? 6 : 9), MIGAN_EINVAL, "internal: input tile exceeds the prefetch registers");
+    const int nia = KC == 32 ? (MTI == 4 ? 11 : 6) : (MTI == 4 ? 18 : 9);
+    MIGAN_CHECK(a.IH * a.IW * (KC / 4) <= 256 * nia, MIGAN_EINVAL, "internal: input tile exceeds the prefetch registers");
     const unsigned grid = (unsigned)((size_t)a.tiles_x * a.tiles_y * B * a.nchunks);
     const double mf = 2.0 * cw.ci * cw.co * a.ntaps * (double)a.GHn * a.GWn;
     const double by = 4.0 * ((double)cw.ci * H * Wd + (double)cw.co * a.GHn * a.GWn * (skip ? 2 : 1));
     const bool nine = a.ntaps == 9;
     MIGAN_CHECK(!nine || (cw.ci / KC) % 2 == 0, MIGAN_EINVAL, "internal: the nine-tap kernel walks channel chunks in pairs");
     MIGAN_CHECK(nine || KC == 32, MIGAN_EINVAL, "internal: no generic-tap-list kernel with 16-channel chunks");
-    if (nine && KC == 32 && NT == 256) emit(layer, "migan::cm_conv_kernel<256, 32, 6, true>", mf, mf, by, cm_conv_kernel<256, 32, 6, true>, a, grid, lds);
-    else if (nine && NT == 256) emit(layer, "migan::cm_conv_kernel<256, 16, 9, true>", mf, mf, by, cm_conv_kernel<256, 16, 9, true>, a, grid, lds);
-    else if (NT == 256) emit(layer, "migan::cm_conv_kernel<256, 32, 6, false>", mf, mf, by, cm_conv_kernel<256, 32, 6, false>, a, grid, lds);
-    else if (nine && KC == 32 && NT == 128) emit(layer, "migan::cm_conv_kernel<128, 32, 6, true>", mf, mf, by, cm_conv_kernel<128, 32, 6, true>, a, grid, lds);
-    else if (nine && KC == 32) emit(layer, "migan::cm_conv_kernel<64, 32, 6, true>", mf, mf, by, cm_conv_kernel<64, 32, 6, true>, a, grid, lds);
-    else if (nine && NT == 128) emit(layer, "migan::cm_conv_kernel<128, 16, 9, true>", mf, mf, by, cm_conv_kernel<128, 16, 9, true>, a, grid, lds);
-    else if (nine) emit(layer, "migan::cm_conv_kernel<64, 16, 9, true>", mf, mf, by, cm_conv_kernel<64, 16, 9, true>, a, grid, lds);
-    else if (NT == 128) emit(layer, "migan::cm_conv_kernel<128, 32, 6, false>", mf, mf, by, cm_conv_kernel<128, 32, 6, false>, a, grid, lds);
-    else emit(layer, "migan::cm_conv_kernel<64, 32, 6, false>", mf, mf, by, cm_conv_kernel<64, 32, 6, false>, a, grid, lds);
+    const CmConvEntry& ke = cm_pick_conv(NT, KC, nine, MTI);
+    emit(layer, ke.name, mf, mf, by, ke.fn, a, grid, lds);
   };
 
   // ---------------------------------------------------------------- buffers

@@ -60,6 +60,7 @@ struct CmConvArgs {
   int tiles_x, tiles_y, nchunks;
   int raw;                      // 1: store acc * coef only (transposed-convolution phases; cm_upfir_kernel finishes the layer)
   int off_b, off_g;             // LDS carve in bytes: B tile buffers; the result tile aliases everything
+  unsigned long long* prof;     // phase-cycle accumulators (MIGAN_PHASE_PROF builds only), else null
 };
 
 // LDS layout of the A (input tile) and B (weight tile) operands: one row per pixel / output channel holding both fp16
@@ -89,13 +90,15 @@ MIGAN_DEVICE MIGAN_INLINE int cm_pixel_of_row(int r) {
 //   NIA : float4 input-tile items per thread per chunk = ceil(tile pixels * KC/4 / 256) (prefetch registers)
 //   NINE: the tap list has exactly nine entries and CI / KC is even (plain and strided 3x3): K loop unrolled over two
 //         chunks, two weight tiles in flight
-//   NT = 256: one workgroup per CU, one wave per SIMD with the 512-register budget; each wave owns 64 x 128 (12 operand reads per
-//         24 MFMAs instead of 16, twice the MFMA work per barrier)
-template <int NT, int KC, int NIA, bool NINE>
-MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, (NT == 256 ? 1 : 2)) cm_conv_kernel(const CmConvArgs p) {
+//   MTI : 32-row MFMA tiles per wave along M: the workgroup owns MT = 64 * MTI grid pixels ((4 * MTI) x 16).  MTI = 4 (16 x 16
+//         pixels): every weight tile fetched from L2 feeds twice the MFMAs -- the weight-tile stream (MT-independent bytes per
+//         workgroup and tap) is what saturates the per-CU vector-memory path with 128-pixel tiles
+//   Register budget: accumulators MTI * NT/64 * 16; more than 64 of them -> one workgroup per CU, one wave per SIMD (512 registers)
+template <int NT, int KC, int NIA, bool NINE, int MTI>
+MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, ((MTI * NT > 256) ? 1 : 2)) cm_conv_kernel(const CmConvArgs p) {
   MIGAN_DYN_SMEM(smem);
-  constexpr int MT = 128, GW = 16;
-  constexpr int WCOLS = NT / 2, NTI = WCOLS / 32, MTI = 2;
+  constexpr int MT = 64 * MTI, GW = 16, GH = MT / GW, WROWS = 32 * MTI;
+  constexpr int WCOLS = NT / 2, NTI = WCOLS / 32;
   constexpr int GS = NT + 4;
   constexpr int RB = KC * 2;                                  // bytes of one plane of one row
   constexpr int PB = 2 * RB + 16;                             // LDS row pitch in bytes (both planes + pad)
@@ -110,14 +113,14 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, (NT == 256 ? 1 : 2)) cm_conv_kernel(c
   const int ty = t % p.tiles_y; t /= p.tiles_y;
   const int b = t;
   const int co0 = nc * NT;
-  const int gy0 = ty * 8, gx0 = tx * GW;
+  const int gy0 = ty * GH, gx0 = tx * GW;
   const int iy0 = gy0 * p.stride + p.dymin, ix0 = gx0 * p.stride + p.dxmin;
   const int npix = p.IH * p.IW;
   const int nck = p.CI / KC;
 
   char* a_s = reinterpret_cast<char*>(smem);                  // [npix][PB]
   char* b_s = reinterpret_cast<char*>(smem) + p.off_b;        // [2 buffers][NT][PB]
-  float* g_s = smem;                                          // [MT][GS] after the K loop
+  float* g_s = smem;                                          // [64][GS] per epilogue pass, after the K loop
   constexpr int b_buf = NT * PB;
 
   const float* __restrict__ xb = p.x + (size_t)b * p.H * p.W * p.CI;
@@ -132,6 +135,9 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, (NT == 256 ? 1 : 2)) cm_conv_kernel(c
     for (int j = 0; j < NTI; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+  // phase profile (MIGAN_PHASE_PROF builds): 0 prologue, 1 load issue, 2 LDS reads + MFMAs, 3 weight tile -> LDS (incl. the wait for
+  // its loads), 4 barrier, 5 input tile -> LDS + barrier, 6 epilogue
+  PROF_BEGIN();
 
   // ---- input-tile items of this thread: item = tid + k*256 -> pixel q = item / QK, channel quad c4 = item % QK
   // (c4 is the same for every k).  goff = element offset of the pixel's channel 0 in the image, -1 = zero padding / no item.
@@ -199,7 +205,7 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, (NT == 256 ? 1 : 2)) cm_conv_kernel(c
   int a_off[MTI], b_off[NTI];
 #pragma unroll
   for (int i = 0; i < MTI; ++i) {
-    const int m = cm_pixel_of_row(wm * 64 + i * 32 + l31);
+    const int m = cm_pixel_of_row(wm * WROWS + i * 32 + l31);
     a_off[i] = (((m >> 4) * p.stride) * p.IW + (m & 15) * p.stride) * PB + half * 16;
   }
 #pragma unroll
@@ -213,6 +219,35 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, (NT == 256 ? 1 : 2)) cm_conv_kernel(c
     for (int i = 0; i < MTI; ++i) aa[i] = a_s + (a_off[i] + delta);
 #pragma unroll
     for (int j = 0; j < NTI; ++j) bb[j] = b_s + (b_off[j] + buf * b_buf);
+    if constexpr (MTI * NT > 256 && MTI * NTI <= 8) {
+      // one wave per SIMD: nobody else hides the LDS latency, so all operand reads of the tap (both 16-k steps) are issued
+      // up front; the MFMAs of the first step start as soon as its fragments have landed while the second step's stream in
+      constexpr int NKS = KC / 16;
+      f4 av[NKS][MTI][2], bv[NKS][NTI][2];
+#pragma unroll
+      for (int ks = 0; ks < NKS; ++ks) {
+#pragma unroll
+        for (int i = 0; i < MTI; ++i) {
+          av[ks][i][0] = ld4(reinterpret_cast<const float*>(aa[i] + ks * 32));
+          av[ks][i][1] = ld4(reinterpret_cast<const float*>(aa[i] + ks * 32 + RB));
+        }
+#pragma unroll
+        for (int j = 0; j < NTI; ++j) {
+          bv[ks][j][0] = ld4(reinterpret_cast<const float*>(bb[j] + ks * 32));
+          bv[ks][j][1] = ld4(reinterpret_cast<const float*>(bb[j] + ks * 32 + RB));
+        }
+      }
+      MIGAN_SCHED_FENCE();
+#pragma unroll
+      for (int ks = 0; ks < NKS; ++ks)
+#pragma unroll
+        for (int pr = 0; pr < 3; ++pr)
+#pragma unroll
+          for (int i = 0; i < MTI; ++i)
+#pragma unroll
+            for (int j = 0; j < NTI; ++j)
+              acc[i][j] = MIGAN_MFMA_F16_32X32X16(av[ks][i][pr == 0 ? 1 : 0], bv[ks][j][pr == 1 ? 1 : 0], acc[i][j]);
+    } else {
 #pragma unroll
     for (int ks = 0; ks < KC / 16; ++ks) {
       f4 av[MTI][2], bv[NTI][2];
@@ -235,6 +270,7 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, (NT == 256 ? 1 : 2)) cm_conv_kernel(c
 #pragma unroll
           for (int j = 0; j < NTI; ++j)
             acc[i][j] = MIGAN_MFMA_F16_32X32X16(av[i][pr == 0 ? 1 : 0], bv[j][pr == 1 ? 1 : 0], acc[i][j]);
+    }
     }
   };
 
@@ -282,16 +318,51 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, (NT == 256 ? 1 : 2)) cm_conv_kernel(c
       if constexpr (TP == 7) load_a(c + 1 < nck ? c + 1 : c);
       const bool inside = c + CN < nck;                        // beyond the end: re-load the last tile (never used)
       load_b(inside ? c + CN : nck - 1, inside ? TN : 8, IntT<PAR>{});
-      MIGAN_SCHED_FENCE();
-      mfma_tap(TP, PAR);
-      MIGAN_SCHED_FENCE();
-      store_b(PAR ^ 1, IntT<PAR ^ 1>{});
-      __syncthreads();
+      if constexpr (MTI == 2) {
+        // Two-waves-per-SIMD tiles: instruction-class pipeline hints instead of hard fences (phase profile: 30 % of a tap went
+        // to issuing the weight loads, storing the previous tile to LDS and the barrier, serialised around the MFMAs): first
+        // 16-k step's operand reads, the weight-tile loads spread over its MFMAs, then the second step.  Measured +8..12 % on
+        // the 64- and 128-column kernels; the 512-register 16 x 16 tiles lose 5 % with it and keep the fences.
+        mfma_tap(TP, PAR);
+        store_b(PAR ^ 1, IntT<PAR ^ 1>{});
+        constexpr int M = MTI * NTI * 3, RD = (MTI + NTI) * 2, NKS = KC / 16;
+        constexpr int A1 = M / BPIECES > 0 ? M / BPIECES : 1;
+        MIGAN_SCHED_GROUP(0x100, RD);
+#pragma unroll
+        for (int k = 0; k < BPIECES; ++k) {
+          MIGAN_SCHED_GROUP(0x008, A1);
+          MIGAN_SCHED_GROUP(0x020, 1);
+        }
+        if constexpr (M - A1 * BPIECES > 0) MIGAN_SCHED_GROUP(0x008, M - A1 * BPIECES);
+        if constexpr (NKS == 2) {
+          MIGAN_SCHED_GROUP(0x100, RD);
+#pragma unroll
+          for (int k = 0; k < BPIECES; ++k) {
+            MIGAN_SCHED_GROUP(0x008, A1);
+            MIGAN_SCHED_GROUP(0x200, 1);
+          }
+          if constexpr (M - A1 * BPIECES > 0) MIGAN_SCHED_GROUP(0x008, M - A1 * BPIECES);
+        } else {
+          MIGAN_SCHED_GROUP(0x200, BPIECES);
+        }
+        __syncthreads();
+      } else {
+        MIGAN_SCHED_FENCE();
+        PROF_MARK(1);
+        mfma_tap(TP, PAR);
+        MIGAN_SCHED_FENCE();
+        PROF_MARK(2);
+        store_b(PAR ^ 1, IntT<PAR ^ 1>{});
+        PROF_MARK(3);
+        __syncthreads();
+        PROF_MARK(4);
+      }
     };
     auto chunk9 = [&](int c, auto cpar) {
       constexpr int CP = decltype(cpar)::value;         // parity of the chunk's first global tap index
       store_a(c);
       __syncthreads();
+      PROF_MARK(5);
       tap9(c, IntT<0>{}, IntT<CP>{});     tap9(c, IntT<1>{}, IntT<CP ^ 1>{}); tap9(c, IntT<2>{}, IntT<CP>{});
       tap9(c, IntT<3>{}, IntT<CP ^ 1>{}); tap9(c, IntT<4>{}, IntT<CP>{});     tap9(c, IntT<5>{}, IntT<CP ^ 1>{});
       tap9(c, IntT<6>{}, IntT<CP>{});     tap9(c, IntT<7>{}, IntT<CP ^ 1>{}); tap9(c, IntT<8>{}, IntT<CP>{});
@@ -300,44 +371,51 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, (NT == 256 ? 1 : 2)) cm_conv_kernel(c
     load_b(0, 0, IntT<0>{});
     load_b(0, 1, IntT<1>{});
     store_b(0, IntT<0>{});
+    PROF_MARK(0);
     for (int c = 0; c < nck; c += 2) {      // nck is even (host check)
       chunk9(c, IntT<0>{});
       chunk9(c + 1, IntT<1>{});
     }
   }
 
-  // ---- epilogue: accumulators -> LDS result tile -> per float4: coefficient, noise, bias, activation, skip
+  // ---- epilogue, one pass per MFMA row tile i (64 GEMM rows: rows i*32..i*32+31 of both wave rows): accumulators -> LDS result
+  // tile -> per float4: coefficient, noise, bias, activation, skip
+  const float inv_wscale = 1.0f / reinterpret_cast<const float*>(p.wsplit)[-2];      // power of two (cm_split_conv_kernel)
+  const float ns = p.noise ? p.noise_strength[0] : 0.0f;
+  constexpr int QN = NT / 4;
 #pragma unroll
-  for (int i = 0; i < MTI; ++i)
+  for (int i = 0; i < MTI; ++i) {
+    if (i > 0) __syncthreads();            // the previous pass has been read (pass 0: the K loop ended with a barrier)
 #pragma unroll
     for (int j = 0; j < NTI; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int row = cm_pixel_of_row(wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half);
+        const int lrow = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
         const int col = wn * WCOLS + j * 32 + l31;
-        g_s[row * GS + col] = acc[i][j][r];
+        g_s[lrow * GS + col] = acc[i][j][r];
       }
-  __syncthreads();
-  const float inv_wscale = 1.0f / reinterpret_cast<const float*>(p.wsplit)[-2];      // power of two (cm_split_conv_kernel)
-  const float ns = p.noise ? p.noise_strength[0] : 0.0f;
-  constexpr int QN = NT / 4;
-  for (int item = tid; item < MT * QN; item += 256) {
-    const int q4 = item % QN, m = item / QN;
-    const int gy = gy0 + (m >> 4), gx = gx0 + (m & 15);
-    if (gy >= p.GHn || gx >= p.GWn) continue;
-    const int oy = gy * p.oy_mul + p.oy_add, ox = gx * p.ox_mul + p.ox_add;
-    const int co = co0 + q4 * 4;
-    f4 cf = p.coef ? ld4(p.coef + (size_t)b * p.CO + co) : f4{p.cgain, p.cgain, p.cgain, p.cgain};
-    cf = cf * inv_wscale;
-    f4 v = ld4(g_s + m * GS + q4 * 4) * cf;
-    const size_t o = (((size_t)b * p.HO + oy) * p.WO + ox) * p.CO + co;
-    if (!p.raw) {
-      if (p.noise) v = v + MIGAN_FMUL_RN(p.noise[(size_t)b * p.noise_bstride + (size_t)oy * p.WO + ox], ns);
-      v = act4(v + ld4(p.bias + co));
-      if (p.skip) v = v + ld4once(p.skip + o);
+    __syncthreads();
+    for (int item = tid; item < 64 * QN; item += 256) {
+      const int q4 = item % QN, lrow = item / QN;
+      const int m = cm_pixel_of_row((lrow >> 5) * WROWS + i * 32 + (lrow & 31));
+      const int gy = gy0 + (m >> 4), gx = gx0 + (m & 15);
+      if (gy >= p.GHn || gx >= p.GWn) continue;
+      const int oy = gy * p.oy_mul + p.oy_add, ox = gx * p.ox_mul + p.ox_add;
+      const int co = co0 + q4 * 4;
+      f4 cf = p.coef ? ld4(p.coef + (size_t)b * p.CO + co) : f4{p.cgain, p.cgain, p.cgain, p.cgain};
+      cf = cf * inv_wscale;
+      f4 v = ld4(g_s + lrow * GS + q4 * 4) * cf;
+      const size_t o = (((size_t)b * p.HO + oy) * p.WO + ox) * p.CO + co;
+      if (!p.raw) {
+        if (p.noise) v = v + MIGAN_FMUL_RN(p.noise[(size_t)b * p.noise_bstride + (size_t)oy * p.WO + ox], ns);
+        v = act4(v + ld4(p.bias + co));
+        if (p.skip) v = v + ld4once(p.skip + o);
+      }
+      st4o(p.y + o, v);
     }
-    st4o(p.y + o, v);
   }
+  PROF_MARK(6);
+  PROF_END();
 }
 
 // ------------------------------------------------------------------------------------------------

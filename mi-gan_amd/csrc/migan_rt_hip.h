@@ -44,6 +44,9 @@ __device__ __forceinline__ float migan_swizzle_xor(float v) {
 }
 #define MIGAN_SWIZZLE_XOR(v, m) migan_swizzle_xor<(m)>(v)
 #define MIGAN_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+// instruction-class pipeline hints for the machine scheduler: the next `n` instructions of class `mask` (0x8 MFMA, 0x20 VMEM
+// read, 0x100 DS read, 0x200 DS write) form one group; groups are laid out in the order these calls appear
+#define MIGAN_SCHED_GROUP(mask, n) __builtin_amdgcn_sched_group_barrier((mask), (n), 0)
 #define MIGAN_STORE_NT(ptr, v) __builtin_nontemporal_store((v), (ptr))
 #define MIGAN_LOAD_NT(ptr) __builtin_nontemporal_load(ptr)
 #define MIGAN_OPAQUE(x) asm volatile("" : "+v"(x))

@@ -89,7 +89,7 @@ def test_generator_matches_reference_golden(tag):
     y, _, info = run_emu(cfg, sd, x, z, psi=float(g["psi"]))
     assert np.abs(y - g["y"]).max() <= 1e-3, np.abs(y - g["y"]).max()
     kernels = {i["kernel"] for i in info}
-    assert ("migan::cm_conv_kernel<128, 32, 6, true>" if "c128" in tag else "migan::cm_conv_kernel<64, 32, 6, true>") in kernels
+    assert ("migan::cm_conv_kernel<128, 32, 6, 1, 2>" if "c128" in tag else "migan::cm_conv_kernel<64, 32, 6, 1, 2>") in kernels
 
 
 @pytest.mark.parametrize("mode", ["none", "random"])
@@ -148,13 +148,25 @@ def test_c_abi_edge_cases():
 
 
 def test_256_column_tiles(monkeypatch):
-    """cm_conv_kernel<256, ...> (one wave per SIMD, 64 x 128 wave tiles) on a 256-channel geometry, all three modes, vs the oracle."""
-    monkeypatch.setenv("COMODGAN_NT256_MINRES", "4")
-    cfg = cs.Config(resolution=16, ch_base=8192, ch_max=256, num_ws=cs.default_num_ws(16))
+    """cm_conv_kernel<256, ..., 4> (16 x 16 pixels x 256 channels per workgroup, one wave per SIMD with 128 x 128 wave tiles) on a
+    256-channel geometry, all three modes, vs the oracle."""
+    monkeypatch.setenv("COMODGAN_MTI", "4")          # the host picks these tiles for large launches only
+    cfg = cs.Config(resolution=32, ch_base=8192, ch_max=256, num_ws=cs.default_num_ws(32))
     sd = pkg.synth.make_comodgan_state_dict(cfg, 21)
-    x, z = pkg.synth.make_input(1, 16, 21), pkg.synth.make_latent(1, 512, 21)
+    x, z = pkg.synth.make_input(1, 32, 21), pkg.synth.make_latent(1, 512, 21)
     y, _, info = run_emu(cfg, sd, x, z)
     kernels = {i["kernel"] for i in info}
-    assert {"migan::cm_conv_kernel<256, 32, 6, true>", "migan::cm_conv_kernel<256, 16, 9, true>", "migan::cm_conv_kernel<256, 32, 6, false>"} <= kernels
-    want = orc.generator(x, z, sd, 16, cfg.num_ws)
+    assert {"migan::cm_conv_kernel<256, 32, 11, 1, 4>", "migan::cm_conv_kernel<256, 16, 18, 1, 4>",
+            "migan::cm_conv_kernel<256, 32, 11, 0, 4>"} <= kernels, kernels
+    want = orc.generator(x, z, sd, 32, cfg.num_ws)
     assert np.abs(y - want).max() <= 1e-3, np.abs(y - want).max()
+
+
+def test_small_tiles_forced(monkeypatch):
+    """COMODGAN_MTI=2 keeps every layer on the 8 x 16 pixel tiles (the pre-16x16 kernels stay tested)."""
+    monkeypatch.setenv("COMODGAN_MTI", "2")
+    g, cfg, sd, x, z = case("r32_c128")
+    y, _, info = run_emu(cfg, sd, x[:1], z[:1])
+    assert all(", 4>" not in i["kernel"] for i in info if "cm_conv" in i["kernel"])
+    want = orc.generator(x[:1], z[:1], sd, cfg.resolution, cfg.num_ws)
+    assert np.abs(y - want).max() <= 1e-3
