@@ -287,8 +287,24 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, ((MTI * NT > 256) ? 1 : 2)) cm_conv_k
       if (cn == nck) { cn = c; tn = tp; }
       load_b(cn, tn, IntT<0>{});
       if constexpr (decltype(prefetch_a)::value) load_a(c + 1 < nck ? c + 1 : c);
-      MIGAN_SCHED_FENCE();        // keep the loads ahead of the MFMAs (the scheduler otherwise sinks them to their use)
-      mfma_tap(tp, it & 1);
+      if constexpr (MTI == 2 && !decltype(prefetch_a)::value) {
+        // same pipeline hints as the nine-tap path: operand reads, weight loads spread over the first step's MFMAs
+        mfma_tap(tp, it & 1);
+        constexpr int M = MTI * NTI * 3, RD = (MTI + NTI) * 2;
+        constexpr int A1 = M / BPIECES > 0 ? M / BPIECES : 1;
+        MIGAN_SCHED_GROUP(0x100, RD);
+#pragma unroll
+        for (int k = 0; k < BPIECES; ++k) {
+          MIGAN_SCHED_GROUP(0x008, A1);
+          MIGAN_SCHED_GROUP(0x020, 1);
+        }
+        if constexpr (M - A1 * BPIECES > 0) MIGAN_SCHED_GROUP(0x008, M - A1 * BPIECES);
+        MIGAN_SCHED_GROUP(0x100, RD);
+        MIGAN_SCHED_GROUP(0x008, M);
+      } else {
+        MIGAN_SCHED_FENCE();        // keep the loads ahead of the MFMAs (the scheduler otherwise sinks them to their use)
+        mfma_tap(tp, it & 1);
+      }
       MIGAN_SCHED_FENCE();
       store_b((it + 1) & 1, IntT<0>{});
       __syncthreads();

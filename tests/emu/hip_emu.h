@@ -57,6 +57,7 @@ struct Block {
   int wave_alive[kMaxWaves] = {0};
   float xa[kMaxWaves][64], xb[kMaxWaves][64];
   unsigned xq[kMaxWaves][64][4], yq[kMaxWaves][64][4];
+  float xf[kMaxWaves][64][8], yf[kMaxWaves][64][8];       // decoded 16-bit MFMA operands
   void (*invoke)(const void*) = nullptr;
   const void* arg = nullptr;
   char* stacks = nullptr;
@@ -228,10 +229,10 @@ inline float hipemu_f16_to_f32(unsigned h) {
 inline emu_f16v hipemu_mfma_16b_32x32x16(emu_f4 a, emu_f4 bv, emu_f16v c, bool f16) {
   hipemu::Block* b = hipemu::tl_blk;
   const int w = b->cur >> 6, l = b->cur & 63;
-  std::memcpy(b->xq[w][l], &a, 16);
-  std::memcpy(b->yq[w][l], &bv, 16);
-  hipemu::wave_barrier();
-  const int j = l & 31, hh = l >> 5;
+  // every lane decodes its own 8 + 8 operand elements once (into the exchange area, as floats), then reads the others'
+  unsigned qa[4], qb[4];
+  std::memcpy(qa, &a, 16);
+  std::memcpy(qb, &bv, 16);
   auto elem = [f16](const unsigned* q, int e) {
     const unsigned pk = q[e >> 1];
     if (f16) return hipemu_f16_to_f32((e & 1) ? (pk >> 16) : (pk & 0xffffu));
@@ -240,11 +241,20 @@ inline emu_f16v hipemu_mfma_16b_32x32x16(emu_f4 a, emu_f4 bv, emu_f16v c, bool f
     std::memcpy(&f, &bits, 4);
     return f;
   };
+  float* fa = reinterpret_cast<float*>(b->xq[w][l]);      // 4 words of xq + 4 words of yq per lane are not enough for 16 floats:
+  float* fb = reinterpret_cast<float*>(b->yq[w][l]);      // the decoded operands live in xf / yf below
+  (void)fa; (void)fb;
+  for (int e = 0; e < 8; ++e) {
+    b->xf[w][l][e] = elem(qa, e);
+    b->yf[w][l][e] = elem(qb, e);
+  }
+  hipemu::wave_barrier();
+  const int j = l & 31, hh = l >> 5;
   for (int r = 0; r < 16; ++r) {
     const int i = (r & 3) + 8 * (r >> 2) + 4 * hh;
     double s = 0.0;
     for (int k = 0; k < 16; ++k)
-      s += (double)elem(b->xq[w][i + 32 * (k >> 3)], k & 7) * (double)elem(b->yq[w][j + 32 * (k >> 3)], k & 7);
+      s += (double)b->xf[w][i + 32 * (k >> 3)][k & 7] * (double)b->yf[w][j + 32 * (k >> 3)][k & 7];
     c[r] = (float)((double)c[r] + s);
   }
   hipemu::wave_barrier();

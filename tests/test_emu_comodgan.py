@@ -151,14 +151,14 @@ def test_256_column_tiles(monkeypatch):
     """cm_conv_kernel<256, ..., 4> (16 x 16 pixels x 256 channels per workgroup, one wave per SIMD with 128 x 128 wave tiles) on a
     256-channel geometry, all three modes, vs the oracle."""
     monkeypatch.setenv("COMODGAN_MTI", "4")          # the host picks these tiles for large launches only
-    cfg = cs.Config(resolution=32, ch_base=8192, ch_max=256, num_ws=cs.default_num_ws(32))
+    cfg = cs.Config(resolution=16, ch_base=8192, ch_max=256, num_ws=cs.default_num_ws(16))
     sd = pkg.synth.make_comodgan_state_dict(cfg, 21)
-    x, z = pkg.synth.make_input(1, 32, 21), pkg.synth.make_latent(1, 512, 21)
+    x, z = pkg.synth.make_input(1, 16, 21), pkg.synth.make_latent(1, 512, 21)
     y, _, info = run_emu(cfg, sd, x, z)
     kernels = {i["kernel"] for i in info}
     assert {"migan::cm_conv_kernel<256, 32, 11, 1, 4>", "migan::cm_conv_kernel<256, 16, 18, 1, 4>",
             "migan::cm_conv_kernel<256, 32, 11, 0, 4>"} <= kernels, kernels
-    want = orc.generator(x, z, sd, 32, cfg.num_ws)
+    want = orc.generator(x, z, sd, 16, cfg.num_ws)
     assert np.abs(y - want).max() <= 1e-3, np.abs(y - want).max()
 
 
