@@ -43,15 +43,25 @@ def gather_outputs(y_local: torch.Tensor, total: int, group=None) -> torch.Tenso
     return torch.cat([p[:s] for p, s in zip(parts, sizes)], dim=0)
 
 
-def sharded_forward(forward: Callable[[torch.Tensor], torch.Tensor], x_global: torch.Tensor,
-                    group=None, gather: bool = True) -> torch.Tensor:
-    """Run ``forward`` on this rank's slice of ``x_global`` and (optionally) gather all outputs."""
+def sharded_forward(forward: Callable[..., torch.Tensor], x_global, group=None, gather: bool = True) -> torch.Tensor:
+    """Run ``forward`` on this rank's slice of ``x_global`` and (optionally) gather all outputs.
+
+    ``x_global`` is one tensor or a tuple of tensors sharing the batch dimension, all sliced alike and passed as
+    positional arguments -- e.g. ``(x, z)`` for the Co-Mod-GAN generator, whose latent is per image
+    (``sharded_forward(lambda x, z: model(x, z=z, noise_mode="const"), (x, z))``).  Co-Mod-GAN images interact only through
+    the batch-wide style normalisation (stylegan.py:139), which the demodulation cancels up to its 1e-8 epsilon, so the
+    gathered output equals the single-GPU output to fp32 rounding rather than bit for bit."""
+    many = isinstance(x_global, (tuple, list))
+    xs = tuple(x_global) if many else (x_global,)
+    total = xs[0].shape[0]
+    if any(t.shape[0] != total for t in xs):
+        raise ValueError("all sharded inputs need the same batch size")
     if not dist.is_initialized():
-        return forward(x_global)
+        return forward(*xs)
     rank, world = dist.get_rank(group), dist.get_world_size(group)
-    lo, hi = shard_range(x_global.shape[0], rank, world)
-    y = forward(x_global[lo:hi])
-    return gather_outputs(y, x_global.shape[0], group) if gather else y
+    lo, hi = shard_range(total, rank, world)
+    y = forward(*(t[lo:hi] for t in xs))
+    return gather_outputs(y, total, group) if gather else y
 
 
 class OutputGather:

@@ -113,3 +113,40 @@ def test_output_gather_pipeline_world2_gloo(tmp_path):
             blk = a[i, 3 * r:3 * r + 3]
             assert np.all(blk[:, 1:] == 100 * i + r)    # rank r's shard of step i, in rank order
             np.testing.assert_array_equal(blk[:, 0, 0, 0], np.arange(3) + 10 * r)
+
+
+def _worker_comodgan(rank, world, port, total, out_dir):
+    sys.path.insert(0, ROOT)
+    import importlib
+    pkg = importlib.import_module("mi-gan_amd")
+    from oracle import comodgan_oracle as corc
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    cs = pkg.comodgan_schema
+    cfg = cs.Config(resolution=16, ch_base=1024, ch_max=64, num_ws=cs.default_num_ws(16))
+    sd = pkg.synth.make_comodgan_state_dict(cfg, 1)
+    x = torch.from_numpy(pkg.synth.make_input(total, 16, seed=2))
+    z = torch.from_numpy(pkg.synth.make_latent(total, 512, seed=2))
+    fwd = lambda xs, zs: torch.from_numpy(corc.generator(xs.numpy(), zs.numpy(), sd, 16, cfg.num_ws))
+    y_all = pkg.distributed.sharded_forward(fwd, (x, z))          # image and latent sliced alike
+    np.save(os.path.join(out_dir, f"cm_{rank}.npy"), y_all.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_comodgan_forward_world2_gloo(pkg, tmp_path):
+    """Co-Mod-GAN takes (x, z) per image: both are sharded; the gathered output equals the whole-batch output up to the
+    batch-wide style normalisation's epsilon (stylegan.py:139,147)."""
+    from oracle import comodgan_oracle as corc
+    cs = pkg.comodgan_schema
+    total, world = 3, 2
+    mp.spawn(_worker_comodgan, args=(world, _free_port(), total, str(tmp_path)), nprocs=world, join=True)
+    cfg = cs.Config(resolution=16, ch_base=1024, ch_max=64, num_ws=cs.default_num_ws(16))
+    sd = pkg.synth.make_comodgan_state_dict(cfg, 1)
+    want = corc.generator(pkg.synth.make_input(total, 16, seed=2), pkg.synth.make_latent(total, 512, seed=2), sd, 16, cfg.num_ws)
+    for r in range(world):
+        got = np.load(tmp_path / f"cm_{r}.npy")
+        assert got.shape == want.shape
+        assert np.abs(got - want).max() <= 1e-4 * max(1.0, np.abs(want).max())
