@@ -40,18 +40,18 @@ struct CmDebugTensor {
 
 typedef void (*CmConvFn)(const CmConvArgs);
 struct CmConvEntry { int NT, KC, nine, MTI; CmConvFn fn; const char* name; };
-#define CM_CONV_ENTRY(NT, KC, NIA, NINE, MTI) {NT, KC, NINE, MTI, cm_conv_kernel<NT, KC, NIA, (NINE != 0), MTI>, "migan::cm_conv_kernel<" #NT ", " #KC ", " #NIA ", " #NINE ", " #MTI ">"}
+#define CM_CONV_ENTRY(NT, KC, NIA, NINE, MTI) {NT, KC, NINE, MTI, cm_conv_kernel<NT, KC, NIA, NINE, MTI>, "migan::cm_conv_kernel<" #NT ", " #KC ", " #NIA ", " #NINE ", " #MTI ">"}
 inline const std::vector<CmConvEntry>& cm_conv_table() {
   static const std::vector<CmConvEntry> t = {
       // 8 x 16 pixel tiles (MTI 2): nine-tap unrolled K loop (plain: 10x18-pixel tile, 6 items; strided: 17x33 at 16 channels, 9 items)
-      CM_CONV_ENTRY(64, 32, 6, 1, 2), CM_CONV_ENTRY(128, 32, 6, 1, 2), CM_CONV_ENTRY(256, 32, 6, 1, 2),
-      CM_CONV_ENTRY(64, 16, 9, 1, 2), CM_CONV_ENTRY(128, 16, 9, 1, 2), CM_CONV_ENTRY(256, 16, 9, 1, 2),
+      CM_CONV_ENTRY(64, 32, 6, true, 2), CM_CONV_ENTRY(128, 32, 6, true, 2), CM_CONV_ENTRY(256, 32, 6, true, 2),
+      CM_CONV_ENTRY(64, 16, 9, true, 2), CM_CONV_ENTRY(128, 16, 9, true, 2), CM_CONV_ENTRY(256, 16, 9, true, 2),
       // generic tap list (transposed-convolution phases)
-      CM_CONV_ENTRY(64, 32, 6, 0, 2), CM_CONV_ENTRY(128, 32, 6, 0, 2), CM_CONV_ENTRY(256, 32, 6, 0, 2),
+      CM_CONV_ENTRY(64, 32, 6, false, 2), CM_CONV_ENTRY(128, 32, 6, false, 2), CM_CONV_ENTRY(256, 32, 6, false, 2),
       // 16 x 16 pixel tiles (MTI 4): plain 18x18 tile = 11 items; strided 33x33 at 16 channels = 18 items
-      CM_CONV_ENTRY(64, 32, 11, 1, 4), CM_CONV_ENTRY(128, 32, 11, 1, 4), CM_CONV_ENTRY(256, 32, 11, 1, 4),
-      CM_CONV_ENTRY(64, 16, 18, 1, 4), CM_CONV_ENTRY(128, 16, 18, 1, 4), CM_CONV_ENTRY(256, 16, 18, 1, 4),
-      CM_CONV_ENTRY(64, 32, 11, 0, 4), CM_CONV_ENTRY(128, 32, 11, 0, 4), CM_CONV_ENTRY(256, 32, 11, 0, 4),
+      CM_CONV_ENTRY(64, 32, 11, true, 4), CM_CONV_ENTRY(128, 32, 11, true, 4), CM_CONV_ENTRY(256, 32, 11, true, 4),
+      CM_CONV_ENTRY(64, 16, 18, true, 4), CM_CONV_ENTRY(128, 16, 18, true, 4), CM_CONV_ENTRY(256, 16, 18, true, 4),
+      CM_CONV_ENTRY(64, 32, 11, false, 4), CM_CONV_ENTRY(128, 32, 11, false, 4), CM_CONV_ENTRY(256, 32, 11, false, 4),
   };
   return t;
 }

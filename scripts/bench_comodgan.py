@@ -62,6 +62,17 @@ def main():
                 rounds.append(ms)
     launches = model.launch_info()
     roof = north_star.roofline_from_launches(launches, rounds, B, "f16x2")
+    # HBM bytes per launch of the dominant kernel from the PMC passes of this same command (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE,
+    # separate runs, scripts/gpu_comodgan_traffic.sh + scripts/pmc_traffic.py); committed under profiles/, null if absent
+    tpath = os.path.join(ROOT, "profiles", "r01_comodgan_v12_pmc_traffic.json")
+    if R == 512 and B == 16 and os.path.exists(tpath):
+        try:
+            t = json.load(open(tpath)).get(roof["kernel"])
+            if t:
+                roof["traffic"] = round(t["hbm_bytes_per_launch"])
+                roof["traffic_source"] = "profiles/r01_comodgan_v12_pmc_traffic.json (rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE, avg per launch)"
+        except Exception:
+            pass
     if args.dump_layers:
         med = np.median(np.asarray(rounds), axis=0)
         with open(args.dump_layers, "w") as f:

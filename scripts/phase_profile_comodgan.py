@@ -34,7 +34,7 @@ lib.migan_prof_layer.argtypes = [C.c_int, C.POINTER(C.c_ulonglong)]
 names = ["prolog", "ld_issue", "rd+mfma", "wt->lds", "barrier", "in->lds", "epilog"]
 print(f"{'layer':28s} {'kernel':22s} {'ms':>7s} {'WGs':>7s} " + " ".join(f"{n:>9s}" for n in names) + "   total cyc/WG   mfma_cyc/wave")
 for i, (L, t) in enumerate(zip(model.launch_info(), ms)):
-    if "cm_conv_kernel" not in L["kernel"] or ", 1, " not in L["kernel"]:
+    if "cm_conv_kernel" not in L["kernel"] or ", true, " not in L["kernel"]:
         continue
     out = (C.c_ulonglong * 16)()
     if lib.migan_prof_layer(i, out) != 0 or out[8] == 0:
