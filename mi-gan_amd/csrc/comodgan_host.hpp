@@ -39,7 +39,7 @@ struct CmDebugTensor {
 };
 
 typedef void (*CmConvFn)(const CmConvArgs);
-struct CmConvEntry { int NT, KC, nine, MTI; CmConvFn fn; const char* name; };
+struct CmConvEntry { int NT, KC, nine, MTI; CmConvFn fn; const char* name; int up4 = 0; };
 #define CM_CONV_ENTRY(NT, KC, NIA, NINE, MTI) {NT, KC, NINE, MTI, cm_conv_kernel<NT, KC, NIA, NINE, MTI>, "migan::cm_conv_kernel<" #NT ", " #KC ", " #NIA ", " #NINE ", " #MTI ">"}
 inline const std::vector<CmConvEntry>& cm_conv_table() {
   static const std::vector<CmConvEntry> t = {
@@ -52,12 +52,15 @@ inline const std::vector<CmConvEntry>& cm_conv_table() {
       CM_CONV_ENTRY(64, 32, 11, true, 4), CM_CONV_ENTRY(128, 32, 11, true, 4), CM_CONV_ENTRY(256, 32, 11, true, 4),
       CM_CONV_ENTRY(64, 16, 18, true, 4), CM_CONV_ENTRY(128, 16, 18, true, 4), CM_CONV_ENTRY(256, 16, 18, true, 4),
       CM_CONV_ENTRY(64, 32, 11, false, 4), CM_CONV_ENTRY(128, 32, 11, false, 4), CM_CONV_ENTRY(256, 32, 11, false, 4),
+      // all four transposed-convolution phases in one launch (nine taps, four accumulator sets)
+      {64, 32, 1, 2, cm_conv_kernel<64, 32, 6, true, 2, true>, "migan::cm_conv_kernel<64, 32, 6, true, 2, true>", 1},
+      {128, 32, 1, 2, cm_conv_kernel<128, 32, 6, true, 2, true>, "migan::cm_conv_kernel<128, 32, 6, true, 2, true>", 1},
   };
   return t;
 }
-inline const CmConvEntry& cm_pick_conv(int NT, int KC, bool nine, int MTI) {
+inline const CmConvEntry& cm_pick_conv(int NT, int KC, bool nine, int MTI, bool up4 = false) {
   for (const auto& e : cm_conv_table())
-    if (e.NT == NT && e.KC == KC && (e.nine != 0) == nine && e.MTI == MTI) return e;
+    if (e.NT == NT && e.KC == KC && (e.nine != 0) == nine && e.MTI == MTI && (e.up4 != 0) == up4) return e;
   throw Error(MIGAN_EINVAL, "internal: no cm_conv_kernel instantiation for this tile");
 }
 
@@ -68,7 +71,7 @@ inline void cm_prepare_kernels() {
   done = true;
 }
 
-enum : int { CM_CONV_NORMAL = 0, CM_CONV_DOWN = 1, CM_CONV_UP = 2 };
+enum : int { CM_CONV_NORMAL = 0, CM_CONV_DOWN = 1, CM_CONV_UP = 2, CM_CONV_UP4 = 3 };
 
 }  // namespace migan
 
@@ -283,13 +286,15 @@ inline size_t comodgan_handle::walk(int batch, const float* x, const float* z, f
     a.prof = prof_buffer();
     // tile: 16 x 16 grid pixels (MTI 4) where the layer is large enough, else 8 x 16
     const char* mti_env = std::getenv("COMODGAN_MTI");                     // experiments / tests: force 2 or 4
-    const int ghn = mode == CM_CONV_UP ? H + (ey == 0) : HO, gwn = mode == CM_CONV_UP ? Wd + (ex == 0) : WO;
+    const int ghn = mode == CM_CONV_UP4 ? H + 1 : (mode == CM_CONV_UP ? H + (ey == 0) : HO);
+    const int gwn = mode == CM_CONV_UP4 ? Wd + 1 : (mode == CM_CONV_UP ? Wd + (ex == 0) : WO);
     // 16 x 16 pixels x 256 channels per workgroup (one wave per SIMD, 128 x 128 wave tiles) pays where Cout allows it and the
     // launch still has two workgroups per CU (measured: +5..15 % at >= 64^2 with 256/512 channels, a loss on smaller launches
     // and with 128- or 64-column tiles)
     const size_t wgs16 = (size_t)cdiv(ghn, 16) * cdiv(gwn, 16) * B * (cw.co / 256);
     int MTI = (cw.co % 256 == 0 && std::min(ghn, gwn) >= 16 && wgs16 >= 512) ? 4 : 2;
     if (mti_env && (std::atoi(mti_env) == 2 || std::atoi(mti_env) == 4)) MTI = std::atoi(mti_env);
+    if (mode == CM_CONV_UP4) MTI = 2;
     const int GH = 4 * MTI;
     if (mode == CM_CONV_NORMAL) {
       a.stride = 1;
@@ -301,6 +306,13 @@ inline size_t comodgan_handle::walk(int batch, const float* x, const float* z, f
       for (int ky = 0; ky < 3; ++ky)
         for (int kx = 0; kx < 3; ++kx) { a.dy[a.ntaps] = ky; a.dx[a.ntaps] = kx; a.wtap[a.ntaps] = ky * 3 + kx; ++a.ntaps; }
       a.dymin = 0; a.dxmin = 0; a.IH = 2 * GH + 1; a.IW = 33; a.GHn = HO; a.GWn = WO;
+    } else if (mode == CM_CONV_UP4) {
+      // every phase of conv_transpose2d(stride 2) at once: tap (ky, kx) feeds the phase (ky == 1, kx == 1) from x[g - (k == 2)]
+      a.stride = 1;
+      for (int ky = 0; ky < 3; ++ky)
+        for (int kx = 0; kx < 3; ++kx) { a.dy[a.ntaps] = ky == 2 ? -1 : 0; a.dx[a.ntaps] = kx == 2 ? -1 : 0; a.wtap[a.ntaps] = ky * 3 + kx; ++a.ntaps; }
+      a.dymin = -1; a.dxmin = -1; a.IH = GH + 1; a.IW = 17; a.GHn = H + 1; a.GWn = Wd + 1;
+      a.oy_mul = 2; a.ox_mul = 2;
     } else {
       // output phase (ey, ex) of conv_transpose2d(stride 2): raw[2g + e] = sum over taps k with k = e (mod 2) of x[g - (k - e) / 2] w[k]
       a.stride = 1;
@@ -317,7 +329,7 @@ inline size_t comodgan_handle::walk(int batch, const float* x, const float* z, f
     }
     const char* nt256_env = std::getenv("COMODGAN_NT256");                 // experiments / tests: 0 disables the 256-column tiles
     const bool nt256 = nt256_env ? std::atoi(nt256_env) != 0 : true;
-    const int NT = (cw.co % 256 == 0 && nt256 && MTI == 4) ? 256 : ((cw.co % 128 == 0) ? 128 : 64);
+    const int NT = (cw.co % 256 == 0 && nt256 && MTI == 4 && mode != CM_CONV_UP4) ? 256 : ((cw.co % 128 == 0) ? 128 : 64);
     const int KC = mode == CM_CONV_DOWN ? 16 : 32;          // the (2GH+1)x33-pixel tile of the strided mode is staged 16 channels at a time
     a.tiles_y = cdiv(a.GHn, GH); a.tiles_x = cdiv(a.GWn, 16); a.nchunks = cw.co / NT;
     const size_t pitch = (size_t)4 * KC + 16;                // LDS row: both fp16 planes of KC channels + 16 bytes of padding
@@ -328,12 +340,15 @@ inline size_t comodgan_handle::walk(int batch, const float* x, const float* z, f
     const int nia = KC == 32 ? (MTI == 4 ? 11 : 6) : (MTI == 4 ? 18 : 9);
     MIGAN_CHECK(a.IH * a.IW * (KC / 4) <= 256 * nia, MIGAN_EINVAL, "internal: input tile exceeds the prefetch registers");
     const unsigned grid = (unsigned)((size_t)a.tiles_x * a.tiles_y * B * a.nchunks);
-    const double mf = 2.0 * cw.ci * cw.co * a.ntaps * (double)a.GHn * a.GWn;
-    const double by = 4.0 * ((double)cw.ci * H * Wd + (double)cw.co * a.GHn * a.GWn * (skip ? 2 : 1));
+    // four-phase launch: the same multiply-adds and output pixels as the four single-phase launches together
+    const double mf = mode == CM_CONV_UP4 ? 2.0 * cw.ci * cw.co * ((double)(H + 1) * (Wd + 1) * 4 + 2.0 * (H + 1) * Wd + 2.0 * H * (Wd + 1) + (double)H * Wd)
+                                          : 2.0 * cw.ci * cw.co * a.ntaps * (double)a.GHn * a.GWn;
+    const double by = mode == CM_CONV_UP4 ? 4.0 * ((double)cw.ci * H * Wd + (double)cw.co * (2.0 * H + 1) * (2.0 * Wd + 1))
+                                          : 4.0 * ((double)cw.ci * H * Wd + (double)cw.co * a.GHn * a.GWn * (skip ? 2 : 1));
     const bool nine = a.ntaps == 9;
     MIGAN_CHECK(!nine || (cw.ci / KC) % 2 == 0, MIGAN_EINVAL, "internal: the nine-tap kernel walks channel chunks in pairs");
     MIGAN_CHECK(nine || KC == 32, MIGAN_EINVAL, "internal: no generic-tap-list kernel with 16-channel chunks");
-    const CmConvEntry& ke = cm_pick_conv(NT, KC, nine, MTI);
+    const CmConvEntry& ke = cm_pick_conv(NT, KC, nine, MTI, mode == CM_CONV_UP4);
     emit(layer, ke.name, mf, mf, by, ke.fn, a, grid, lds);
   };
 
@@ -500,9 +515,16 @@ inline size_t comodgan_handle::walk(int batch, const float* x, const float* z, f
       // conv0: modulated transposed convolution (4 output phases) -> FIR + noise + bias + activation, + skip (comodgan.py:329-331)
       const ConvW& c0w = conv_of(b + ".conv0");
       const Mod m0s = style_demod(b + ".conv0", c0w);
-      for (int ph = 0; ph < 4; ++ph)
-        conv(b + ".conv0.phase" + std::to_string(ph), CM_CONV_UP, ph >> 1, ph & 1, xcur, tmp, nullptr, c0w, m0s.sa, m0s.coef, 1.0f, nullptr, nullptr,
-             nullptr, 0, h, h, res + 1, res + 1, true);
+      // all four phases in one launch where Cout is a multiple of 128 (measured: better at <= 64^2, equal at 128^2 / 256^2; with
+      // 64-column tiles, 512^2, the four single-phase launches are 15 % faster).  COMODGAN_UP4=0|1 forces one form (experiments / tests).
+      const char* up4_env = std::getenv("COMODGAN_UP4");
+      if (up4_env ? std::atoi(up4_env) != 0 : (co % 128 == 0))
+        conv(b + ".conv0.phases", CM_CONV_UP4, 0, 0, xcur, tmp, nullptr, c0w, m0s.sa, m0s.coef, 1.0f, nullptr, nullptr, nullptr, 0, h, h,
+             res + 1, res + 1, true);
+      else
+        for (int ph = 0; ph < 4; ++ph)
+          conv(b + ".conv0.phase" + std::to_string(ph), CM_CONV_UP, ph >> 1, ph & 1, xcur, tmp, nullptr, c0w, m0s.sa, m0s.coef, 1.0f, nullptr,
+               nullptr, nullptr, 0, h, h, res + 1, res + 1, true);
       noise_of(b + ".conv0", res, nz, nbs);
       float* x0 = act_out(b + ".conv0", bufA, res, co);
       {

@@ -94,8 +94,12 @@ MIGAN_DEVICE MIGAN_INLINE int cm_pixel_of_row(int r) {
 //         pixels): every weight tile fetched from L2 feeds twice the MFMAs -- the weight-tile stream (MT-independent bytes per
 //         workgroup and tap) is what saturates the per-CU vector-memory path with 128-pixel tiles
 //   Register budget: accumulators MTI * NT/64 * 16; more than 64 of them -> one workgroup per CU, one wave per SIMD (512 registers)
-template <int NT, int KC, int NIA, bool NINE, int MTI>
-MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, ((MTI * NT > 256) ? 1 : 2)) cm_conv_kernel(const CmConvArgs p) {
+//   UP4 : all four output phases of the stride-2 transposed convolution in one launch (synthesis conv0): the nine taps of the 3x3
+//         kernel, each feeding the accumulator set of its phase (tap (ky, kx) -> output parity (ky == 1, kx == 1), input shift
+//         (-(ky == 2), -(kx == 2))).  The low-resolution input tile is staged once per chunk for all phases instead of once per
+//         phase launch, and the K loop has nine taps per chunk (the unrolled NINE path) instead of 1 / 2 / 2 / 4.
+template <int NT, int KC, int NIA, bool NINE, int MTI, bool UP4 = false>
+MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, ((MTI * NT * (UP4 ? 4 : 1) > 256) ? 1 : 2)) cm_conv_kernel(const CmConvArgs p) {
   MIGAN_DYN_SMEM(smem);
   constexpr int MT = 64 * MTI, GW = 16, GH = MT / GW, WROWS = 32 * MTI;
   constexpr int WCOLS = NT / 2, NTI = WCOLS / 32;
@@ -128,13 +132,17 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, ((MTI * NT > 256) ? 1 : 2)) cm_conv_k
   const unsigned w_plane_bytes = (unsigned)(9 * p.CI * p.CO) * 2u;     // bytes of one weight plane (< 2^23)
   const int total = nck * p.ntaps;
 
-  f16v acc[MTI][NTI];
+  constexpr int NPH = UP4 ? 4 : 1;                            // accumulator sets (output phases)
+  static_assert(!UP4 || NINE, "the four-phase mode runs the nine-tap K loop");
+  f16v acc[NPH][MTI][NTI];
 #pragma unroll
-  for (int i = 0; i < MTI; ++i)
+  for (int ph = 0; ph < NPH; ++ph)
 #pragma unroll
-    for (int j = 0; j < NTI; ++j)
+    for (int i = 0; i < MTI; ++i)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+      for (int j = 0; j < NTI; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[ph][i][j][r] = 0.0f;
   // phase profile (MIGAN_PHASE_PROF builds): 0 prologue, 1 load issue, 2 LDS reads + MFMAs, 3 weight tile -> LDS (incl. the wait for
   // its loads), 4 barrier, 5 input tile -> LDS + barrier, 6 epilogue
   PROF_BEGIN();
@@ -211,7 +219,8 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, ((MTI * NT > 256) ? 1 : 2)) cm_conv_k
 #pragma unroll
   for (int j = 0; j < NTI; ++j) b_off[j] = (wn * WCOLS + j * 32 + l31) * PB + half * 16;
   // MFMAs of one filter tap: A rows = the staged input tile shifted by the tap's offset, B = weight tile in LDS buffer `buf`
-  auto mfma_tap = [&](int tp, int buf) {
+  auto mfma_tap = [&](int tp, int buf, auto phc) {
+    constexpr int PH = decltype(phc)::value;                   // accumulator set of this tap
     const int delta = ((p.dy[tp] - p.dymin) * p.IW + (p.dx[tp] - p.dxmin)) * PB;       // wave-uniform
     const char* aa[MTI];
     const char* bb[NTI];
@@ -246,7 +255,7 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, ((MTI * NT > 256) ? 1 : 2)) cm_conv_k
           for (int i = 0; i < MTI; ++i)
 #pragma unroll
             for (int j = 0; j < NTI; ++j)
-              acc[i][j] = MIGAN_MFMA_F16_32X32X16(av[ks][i][pr == 0 ? 1 : 0], bv[ks][j][pr == 1 ? 1 : 0], acc[i][j]);
+              acc[PH][i][j] = MIGAN_MFMA_F16_32X32X16(av[ks][i][pr == 0 ? 1 : 0], bv[ks][j][pr == 1 ? 1 : 0], acc[PH][i][j]);
     } else {
 #pragma unroll
     for (int ks = 0; ks < KC / 16; ++ks) {
@@ -269,7 +278,7 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, ((MTI * NT > 256) ? 1 : 2)) cm_conv_k
         for (int i = 0; i < MTI; ++i)
 #pragma unroll
           for (int j = 0; j < NTI; ++j)
-            acc[i][j] = MIGAN_MFMA_F16_32X32X16(av[i][pr == 0 ? 1 : 0], bv[j][pr == 1 ? 1 : 0], acc[i][j]);
+            acc[PH][i][j] = MIGAN_MFMA_F16_32X32X16(av[i][pr == 0 ? 1 : 0], bv[j][pr == 1 ? 1 : 0], acc[PH][i][j]);
     }
     }
   };
@@ -289,7 +298,7 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, ((MTI * NT > 256) ? 1 : 2)) cm_conv_k
       if constexpr (decltype(prefetch_a)::value) load_a(c + 1 < nck ? c + 1 : c);
       if constexpr (MTI == 2 && !decltype(prefetch_a)::value) {
         // same pipeline hints as the nine-tap path: operand reads, weight loads spread over the first step's MFMAs
-        mfma_tap(tp, it & 1);
+        mfma_tap(tp, it & 1, IntT<0>{});
         constexpr int M = MTI * NTI * 3, RD = (MTI + NTI) * 2;
         constexpr int A1 = M / BPIECES > 0 ? M / BPIECES : 1;
         MIGAN_SCHED_GROUP(0x100, RD);
@@ -303,7 +312,7 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, ((MTI * NT > 256) ? 1 : 2)) cm_conv_k
         MIGAN_SCHED_GROUP(0x008, M);
       } else {
         MIGAN_SCHED_FENCE();        // keep the loads ahead of the MFMAs (the scheduler otherwise sinks them to their use)
-        mfma_tap(tp, it & 1);
+        mfma_tap(tp, it & 1, IntT<0>{});
       }
       MIGAN_SCHED_FENCE();
       store_b((it + 1) & 1, IntT<0>{});
@@ -339,7 +348,7 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, ((MTI * NT > 256) ? 1 : 2)) cm_conv_k
         // to issuing the weight loads, storing the previous tile to LDS and the barrier, serialised around the MFMAs): first
         // 16-k step's operand reads, the weight-tile loads spread over its MFMAs, then the second step.  Measured +8..12 % on
         // the 64- and 128-column kernels; the 512-register 16 x 16 tiles lose 5 % with it and keep the fences.
-        mfma_tap(TP, PAR);
+        mfma_tap(TP, PAR, IntT<(UP4 ? (((TP / 3) == 1) * 2 + ((TP % 3) == 1)) : 0)>{});
         store_b(PAR ^ 1, IntT<PAR ^ 1>{});
         constexpr int M = MTI * NTI * 3, RD = (MTI + NTI) * 2, NKS = KC / 16;
         constexpr int A1 = M / BPIECES > 0 ? M / BPIECES : 1;
@@ -365,7 +374,7 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, ((MTI * NT > 256) ? 1 : 2)) cm_conv_k
       } else {
         MIGAN_SCHED_FENCE();
         PROF_MARK(1);
-        mfma_tap(TP, PAR);
+        mfma_tap(TP, PAR, IntT<(UP4 ? (((TP / 3) == 1) * 2 + ((TP % 3) == 1)) : 0)>{});
         MIGAN_SCHED_FENCE();
         PROF_MARK(2);
         store_b(PAR ^ 1, IntT<PAR ^ 1>{});
@@ -400,34 +409,41 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, ((MTI * NT > 256) ? 1 : 2)) cm_conv_k
   const float ns = p.noise ? p.noise_strength[0] : 0.0f;
   constexpr int QN = NT / 4;
 #pragma unroll
-  for (int i = 0; i < MTI; ++i) {
-    if (i > 0) __syncthreads();            // the previous pass has been read (pass 0: the K loop ended with a barrier)
+  for (int ph = 0; ph < NPH; ++ph) {
+    // four-phase mode: phase (ey, ex) writes raw[2 g + e]; its grid extent is H + (ey == 0) by W + (ex == 0)
+    const int ey = ph >> 1, ex = ph & 1;
+    const int ghn = UP4 ? p.H + (ey == 0) : p.GHn, gwn = UP4 ? p.W + (ex == 0) : p.GWn;
+    const int oym = UP4 ? 2 : p.oy_mul, oya = UP4 ? ey : p.oy_add, oxm = UP4 ? 2 : p.ox_mul, oxa = UP4 ? ex : p.ox_add;
 #pragma unroll
-    for (int j = 0; j < NTI; ++j)
+    for (int i = 0; i < MTI; ++i) {
+      if (ph + i > 0) __syncthreads();       // the previous pass has been read (first pass: the K loop ended with a barrier)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int lrow = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        const int col = wn * WCOLS + j * 32 + l31;
-        g_s[lrow * GS + col] = acc[i][j][r];
+      for (int j = 0; j < NTI; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int lrow = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+          const int col = wn * WCOLS + j * 32 + l31;
+          g_s[lrow * GS + col] = acc[ph][i][j][r];
+        }
+      __syncthreads();
+      for (int item = tid; item < 64 * QN; item += 256) {
+        const int q4 = item % QN, lrow = item / QN;
+        const int m = cm_pixel_of_row((lrow >> 5) * WROWS + i * 32 + (lrow & 31));
+        const int gy = gy0 + (m >> 4), gx = gx0 + (m & 15);
+        if (gy >= ghn || gx >= gwn) continue;
+        const int oy = gy * oym + oya, ox = gx * oxm + oxa;
+        const int co = co0 + q4 * 4;
+        f4 cf = p.coef ? ld4(p.coef + (size_t)b * p.CO + co) : f4{p.cgain, p.cgain, p.cgain, p.cgain};
+        cf = cf * inv_wscale;
+        f4 v = ld4(g_s + lrow * GS + q4 * 4) * cf;
+        const size_t o = (((size_t)b * p.HO + oy) * p.WO + ox) * p.CO + co;
+        if (!p.raw) {
+          if (p.noise) v = v + MIGAN_FMUL_RN(p.noise[(size_t)b * p.noise_bstride + (size_t)oy * p.WO + ox], ns);
+          v = act4(v + ld4(p.bias + co));
+          if (p.skip) v = v + ld4once(p.skip + o);
+        }
+        st4o(p.y + o, v);
       }
-    __syncthreads();
-    for (int item = tid; item < 64 * QN; item += 256) {
-      const int q4 = item % QN, lrow = item / QN;
-      const int m = cm_pixel_of_row((lrow >> 5) * WROWS + i * 32 + (lrow & 31));
-      const int gy = gy0 + (m >> 4), gx = gx0 + (m & 15);
-      if (gy >= p.GHn || gx >= p.GWn) continue;
-      const int oy = gy * p.oy_mul + p.oy_add, ox = gx * p.ox_mul + p.ox_add;
-      const int co = co0 + q4 * 4;
-      f4 cf = p.coef ? ld4(p.coef + (size_t)b * p.CO + co) : f4{p.cgain, p.cgain, p.cgain, p.cgain};
-      cf = cf * inv_wscale;
-      f4 v = ld4(g_s + lrow * GS + q4 * 4) * cf;
-      const size_t o = (((size_t)b * p.HO + oy) * p.WO + ox) * p.CO + co;
-      if (!p.raw) {
-        if (p.noise) v = v + MIGAN_FMUL_RN(p.noise[(size_t)b * p.noise_bstride + (size_t)oy * p.WO + ox], ns);
-        v = act4(v + ld4(p.bias + co));
-        if (p.skip) v = v + ld4once(p.skip + o);
-      }
-      st4o(p.y + o, v);
     }
   }
   PROF_MARK(6);

@@ -90,6 +90,8 @@ def test_generator_matches_reference_golden(tag):
     assert np.abs(y - g["y"]).max() <= 1e-3, np.abs(y - g["y"]).max()
     kernels = {i["kernel"] for i in info}
     assert ("migan::cm_conv_kernel<128, 32, 6, true, 2>" if "c128" in tag else "migan::cm_conv_kernel<64, 32, 6, true, 2>") in kernels
+    # synthesis conv0: all four transposed-convolution phases in one launch with 128-column tiles, one launch per phase with 64
+    assert ("migan::cm_conv_kernel<128, 32, 6, true, 2, true>" if "c128" in tag else "migan::cm_conv_kernel<64, 32, 6, false, 2>") in kernels
 
 
 @pytest.mark.parametrize("mode", ["none", "random"])
@@ -151,6 +153,7 @@ def test_256_column_tiles(monkeypatch):
     """cm_conv_kernel<256, ..., 4> (16 x 16 pixels x 256 channels per workgroup, one wave per SIMD with 128 x 128 wave tiles) on a
     256-channel geometry, all three modes, vs the oracle."""
     monkeypatch.setenv("COMODGAN_MTI", "4")          # the host picks these tiles for large launches only
+    monkeypatch.setenv("COMODGAN_UP4", "0")          # one launch per transposed-convolution phase (generic tap-list kernels)
     cfg = cs.Config(resolution=16, ch_base=8192, ch_max=256, num_ws=cs.default_num_ws(16))
     sd = pkg.synth.make_comodgan_state_dict(cfg, 21)
     x, z = pkg.synth.make_input(1, 16, 21), pkg.synth.make_latent(1, 512, 21)
@@ -163,10 +166,13 @@ def test_256_column_tiles(monkeypatch):
 
 
 def test_small_tiles_forced(monkeypatch):
-    """COMODGAN_MTI=2 keeps every layer on the 8 x 16 pixel tiles (the pre-16x16 kernels stay tested)."""
+    """COMODGAN_MTI=2 keeps every layer on the 8 x 16 pixel tiles (the pre-16x16 kernels stay tested); COMODGAN_UP4=1 runs the
+    four-phase launch of the transposed convolution on 64-column tiles too."""
     monkeypatch.setenv("COMODGAN_MTI", "2")
-    g, cfg, sd, x, z = case("r32_c128")
+    monkeypatch.setenv("COMODGAN_UP4", "1")
+    g, cfg, sd, x, z = case("r64_c64")
     y, _, info = run_emu(cfg, sd, x[:1], z[:1])
     assert all(", 4>" not in i["kernel"] for i in info if "cm_conv" in i["kernel"])
+    assert "migan::cm_conv_kernel<64, 32, 6, true, 2, true>" in {i["kernel"] for i in info}
     want = orc.generator(x[:1], z[:1], sd, cfg.resolution, cfg.num_ws)
     assert np.abs(y - want).max() <= 1e-3
