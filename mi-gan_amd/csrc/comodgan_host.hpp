@@ -43,15 +43,13 @@ struct CmConvEntry { int NT, KC, nine, MTI; CmConvFn fn; const char* name; int u
 #define CM_CONV_ENTRY(NT, KC, NIA, NINE, MTI) {NT, KC, NINE, MTI, cm_conv_kernel<NT, KC, NIA, NINE, MTI>, "migan::cm_conv_kernel<" #NT ", " #KC ", " #NIA ", " #NINE ", " #MTI ">"}
 inline const std::vector<CmConvEntry>& cm_conv_table() {
   static const std::vector<CmConvEntry> t = {
-      // 8 x 16 pixel tiles (MTI 2): nine-tap unrolled K loop (plain: 10x18-pixel tile, 6 items; strided: 17x33 at 16 channels, 9 items)
-      CM_CONV_ENTRY(64, 32, 6, true, 2), CM_CONV_ENTRY(128, 32, 6, true, 2), CM_CONV_ENTRY(256, 32, 6, true, 2),
-      CM_CONV_ENTRY(64, 16, 9, true, 2), CM_CONV_ENTRY(128, 16, 9, true, 2), CM_CONV_ENTRY(256, 16, 9, true, 2),
-      // generic tap list (transposed-convolution phases)
-      CM_CONV_ENTRY(64, 32, 6, false, 2), CM_CONV_ENTRY(128, 32, 6, false, 2), CM_CONV_ENTRY(256, 32, 6, false, 2),
-      // 16 x 16 pixel tiles (MTI 4): plain 18x18 tile = 11 items; strided 33x33 at 16 channels = 18 items
-      CM_CONV_ENTRY(64, 32, 11, true, 4), CM_CONV_ENTRY(128, 32, 11, true, 4), CM_CONV_ENTRY(256, 32, 11, true, 4),
-      CM_CONV_ENTRY(64, 16, 18, true, 4), CM_CONV_ENTRY(128, 16, 18, true, 4), CM_CONV_ENTRY(256, 16, 18, true, 4),
-      CM_CONV_ENTRY(64, 32, 11, false, 4), CM_CONV_ENTRY(128, 32, 11, false, 4), CM_CONV_ENTRY(256, 32, 11, false, 4),
+      // 8 x 16 pixel tiles (MTI 2), 64 / 128 output channels: nine-tap unrolled K loop (plain: 10x18-pixel tile, 6 items per thread;
+      // strided: 17x33 pixels at 16 channels, 9 items) and the generic tap list (single transposed-convolution phases)
+      CM_CONV_ENTRY(64, 32, 6, true, 2), CM_CONV_ENTRY(128, 32, 6, true, 2),
+      CM_CONV_ENTRY(64, 16, 9, true, 2), CM_CONV_ENTRY(128, 16, 9, true, 2),
+      CM_CONV_ENTRY(64, 32, 6, false, 2), CM_CONV_ENTRY(128, 32, 6, false, 2),
+      // 16 x 16 pixel tiles (MTI 4) x 256 output channels: plain 18x18 tile = 11 items; strided 33x33 at 16 channels = 18 items
+      CM_CONV_ENTRY(256, 32, 11, true, 4), CM_CONV_ENTRY(256, 16, 18, true, 4), CM_CONV_ENTRY(256, 32, 11, false, 4),
       // all four transposed-convolution phases in one launch (nine taps, four accumulator sets)
       {64, 32, 1, 2, cm_conv_kernel<64, 32, 6, true, 2, true>, "migan::cm_conv_kernel<64, 32, 6, true, 2, true>", 1},
       {128, 32, 1, 2, cm_conv_kernel<128, 32, 6, true, 2, true>, "migan::cm_conv_kernel<128, 32, 6, true, 2, true>", 1},
@@ -293,7 +291,8 @@ inline size_t comodgan_handle::walk(int batch, const float* x, const float* z, f
     // and with 128- or 64-column tiles)
     const size_t wgs16 = (size_t)cdiv(ghn, 16) * cdiv(gwn, 16) * B * (cw.co / 256);
     int MTI = (cw.co % 256 == 0 && std::min(ghn, gwn) >= 16 && wgs16 >= 512) ? 4 : 2;
-    if (mti_env && (std::atoi(mti_env) == 2 || std::atoi(mti_env) == 4)) MTI = std::atoi(mti_env);
+    if (mti_env && std::atoi(mti_env) == 2) MTI = 2;
+    if (mti_env && std::atoi(mti_env) == 4 && cw.co % 256 == 0) MTI = 4;     // the 16 x 16 tiles exist with 256 columns only
     if (mode == CM_CONV_UP4) MTI = 2;
     const int GH = 4 * MTI;
     if (mode == CM_CONV_NORMAL) {
@@ -327,9 +326,7 @@ inline size_t comodgan_handle::walk(int batch, const float* x, const float* z, f
       a.GHn = H + (ey == 0); a.GWn = Wd + (ex == 0);
       a.oy_mul = 2; a.ox_mul = 2; a.oy_add = ey; a.ox_add = ex;
     }
-    const char* nt256_env = std::getenv("COMODGAN_NT256");                 // experiments / tests: 0 disables the 256-column tiles
-    const bool nt256 = nt256_env ? std::atoi(nt256_env) != 0 : true;
-    const int NT = (cw.co % 256 == 0 && nt256 && MTI == 4 && mode != CM_CONV_UP4) ? 256 : ((cw.co % 128 == 0) ? 128 : 64);
+    const int NT = (MTI == 4) ? 256 : ((cw.co % 128 == 0) ? 128 : 64);
     const int KC = mode == CM_CONV_DOWN ? 16 : 32;          // the (2GH+1)x33-pixel tile of the strided mode is staged 16 channels at a time
     a.tiles_y = cdiv(a.GHn, GH); a.tiles_x = cdiv(a.GWn, 16); a.nchunks = cw.co / NT;
     const size_t pitch = (size_t)4 * KC + 16;                // LDS row: both fp16 planes of KC channels + 16 bytes of padding
@@ -511,7 +508,7 @@ inline size_t comodgan_handle::walk(int batch, const float* x, const float* z, f
     int flip = 1;
     for (int res = 8; res <= R; res *= 2) {
       const std::string b = bname("synthesis", res);
-      const int ci = channels(res / 2), co = channels(res), h = res / 2;
+      const int co = channels(res), h = res / 2;
       // conv0: modulated transposed convolution (4 output phases) -> FIR + noise + bias + activation, + skip (comodgan.py:329-331)
       const ConvW& c0w = conv_of(b + ".conv0");
       const Mod m0s = style_demod(b + ".conv0", c0w);
@@ -535,7 +532,6 @@ inline size_t comodgan_handle::walk(int batch, const float* x, const float* z, f
         emit(b + ".conv0.fir", "migan::cm_fir_kernel<1>", 2.0 * 16 * co * res * res, 0, 4.0 * co * ((res + 1.0) * (res + 1.0) + 2.0 * res * res),
              cm_fir_kernel<1>, a, grid1d((size_t)B * (res / 2) * cdiv(res, 4) * (co / 4)), 0);
       }
-      (void)ci;
       // conv1
       const ConvW& c1w = conv_of(b + ".conv1");
       const Mod m1s = style_demod(b + ".conv1", c1w);

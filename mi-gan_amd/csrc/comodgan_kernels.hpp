@@ -59,7 +59,7 @@ struct CmConvArgs {
   int GHn, GWn;                 // grid extent; grid pixels beyond are not stored
   int tiles_x, tiles_y, nchunks;
   int raw;                      // 1: store acc * coef only (transposed-convolution phases; cm_upfir_kernel finishes the layer)
-  int off_b, off_g;             // LDS carve in bytes: B tile buffers; the result tile aliases everything
+  int off_b;                    // LDS carve in bytes: start of the B tile buffers (the result tile aliases everything)
   unsigned long long* prof;     // phase-cycle accumulators (MIGAN_PHASE_PROF builds only), else null
 };
 
@@ -130,7 +130,7 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, ((MTI * NT * (UP4 ? 4 : 1) > 256) ? 1
   const float* __restrict__ xb = p.x + (size_t)b * p.H * p.W * p.CI;
   const float* __restrict__ sab = p.sa ? p.sa + (size_t)b * p.CI : nullptr;
   const unsigned w_plane_bytes = (unsigned)(9 * p.CI * p.CO) * 2u;     // bytes of one weight plane (< 2^23)
-  const int total = nck * p.ntaps;
+  [[maybe_unused]] const int total = nck * p.ntaps;            // generic tap list only
 
   constexpr int NPH = UP4 ? 4 : 1;                            // accumulator sets (output phases)
   static_assert(!UP4 || NINE, "the four-phase mode runs the nine-tap K loop");
@@ -228,35 +228,6 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, ((MTI * NT * (UP4 ? 4 : 1) > 256) ? 1
     for (int i = 0; i < MTI; ++i) aa[i] = a_s + (a_off[i] + delta);
 #pragma unroll
     for (int j = 0; j < NTI; ++j) bb[j] = b_s + (b_off[j] + buf * b_buf);
-    if constexpr (MTI * NT > 256 && MTI * NTI <= 8) {
-      // one wave per SIMD: nobody else hides the LDS latency, so all operand reads of the tap (both 16-k steps) are issued
-      // up front; the MFMAs of the first step start as soon as its fragments have landed while the second step's stream in
-      constexpr int NKS = KC / 16;
-      f4 av[NKS][MTI][2], bv[NKS][NTI][2];
-#pragma unroll
-      for (int ks = 0; ks < NKS; ++ks) {
-#pragma unroll
-        for (int i = 0; i < MTI; ++i) {
-          av[ks][i][0] = ld4(reinterpret_cast<const float*>(aa[i] + ks * 32));
-          av[ks][i][1] = ld4(reinterpret_cast<const float*>(aa[i] + ks * 32 + RB));
-        }
-#pragma unroll
-        for (int j = 0; j < NTI; ++j) {
-          bv[ks][j][0] = ld4(reinterpret_cast<const float*>(bb[j] + ks * 32));
-          bv[ks][j][1] = ld4(reinterpret_cast<const float*>(bb[j] + ks * 32 + RB));
-        }
-      }
-      MIGAN_SCHED_FENCE();
-#pragma unroll
-      for (int ks = 0; ks < NKS; ++ks)
-#pragma unroll
-        for (int pr = 0; pr < 3; ++pr)
-#pragma unroll
-          for (int i = 0; i < MTI; ++i)
-#pragma unroll
-            for (int j = 0; j < NTI; ++j)
-              acc[PH][i][j] = MIGAN_MFMA_F16_32X32X16(av[ks][i][pr == 0 ? 1 : 0], bv[ks][j][pr == 1 ? 1 : 0], acc[PH][i][j]);
-    } else {
 #pragma unroll
     for (int ks = 0; ks < KC / 16; ++ks) {
       f4 av[MTI][2], bv[NTI][2];
@@ -279,7 +250,6 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, ((MTI * NT * (UP4 ? 4 : 1) > 256) ? 1
 #pragma unroll
           for (int j = 0; j < NTI; ++j)
             acc[PH][i][j] = MIGAN_MFMA_F16_32X32X16(av[i][pr == 0 ? 1 : 0], bv[j][pr == 1 ? 1 : 0], acc[PH][i][j]);
-    }
     }
   };
 
