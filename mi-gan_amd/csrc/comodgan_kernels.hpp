@@ -18,7 +18,10 @@
 //                       Epilogue: per-(sample, channel) demodulation coefficient, noise, bias, lrelu*sqrt2, clamp, skip.
 //                       The tap list is data: plain 3x3 (9 taps, stride 1), stride-2 on the FIR-filtered input
 //                       (encoder down path), and the four output phases of the stride-2 transposed convolution
-//                       (synthesis up path: 4 + 2 + 2 + 1 taps, no multiplications by inserted zeros).
+//                       (synthesis up path: 4 + 2 + 2 + 1 taps, no multiplications by inserted zeros) -- one launch per
+//                       phase, or all four in one launch with one accumulator set per phase.
+//                       Tiles: 8x16 pixels x 64/128 channels (two waves per SIMD) or 16x16 pixels x 256 channels (one
+//                       wave per SIMD, 128x128 wave tiles, accumulators in AGPRs), chosen per launch by the host.
 //   cm_fir_kernel<0>    upfirdn2d [1,3,3,1] FIR with pad 2 in front of the strided convolution (conv2d_resample down path)
 //   cm_fir_kernel<1>    upfirdn2d FIR (gain 4) behind the transposed convolution + noise/bias/activation/skip epilogue
 //   cm_fromrgb_kernel   1x1 conv 4 -> C with bias and activation, NCHW planes -> NHWC
@@ -58,7 +61,7 @@ struct CmConvArgs {
   int oy_mul, oy_add, ox_mul, ox_add;   // output pixel of grid pixel (gy, gx)
   int GHn, GWn;                 // grid extent; grid pixels beyond are not stored
   int tiles_x, tiles_y, nchunks;
-  int raw;                      // 1: store acc * coef only (transposed-convolution phases; cm_upfir_kernel finishes the layer)
+  int raw;                      // 1: store acc * coef only (transposed-convolution phases; cm_fir_kernel<1> finishes the layer)
   int off_b;                    // LDS carve in bytes: start of the B tile buffers (the result tile aliases everything)
   unsigned long long* prof;     // phase-cycle accumulators (MIGAN_PHASE_PROF builds only), else null
 };
@@ -721,9 +724,9 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, 2) cm_fromrgb_kernel(const CmFromRgbA
 // every side, NHWC: out[y][x] = sum_{a,b} f[a] f[b] in[y + a - pad][x + b - pad].  Each thread produces a 2 x 4 block of
 // output pixels for one channel quad from a 5 x 7 input window (4.4 loads per output instead of 16), one input row at
 // a time: horizontal taps into 4 row sums, which feed the two output rows.
-//   EPI = 0 (cm_blur): FIR in front of the strided convolution (conv2d_resample.py down path: pad = 2, gain 1, fs = 1/8),
+//   EPI = 0: FIR in front of the strided convolution (conv2d_resample.py down path: pad = 2, gain 1, fs = 1/8),
 //                      [B][H][W][C] -> [B][H+1][W+1][C]
-//   EPI = 1 (cm_upfir): second half of an up=2 synthesis_layer: FIR (gain 4: fs = 1/4, pad 1) over the (2H+1)^2 output
+//   EPI = 1: second half of an up=2 synthesis_layer: FIR (gain 4: fs = 1/4, pad 1) over the (2H+1)^2 output
 //                      of the transposed convolution (conv2d_resample.py up path), then noise, bias, activation, skip
 //                      (stylegan.py:300-309, comodgan.py:331-332); the demodulation coefficient is already applied
 //                      (cm_conv_kernel raw mode)
