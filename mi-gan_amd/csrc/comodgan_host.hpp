@@ -82,6 +82,7 @@ struct comodgan_handle {
   std::vector<migan::CmDebugTensor> debug_tensors;
   std::vector<rt::event_t> events;
   int planned_batch = 0;
+  size_t planned_need = 0;       // workspace bytes of planned_batch (0 = not planned)
 
   int channels(int res) const { return std::min(cfg.ch_base / res, cfg.ch_max); }
   int slot_index(const std::string& n) const {
@@ -578,7 +579,7 @@ int comodgan_create(const comodgan_config* cfg, int device, comodgan_handle** ou
   h->device = device;
   h->build_schema();
   h->planned_batch = 1;
-  h->walk(1, nullptr, nullptr, nullptr, 1.0f, COMODGAN_NOISE_CONST, nullptr, nullptr, nullptr, true, nullptr, 0);
+  h->planned_need = h->walk(1, nullptr, nullptr, nullptr, 1.0f, COMODGAN_NOISE_CONST, nullptr, nullptr, nullptr, true, nullptr, 0);
   *out = h;
   MIGAN_API_END
 }
@@ -652,8 +653,11 @@ int comodgan_workspace_bytes(const comodgan_handle* h, int batch, size_t* bytes)
   MIGAN_API_BEGIN
   MIGAN_CHECK(h && bytes && batch > 0, MIGAN_EINVAL, "bad argument");
   comodgan_handle* m = const_cast<comodgan_handle*>(h);
-  m->planned_batch = batch;
-  *bytes = m->walk(batch, nullptr, nullptr, nullptr, 1.0f, COMODGAN_NOISE_CONST, nullptr, nullptr, nullptr, true, nullptr, 0);
+  if (m->planned_batch != batch || m->planned_need == 0) {
+    m->planned_need = m->walk(batch, nullptr, nullptr, nullptr, 1.0f, COMODGAN_NOISE_CONST, nullptr, nullptr, nullptr, true, nullptr, 0);
+    m->planned_batch = batch;
+  }
+  *bytes = m->planned_need;
   MIGAN_API_END
 }
 
@@ -676,8 +680,12 @@ static int comodgan_forward_impl(comodgan_handle* h, const void* x, const void* 
   MIGAN_CHECK(noise_mode != COMODGAN_NOISE_RANDOM || noise != nullptr, MIGAN_EINVAL, "noise_mode random needs the noise tensor");
   MIGAN_CHECK(ws != nullptr && ((uintptr_t)ws % 256) == 0, MIGAN_EINVAL, "null or misaligned workspace (256 bytes)");
   MIGAN_CHECK(((uintptr_t)x % 16) == 0 && ((uintptr_t)y % 16) == 0 && ((uintptr_t)z % 4) == 0, MIGAN_EINVAL, "misaligned tensor");
-  const size_t need = h->walk(batch, nullptr, nullptr, nullptr, psi, noise_mode, nullptr, ws, nullptr, true, nullptr, 0);
-  h->planned_batch = batch;
+  // the launch list and the workspace size depend on the batch (and the debug flag) only: planned once per batch size
+  if (h->planned_batch != batch || h->planned_need == 0) {
+    h->planned_need = h->walk(batch, nullptr, nullptr, nullptr, psi, noise_mode, nullptr, nullptr, nullptr, true, nullptr, 0);
+    h->planned_batch = batch;
+  }
+  const size_t need = h->planned_need;
   MIGAN_CHECK(ws_bytes >= need, MIGAN_EINVAL, "workspace too small for this batch");
   if (ms) {
     MIGAN_CHECK(n_ms >= (int)h->infos.size(), MIGAN_EINVAL, "launch_ms array too small");
@@ -731,8 +739,8 @@ int comodgan_set_debug(comodgan_handle* h, int keep) {
   MIGAN_API_BEGIN
   MIGAN_CHECK(h, MIGAN_EINVAL, "null handle");
   h->debug = keep != 0;
-  h->walk(h->planned_batch > 0 ? h->planned_batch : 1, nullptr, nullptr, nullptr, 1.0f, COMODGAN_NOISE_CONST, nullptr, nullptr, nullptr, true,
-          nullptr, 0);
+  if (h->planned_batch <= 0) h->planned_batch = 1;
+  h->planned_need = h->walk(h->planned_batch, nullptr, nullptr, nullptr, 1.0f, COMODGAN_NOISE_CONST, nullptr, nullptr, nullptr, true, nullptr, 0);
   MIGAN_API_END
 }
 
@@ -741,9 +749,9 @@ int comodgan_debug_tensor(const comodgan_handle* h, int batch, const char* layer
   MIGAN_CHECK(h && layer && byte_offset && shape && ndim, MIGAN_EINVAL, "null argument");
   MIGAN_CHECK(h->debug, MIGAN_ESTATE, "comodgan_set_debug(h, 1) first");
   comodgan_handle* m = const_cast<comodgan_handle*>(h);
-  if (m->planned_batch != batch) {
+  if (m->planned_batch != batch || m->planned_need == 0) {
     m->planned_batch = batch;
-    m->walk(batch, nullptr, nullptr, nullptr, 1.0f, COMODGAN_NOISE_CONST, nullptr, nullptr, nullptr, true, nullptr, 0);
+    m->planned_need = m->walk(batch, nullptr, nullptr, nullptr, 1.0f, COMODGAN_NOISE_CONST, nullptr, nullptr, nullptr, true, nullptr, 0);
   }
   for (const auto& t : h->debug_tensors) {
     if (t.name != layer) continue;
