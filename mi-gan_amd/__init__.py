@@ -14,4 +14,18 @@ from . import comodgan, comodgan_schema, convert, distributed, hipbind, pipeline
 from .migan_inference import Generator  # noqa: F401
 from .hipbind import MiganLib, MiganError, load_library, library_path  # noqa: F401
 
-__all__ = ["Generator", "MiganLib", "MiganError", "load_library", "library_path", "schema", "synth", "pipeline", "convert", "comodgan"]
+
+
+def install_into_reference(migan: bool = True, comodgan_too: bool = True) -> None:
+    """Make the reference's own scripts pick up the MI355X modules without editing them: registers this package's modules as
+    ``lib.model_zoo.migan_inference`` / ``lib.model_zoo.comodgan`` in ``sys.modules`` (call it before the script's imports, with
+    the reference repository on ``sys.path``; scripts/demo.py:15-21 then imports these classes).  See INTEGRATION.md section 3."""
+    import sys
+    from . import comodgan as _cm, migan_inference as _mi
+    if migan:
+        sys.modules["lib.model_zoo.migan_inference"] = _mi
+    if comodgan_too:
+        sys.modules["lib.model_zoo.comodgan"] = _cm
+
+
+__all__ = ["install_into_reference", "Generator", "MiganLib", "MiganError", "load_library", "library_path", "schema", "synth", "pipeline", "convert", "comodgan"]

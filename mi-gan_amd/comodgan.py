@@ -20,6 +20,10 @@ from . import comodgan_schema as cs
 from .hipbind import CoModGANHandle, MiganLib, load_library
 
 
+version = '3'          # reference comodgan.py:10-11 (lib/model_zoo/__init__.py imports `version` from this module)
+symbol = 'comodgan'
+
+
 class _Node(nn.Module):
     def __init__(self, kind: str = "Module"):
         super().__init__()

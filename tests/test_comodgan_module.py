@@ -52,3 +52,27 @@ def test_constructor_errors_follow_the_reference():
     with pytest.raises(ValueError):
         cm.Generator(cm.Mapping(num_ws=14), cm.Encoder(resolution=16, ch_base=1024, ch_max=64),
                      cm.Synthesis(resolution=16, ch_base=1024, ch_max=64))    # num_ws mismatch, stylegan.py:606-607
+
+
+def test_install_into_reference_resolves_the_imports_of_demo_py(tmp_path, monkeypatch):
+    """scripts/demo.py:15-21 imports the generator classes from lib.model_zoo.*; with install_into_reference() and a package
+    tree shaped like the reference's (whose lib/model_zoo/__init__.py itself does `from .comodgan import version`) they resolve
+    to the MI355X modules."""
+    import sys
+    root = tmp_path / "fake_reference"
+    (root / "lib" / "model_zoo").mkdir(parents=True)
+    (root / "lib" / "__init__.py").write_text("")
+    (root / "lib" / "model_zoo" / "__init__.py").write_text("from .comodgan import version\n")
+    monkeypatch.syspath_prepend(str(root))
+    for k in [k for k in sys.modules if k == "lib" or k.startswith("lib.")]:
+        monkeypatch.delitem(sys.modules, k)
+    pkg.install_into_reference()
+    try:
+        from lib.model_zoo.migan_inference import Generator as MIGAN
+        from lib.model_zoo.comodgan import Generator as G, Mapping as M, Encoder as E, Synthesis as S
+        assert MIGAN is pkg.Generator and G is cm.Generator and (M, E, S) == (cm.Mapping, cm.Encoder, cm.Synthesis)
+        import lib.model_zoo
+        assert lib.model_zoo.version == "3"
+    finally:
+        for k in [k for k in sys.modules if k == "lib" or k.startswith("lib.")]:
+            sys.modules.pop(k, None)
