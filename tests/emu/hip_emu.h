@@ -127,7 +127,7 @@ inline float __shfl_xor(float v, int mask);
 #define MIGAN_CLAMP(v, lo, hi) fminf(fmaxf((v), (lo)), (hi))
 #define MIGAN_SWIZZLE_XOR(v, m) __shfl_xor((v), (m))
 #define MIGAN_SCHED_FENCE() do {} while (0)
-#define MIGAN_SCHED_GROUP(mask, n) do {} while (0)
+#define MIGAN_SCHED_GROUP(mask, n) do { (void)(mask); (void)(n); } while (0)
 #define MIGAN_STORE_NT(ptr, v) (*(ptr) = (v))
 #define MIGAN_LOAD_NT(ptr) (*(ptr))
 #define MIGAN_OPAQUE(x) asm volatile("" : "+r"(x))
