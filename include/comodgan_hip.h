@@ -49,6 +49,13 @@ int comodgan_commit(comodgan_handle* h, void* stream);
 
 int comodgan_workspace_bytes(const comodgan_handle* h, int batch, size_t* bytes);
 
+/* Every forward starts by writing the fp16 operand planes and the demodulation statistics of the 3x3 weights into the head of the
+ * workspace (weights are read in place, so in-place parameter updates are always seen).  on != 0: the caller asserts that the
+ * weight VALUES have not changed since the previous comodgan_forward and that the workspace passed then is passed again with its
+ * contents intact; the preparation launches are then skipped (they are batch-size independent and sit at fixed workspace offsets).
+ * comodgan_set_weight / comodgan_commit, another workspace pointer or on == 0 bring them back for the next forward.  Default 0. */
+int comodgan_assume_static_weights(comodgan_handle* h, int on);
+
 #define COMODGAN_NOISE_NONE 0    /* noise_mode='none'  (stylegan.py:283-289) */
 #define COMODGAN_NOISE_CONST 1   /* noise_mode='const': noise_const * noise_strength */
 #define COMODGAN_NOISE_RANDOM 2  /* noise_mode='random': `noise` holds, for every synthesis layer in forward order

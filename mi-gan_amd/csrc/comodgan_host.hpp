@@ -83,6 +83,10 @@ struct comodgan_handle {
   std::vector<rt::event_t> events;
   int planned_batch = 0;
   size_t planned_need = 0;       // workspace bytes of planned_batch (0 = not planned)
+  // comodgan_assume_static_weights: skip the per-forward weight preparation while nothing it depends on has changed
+  bool static_weights = false;
+  const void* prepared_ws = nullptr;
+  unsigned long long weights_epoch = 1, prepared_epoch = 0;
 
   int channels(int res) const { return std::min(cfg.ch_base / res, cfg.ch_max); }
   int slot_index(const std::string& n) const {
@@ -202,6 +206,7 @@ inline size_t comodgan_handle::walk(int batch, const float* x, const float* z, f
     for (auto v : shp) t.shape[i++] = v;
     debug_tensors.push_back(t);
   };
+  bool skip_launch = false;      // set around the weight-preparation launches when their results in the workspace are still valid
   auto emit = [&](const std::string& layer, const char* kname, double flops, double mfma, double bytes, auto kernel, const auto& args,
                   unsigned grid, size_t lds) {
     if (dry) {
@@ -210,7 +215,7 @@ inline size_t comodgan_handle::walk(int batch, const float* x, const float* z, f
       infos.push_back(inf);
     } else {
       if (timed) rt_check(rt::event_record(events[2 * nlaunch], stream), "hipEventRecord");
-      rt_check(rt::launch(kernel, args, grid, kThreads, lds, stream), kname);
+      if (!skip_launch) rt_check(rt::launch(kernel, args, grid, kThreads, lds, stream), kname);
       if (timed) rt_check(rt::event_record(events[2 * nlaunch + 1], stream), "hipEventRecord");
 #ifdef MIGAN_PHASE_PROF
       if (timed) {
@@ -252,6 +257,7 @@ inline size_t comodgan_handle::walk(int batch, const float* x, const float* z, f
       if (c.name == name) return c;
     throw Error(MIGAN_EINVAL, "internal: no conv " + name);
   };
+  skip_launch = !dry && static_weights && prepared_ws == ws && prepared_epoch == weights_epoch;
   for (const auto& c : convs) {
     CmWprepArgs q{};
     q.w = dry ? nullptr : W(c.name + ".weight"); q.amax = c.amax; q.wsq = c.wsq; q.wn2 = c.wn2; q.CO = c.co; q.CI = c.ci;
@@ -261,6 +267,11 @@ inline size_t comodgan_handle::walk(int batch, const float* x, const float* z, f
     a.src = q.w; a.amax = c.amax; a.dst = c.planes; a.CO = c.co; a.CI = c.ci;
     emit(c.name + ".split", "migan::cm_split_conv_kernel", 0, 0, 8.0 * c.co * c.ci * 9 / B, cm_split_conv_kernel, a,
          grid1d((size_t)c.co * c.ci), 4 * sizeof(float));
+  }
+  skip_launch = false;
+  if (!dry) {
+    prepared_ws = ws;
+    prepared_epoch = weights_epoch;
   }
 
   // ---------------------------------------------------------------- helpers for the layers
@@ -624,6 +635,7 @@ int comodgan_set_weight(comodgan_handle* h, const char* name, const void* dev_pt
   MIGAN_CHECK(((uintptr_t)dev_ptr % 4) == 0, MIGAN_EINVAL, std::string("misaligned tensor ") + name);
   s.ptr = static_cast<const float*>(dev_ptr);
   h->committed = false;
+  ++h->weights_epoch;
   MIGAN_API_END
 }
 
@@ -646,6 +658,15 @@ int comodgan_commit(comodgan_handle* h, void* stream) {
                     s.name + " differs from setup_filter([1,3,3,1]); only the reference FIR is implemented");
   }
   h->committed = true;
+  ++h->weights_epoch;
+  MIGAN_API_END
+}
+
+int comodgan_assume_static_weights(comodgan_handle* h, int on) {
+  MIGAN_API_BEGIN
+  MIGAN_CHECK(h, MIGAN_EINVAL, "null handle");
+  h->static_weights = on != 0;
+  if (!on) h->prepared_ws = nullptr;
   MIGAN_API_END
 }
 

@@ -45,7 +45,8 @@ EXPORTS = (
     "migan_last_error", "migan_backend", "migan_gemm_variant", "migan_version",
     # include/comodgan_hip.h
     "comodgan_create", "comodgan_destroy", "comodgan_num_weights", "comodgan_weight_info", "comodgan_set_weight",
-    "comodgan_commit", "comodgan_workspace_bytes", "comodgan_noise_floats", "comodgan_forward", "comodgan_num_launches",
+    "comodgan_commit", "comodgan_workspace_bytes", "comodgan_assume_static_weights", "comodgan_noise_floats", "comodgan_forward",
+    "comodgan_num_launches",
     "comodgan_launch_info", "comodgan_forward_timed", "comodgan_set_debug", "comodgan_debug_tensor",
 )
 
@@ -103,6 +104,7 @@ class MiganLib:
         L.comodgan_commit.argtypes = [vp, vp]
         L.comodgan_workspace_bytes.argtypes = [vp, ci, C.POINTER(C.c_size_t)]
         L.comodgan_noise_floats.argtypes = [vp, C.POINTER(C.c_size_t)]
+        L.comodgan_assume_static_weights.argtypes = [vp, ci]
         L.comodgan_forward.argtypes = [vp, vp, vp, vp, ci, C.c_float, ci, vp, vp, C.c_size_t, vp]
         L.comodgan_forward_timed.argtypes = [vp, vp, vp, vp, ci, C.c_float, ci, vp, vp, C.c_size_t, vp, fp, ci]
         L.comodgan_num_launches.argtypes = [vp, C.POINTER(ci)]
@@ -285,6 +287,9 @@ class CoModGANHandle:
         n = C.c_size_t()
         self.lib.check(self.lib.lib.comodgan_noise_floats(self._h, C.byref(n)))
         return int(n.value)
+
+    def assume_static_weights(self, on: bool) -> None:
+        self.lib.check(self.lib.lib.comodgan_assume_static_weights(self._h, 1 if on else 0))
 
     def forward(self, x_ptr: int, z_ptr: int, y_ptr: int, batch: int, ws_ptr: int, ws_bytes: int, truncation_psi: float = 1.0,
                 noise_mode: str = "const", noise_ptr: Optional[int] = None, stream: int = 0, timed: bool = False):

@@ -76,3 +76,19 @@ def test_install_into_reference_resolves_the_imports_of_demo_py(tmp_path, monkey
     finally:
         for k in [k for k in sys.modules if k == "lib" or k.startswith("lib.")]:
             sys.modules.pop(k, None)
+
+
+def test_parameter_version_counters_track_in_place_updates():
+    """Generator.forward tells the library that the prepared weight planes are still valid only while no parameter's version
+    counter has moved: in-place updates (optimizer steps, load_state_dict, .mul_()) must all move it."""
+    g = build(16, ch_base=1024, ch_max=64)
+    vers = lambda: tuple(t._version for t in g._tensors())
+    v0 = vers()
+    assert vers() == v0
+    with torch.no_grad():
+        g.encoder.b16.conv0.weight.mul_(2.0)
+    v1 = vers()
+    assert v1 != v0
+    g.load_state_dict(g.state_dict())
+    assert vers() != v1
+    assert g._prep_state is None

@@ -176,3 +176,46 @@ def test_small_tiles_forced(monkeypatch):
     assert "migan::cm_conv_kernel<64, 32, 6, true, 2, true>" in {i["kernel"] for i in info}
     want = orc.generator(x[:1], z[:1], sd, cfg.resolution, cfg.num_ws)
     assert np.abs(y - want).max() <= 1e-3
+
+
+def test_assume_static_weights_skips_the_weight_preparation():
+    """comodgan_assume_static_weights: with the assertion on, a second forward on the same workspace reuses the prepared weight
+    planes (an in-place change of a 3x3 weight is then NOT seen -- that is the contract); off, or after re-binding, it is."""
+    lib = emu_lib()
+    _, cfg, sd, x, z = case("r16_c64")
+    h = hb.CoModGANHandle(lib, 16, cfg.num_ws, cfg.ch_base, cfg.ch_max)
+    keep = {k: aligned(v) for k, v in sd.items()}
+    for name, shape, _ in h.weights():
+        h.set_weight(name, keep[name].ctypes.data, shape)
+    h.commit()
+    n = 1
+    nbytes = h.workspace_bytes(n)
+    ws = np.zeros(nbytes // 4 + 64, dtype=np.float32)
+    wsv = ws[(256 - ws.ctypes.data % 256) % 256 // 4:]
+    xa, za = aligned(x[:n]), aligned(z[:n])
+
+    def fwd():
+        y = aligned(np.zeros((n, 3, 16, 16), np.float32))
+        h.forward(xa.ctypes.data, za.ctypes.data, y.ctypes.data, n, wsv.ctypes.data, nbytes)
+        return y.copy()
+
+    h.assume_static_weights(True)
+    y1 = fwd()                                         # nothing prepared yet: the preparation runs
+    w = keep["encoder.b16.conv0.weight"]
+    w *= 1.5                                           # in place, same address
+    y2 = fwd()
+    assert np.array_equal(y2, y1)                      # stale planes, as the caller asserted
+    h.assume_static_weights(False)
+    y3 = fwd()
+    sd2 = dict(sd)
+    sd2["encoder.b16.conv0.weight"] = np.asarray(w)
+    want = orc.generator(x[:n], z[:n], sd2, 16, cfg.num_ws)
+    assert np.abs(y3 - want).max() <= 1e-3 and np.abs(y3 - y1).max() > 1e-3
+    h.assume_static_weights(True)
+    assert np.array_equal(fwd(), y3)                   # prepared by the previous forward, reused
+    w /= 1.5
+    h.set_weight("encoder.b16.conv0.weight", w.ctypes.data, w.shape)     # re-binding invalidates the preparation
+    h.commit()
+    y5 = fwd()
+    assert np.abs(y5 - y1).max() <= 2e-5 * max(1.0, np.abs(y1).max())
+    h.close()

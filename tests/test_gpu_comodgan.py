@@ -116,3 +116,24 @@ def test_module_errors_on_gpu(pkg, dev):
         m(torch.zeros(1, 4, 16, 16, device=dev), z=torch.zeros(2, 512, device=dev))
     with pytest.raises(NotImplementedError):
         m(torch.zeros(1, 4, 16, 16, device=dev), truncation_cutoff=4)
+
+
+def test_in_place_weight_updates_are_seen_and_static_weights_are_reused(pkg, dev):
+    """The module skips the per-forward weight preparation only while no parameter version counter has moved
+    (comodgan_assume_static_weights): an in-place update must show up in the next forward, repeated forwards stay bit-identical."""
+    cfg = _cfg(pkg, 32, 4096, 128)
+    m, sd = _build(pkg, cfg, 8, dev)
+    x, z = pkg.synth.make_input(2, 32, 9), pkg.synth.make_latent(2, 512, 9)
+    xt, zt = torch.from_numpy(x).to(dev), torch.from_numpy(z).to(dev)
+    with torch.no_grad():
+        y1 = m(xt, z=zt, noise_mode="const").cpu().numpy()
+        y1b = m(xt, z=zt, noise_mode="const").cpu().numpy()          # prepared planes reused
+        m.encoder.b32.conv0.weight.mul_(1.5)                          # in place, same storage
+        y2 = m(xt, z=zt, noise_mode="const").cpu().numpy()
+        y2b = m(xt, z=zt, noise_mode="const").cpu().numpy()
+    assert np.array_equal(y1, y1b) and np.array_equal(y2, y2b)
+    sd2 = dict(sd)
+    sd2["encoder.b32.conv0.weight"] = sd["encoder.b32.conv0.weight"] * np.float32(1.5)
+    assert float(np.abs(y1 - orc.generator(x, z, sd, 32, cfg.num_ws)).max()) <= TOL
+    assert float(np.abs(y2 - orc.generator(x, z, sd2, 32, cfg.num_ws)).max()) <= TOL
+    assert float(np.abs(y2 - y1).max()) > 1e-2
