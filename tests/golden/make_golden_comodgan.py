@@ -44,6 +44,7 @@ CASES = [
     ("r64_c64", 64, 4096, 64, 2, 4, 1.0),
     ("r64_std", 64, 32768, 512, 1, 5, 1.0),       # the real channel rule (512 everywhere at <= 64)
     ("r256_small", 256, 16384, 256, 1, 6, 1.0),   # the 64..256-channel range at the big resolutions
+    ("r512_std", 512, 32768, 512, 1, 7, 1.0),     # comodgan-512 as scripts/demo.py:101-106 builds it (BASELINE configs[4] geometry)
 ]
 
 
