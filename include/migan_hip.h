@@ -9,7 +9,8 @@
  * Conventions
  *   - every function returns 0 on success, a MIGAN_E* code otherwise; the message for the last
  *     failure on the calling thread is migan_last_error().  Nothing throws across the boundary.
- *   - all tensors are fp32 device pointers owned by the caller.  Weights are passed in the
+ *   - all tensors are device pointers owned by the caller; parameters, the network input and the network output are
+ *     fp32 (the reference's dtype).  Weights are passed in the
  *     reference's own state_dict layouts (conv weights [Co][Ci][kh][kw], etc.) and are read in
  *     place: they must stay valid and unmodified-in-address until the next migan_set_weight /
  *     migan_destroy.  The library allocates no device memory.
@@ -35,14 +36,44 @@ extern "C" {
 #define MIGAN_ERUNTIME 3    /* HIP runtime error (launch failure, copy failure) */
 #define MIGAN_EUNSUPPORTED 4 /* checkpoint uses FIR taps other than setup_filter([1,3,3,1]) */
 
+/* Storage format of the activation tensors BETWEEN layers (feature maps and skip tensors, NHWC inside the library).
+ * Parameters, network input/output, the running RGB image and all arithmetic (depthwise, activation, FIR, 1x1 accumulate,
+ * epilogue) are fp32 in every mode; the 16-bit modes round each SeparableConv2d output (after the skip add, where there is
+ * one) once, to nearest even, when it is written -- BASELINE configs[1] ("bf16").  MIGAN_DTYPE_F32 is the reference's
+ * own precision (configs[2], the <= 1e-3 parity configuration). */
 #define MIGAN_DTYPE_F32 0
+#define MIGAN_DTYPE_BF16 1
+#define MIGAN_DTYPE_F16 2
+
+/* How the 1x1 convolutions are multiplied (see migan_gemm_variant below). */
+#define MIGAN_GEMM_DEFAULT (-1)
+#define MIGAN_GEMM_F32 0
+#define MIGAN_GEMM_BF16X3 1
+#define MIGAN_GEMM_F16X2 2
 
 typedef struct migan_handle migan_handle;
 
 /* Generator(resolution) -- reference :356-360.  resolution must be a power of two in [8,512]
- * (the reference raises ValueError for non powers of two, :215-216,:330-331 -> MIGAN_EINVAL). */
+ * (the reference raises ValueError for non powers of two, :215-216,:330-331 -> MIGAN_EINVAL).
+ * dtype: MIGAN_DTYPE_* (activation storage). */
 int migan_create(int resolution, int dtype, int device, migan_handle** out);
 int migan_destroy(migan_handle* h);
+
+/* Per-handle GEMM variant (initially the process default, environment MIGAN_GEMM; 16-bit storage handles are f16x2 only).
+ * Re-plans the launch sequence; the workspace size may change. */
+int migan_set_gemm(migan_handle* h, int variant);
+int migan_get_gemm(const migan_handle* h, int* variant);
+/* on != 0: the caller asserts that the conv2 weights do not change between forwards.  The 16-bit operand planes of the
+ * split GEMM variants (a per-forward preparation pass otherwise, so that in-place parameter updates are always seen) are
+ * then written once -- by the first forward after this call, after any migan_set_weight / migan_commit, or when the
+ * workspace pointer or stream differs from the one they were prepared on -- and reused.  In-place writes to a bound weight
+ * tensor while the assertion is on are NOT seen: call migan_assume_static_weights(h, 1) again (or migan_commit) after them. */
+int migan_assume_static_weights(migan_handle* h, int on);
+/* streams = 2 (default): a forward of >= 16 images runs as two sub-batches on two HIP streams (the caller's and one the
+ * handle owns, forked and joined with events, no host synchronisation), the second starting when the first is a few layers
+ * in: the low-resolution layers of one half (a few dozen workgroups each) overlap full-size layers of the other.
+ * streams = 1: every launch on the caller's stream.  Changes migan_workspace_bytes. */
+int migan_set_streams(migan_handle* h, int streams);
 
 /* state_dict schema (same keys, shapes and parameter/buffer split as
  * reference Generator(resolution).state_dict(); 177 entries at 512, 154 at 256). */
@@ -67,6 +98,30 @@ int migan_workspace_bytes(const migan_handle* h, int batch, size_t* bytes);
  * (reference scripts/demo.py:56-66); y: [batch,3,R,R].  x is not modified. */
 int migan_forward(migan_handle* h, const void* x_nchw, void* y_nchw, int batch,
                   void* workspace, size_t workspace_bytes, void* stream);
+
+/* Fully convolutional forward (reference README.md:87): x [batch,4,height,width] ->
+ * y [batch,3,height,width], height and width positive multiples of resolution / 4.  Block b<res> runs at
+ * (height*res/resolution) x (width*res/resolution); the reference's two fixed-size constants are made "dynamic" the way
+ * its README asks: filter_const (the zero-insertion mask of Upsample2d, :85) is implicit in the polyphase FIR, and each
+ * noise_const [res,res] (:149) is tiled periodically and cropped to its layer's size (== the reference module run with
+ * those buffers replaced by noise_const.repeat(...)[:h,:w]).  height = width = resolution is migan_forward. */
+int migan_workspace_bytes_hw(migan_handle* h, int batch, int height, int width, size_t* bytes);
+int migan_forward_hw(migan_handle* h, const void* x_nchw, void* y_nchw, int batch, int height, int width,
+                     void* workspace, size_t workspace_bytes, void* stream);
+
+/* uint8 in, uint8 out (reference scripts/demo.py:56-66,135-140 at network resolution):
+ * img [batch][R][R][3] uint8 HWC + mask [batch][R][R] uint8 (255 = known pixel) -> composited uint8 image
+ * [batch][R][R][3] = img where the mask is 255, (y*0.5+0.5).clamp(0,1)*255 -> uint8 elsewhere.  preprocess() is computed
+ * inside the first layer's tile builder (no fp32 network input is materialised) and the post-processing + composition
+ * inside the last ToRGB epilogue (no fp32 network output either); bit-identical to migan_pack_input -> migan_forward ->
+ * migan_compose_output. */
+typedef struct migan_io_u8 {
+  const void* img;
+  const void* mask;
+  void* out;
+} migan_io_u8;
+int migan_forward_u8(migan_handle* h, const void* img_hwc_u8, const void* mask_u8, void* out_hwc_u8, int batch,
+                     void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- measurement and debugging ---------------------------------------------------------- */
 
@@ -119,6 +174,9 @@ typedef struct migan_sepconv_desc {
   void* wsplit;               /* optional: 16 + 3*cout*cin*2 bytes (16-byte aligned) for the 16-bit weight planes of the split GEMM
                                  variants; null or too small -> the exact fp32-MFMA kernels run */
   size_t wsplit_bytes;
+  int gemm;                   /* MIGAN_GEMM_*; MIGAN_GEMM_DEFAULT (-1) = the process default */
+  int dtype;                  /* MIGAN_DTYPE_*: storage format of x (unless fromrgb), y and skip; scratch stays fp32 */
+  int width_in;               /* 0: square input (res_in x res_in); otherwise the input is res_in rows x width_in columns */
 } migan_sepconv_desc;
 int migan_sepconv_forward(const migan_sepconv_desc* d, void* stream);
 
@@ -137,7 +195,8 @@ int migan_compose_output(const void* y_nchw, const void* img_hwc_u8, const void*
 const char* migan_last_error(void);
 /* "hip:gfx950" for the product library. */
 const char* migan_backend(void);
-/* How the 1x1 convolutions are multiplied (environment MIGAN_GEMM=f32|bf16x3|f16x2, read once per process):
+/* The process default of how the 1x1 convolutions are multiplied (environment MIGAN_GEMM=f32|bf16x3|f16x2, read once
+ * per process; per handle: migan_set_gemm):
  *   "f32"    v_mfma_f32_32x32x2_f32, exact fp32 products;
  *   "bf16x3" each fp32 operand split into three bf16 pieces, the six products of order <= 2^-16
  *            on v_mfma_f32_32x32x16_bf16 with fp32 accumulation: fp32-grade accuracy at 6/16 of the MFMA cost;

@@ -2,22 +2,34 @@
 
 In-tree on purpose: the .so sits next to its sources (mi-gan_amd/csrc/) so it travels with the
 repository snapshot to the GPU box and shows up as a loaded in-tree native library.
+
+The library is several translation units compiled in parallel: the host plan + C ABI + the small
+kernels (migan_hip.hip) and one unit per slice of the fused-SeparableConv2d kernel table
+(migan_k_slice.hip compiled with -DMIGAN_SLICE_G=<GEMM variant> -DMIGAN_SLICE_S=<storage format>).
 """
 from __future__ import annotations
 
 import os
 import shutil
 import subprocess
-from typing import List
+from concurrent.futures import ThreadPoolExecutor
+from typing import List, Sequence, Tuple
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 ROOT = os.path.dirname(HERE)
 OUT = os.path.join(CSRC, "libmigan_hip.so")
-SOURCES = [os.path.join(CSRC, f) for f in ("migan_hip.hip", "migan_kernels.hpp", "migan_host.hpp", "migan_rt_hip.h",
+OBJ = os.path.join(CSRC, "_obj")
+SOURCES = [os.path.join(CSRC, f) for f in ("migan_hip.hip", "migan_k_slice.hip", "migan_k_slice.inc", "migan_table.hpp",
+                                            "migan_kernels.hpp", "migan_host.hpp", "migan_rt_hip.h",
                                             "comodgan_kernels.hpp", "comodgan_host.hpp")] + [
     os.path.join(ROOT, "include", "migan_hip.h"), os.path.join(ROOT, "include", "comodgan_hip.h")]
 ARCH = "gfx950"
+# (GEMM variant, activation storage format) slices of the sepconv_kernel table; 16-bit storage is built for f16x2 only
+SLICES: Sequence[Tuple[int, int]] = ((0, 0), (1, 0), (2, 0), (2, 1), (2, 2))
+# -fno-honor-nans is NOT used: the reference's Tensor.clamp propagates NaN (SURVEY section 8c) and so does v_med3_f32
+# only when NaNs are honoured
+FLAGS = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC"] + os.environ.get("MIGAN_HIPCC_FLAGS", "").split()
 
 
 def hipcc() -> str:
@@ -27,9 +39,14 @@ def hipcc() -> str:
     raise RuntimeError("hipcc not found (need ROCm >= 7.0 for --offload-arch=gfx950)")
 
 
-def command(extra: List[str] = ()) -> List[str]:
-    return [hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared", "-fno-honor-nans",
-            os.path.join(CSRC, "migan_hip.hip"), "-o", OUT, *extra]
+def units(extra: Sequence[str] = ()) -> List[Tuple[str, List[str]]]:
+    """(object file, command) per translation unit"""
+    cc = hipcc()
+    out = [(os.path.join(OBJ, "migan_hip.o"), [cc, *FLAGS, *extra, "-c", os.path.join(CSRC, "migan_hip.hip")])]
+    for g, s in SLICES:
+        out.append((os.path.join(OBJ, f"migan_k_g{g}s{s}.o"),
+                    [cc, *FLAGS, *extra, f"-DMIGAN_SLICE_G={g}", f"-DMIGAN_SLICE_S={s}", "-c", os.path.join(CSRC, "migan_k_slice.hip")]))
+    return [(o, cmd + ["-o", o]) for o, cmd in out]
 
 
 def is_fresh() -> bool:
@@ -38,16 +55,28 @@ def is_fresh() -> bool:
     return os.path.getmtime(OUT) >= max(os.path.getmtime(s) for s in SOURCES)
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
-    if not force and is_fresh():
+def build(force: bool = False, verbose: bool = False, extra: Sequence[str] = (), jobs: int = 0) -> str:
+    if not force and not extra and is_fresh():
         return OUT
-    cmd = command()
+    os.makedirs(OBJ, exist_ok=True)
+    us = units(extra)
+
+    def run(u):
+        if verbose:
+            print(" ".join(u[1]), flush=True)
+        subprocess.run(u[1], check=True, cwd=CSRC, stderr=None if verbose else subprocess.DEVNULL)
+        return u[0]
+
+    with ThreadPoolExecutor(max_workers=jobs or min(len(us), os.cpu_count() or 1)) as ex:
+        objs = list(ex.map(run, us))
+    link = [hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC", *objs, "-o", OUT]
     if verbose:
-        print(" ".join(cmd))
-    subprocess.run(cmd, check=True, cwd=CSRC)
+        print(" ".join(link), flush=True)
+    subprocess.run(link, check=True, cwd=CSRC)
     return OUT
 
 
 if __name__ == "__main__":
     import sys
-    print(build(force="--force" in sys.argv, verbose=True))
+    print(build(force="--force" in sys.argv, verbose=True,
+                extra=[a for a in sys.argv[1:] if a.startswith("-D") or a.startswith("-R") or a.startswith("-save")]))

@@ -62,11 +62,18 @@ inline const CmConvEntry& cm_pick_conv(int NT, int KC, bool nine, int MTI, bool 
   throw Error(MIGAN_EINVAL, "internal: no cm_conv_kernel instantiation for this tile");
 }
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-device attribute: once per device ordinal (the caller has made
+// that device current)
 inline void cm_prepare_kernels() {
-  static bool done = false;
-  if (done) return;
+  static std::vector<char> done;
+  static std::mutex mu;
+  int dev = 0;
+  rt_check(rt::get_device(&dev), "hipGetDevice");
+  std::lock_guard<std::mutex> lock(mu);
+  if (dev >= 0 && dev < (int)done.size() && done[dev]) return;
   for (const auto& e : cm_conv_table()) rt_check(rt::allow_dynamic_lds((const void*)e.fn, 160 * 1024), "hipFuncSetAttribute");
-  done = true;
+  if (dev >= (int)done.size()) done.resize(dev + 1, 0);
+  if (dev >= 0) done[dev] = 1;
 }
 
 enum : int { CM_CONV_NORMAL = 0, CM_CONV_DOWN = 1, CM_CONV_UP = 2, CM_CONV_UP4 = 3 };
@@ -86,6 +93,7 @@ struct comodgan_handle {
   // comodgan_assume_static_weights: skip the per-forward weight preparation while nothing it depends on has changed
   bool static_weights = false;
   const void* prepared_ws = nullptr;
+  rt::stream_t prepared_stream{};   // the planes are only valid for work ordered after their preparation: same stream
   unsigned long long weights_epoch = 1, prepared_epoch = 0;
 
   int channels(int res) const { return std::min(cfg.ch_base / res, cfg.ch_max); }
@@ -257,7 +265,8 @@ inline size_t comodgan_handle::walk(int batch, const float* x, const float* z, f
       if (c.name == name) return c;
     throw Error(MIGAN_EINVAL, "internal: no conv " + name);
   };
-  skip_launch = !dry && static_weights && prepared_ws == ws && prepared_epoch == weights_epoch;
+  skip_launch = !dry && static_weights && prepared_ws == ws && prepared_epoch == weights_epoch && prepared_stream == stream;
+  if (!dry && !skip_launch) prepared_ws = nullptr;      // marked prepared again only after every preparation launch succeeded
   for (const auto& c : convs) {
     CmWprepArgs q{};
     q.w = dry ? nullptr : W(c.name + ".weight"); q.amax = c.amax; q.wsq = c.wsq; q.wn2 = c.wn2; q.CO = c.co; q.CI = c.ci;
@@ -272,6 +281,7 @@ inline size_t comodgan_handle::walk(int batch, const float* x, const float* z, f
   if (!dry) {
     prepared_ws = ws;
     prepared_epoch = weights_epoch;
+    prepared_stream = stream;
   }
 
   // ---------------------------------------------------------------- helpers for the layers
@@ -582,7 +592,7 @@ int comodgan_create(const comodgan_config* cfg, int device, comodgan_handle** ou
     const int c = std::min(cfg->ch_base / res, cfg->ch_max);
     MIGAN_CHECK(c >= 64 && c % 64 == 0, MIGAN_EINVAL, "channel counts must be multiples of 64");
   }
-  rt_check(rt::set_device(device), "hipSetDevice");
+  DeviceGuard guard(device);
   prepare_kernels();
   cm_prepare_kernels();
   comodgan_handle* h = new comodgan_handle();
@@ -643,7 +653,7 @@ int comodgan_commit(comodgan_handle* h, void* stream) {
   MIGAN_API_BEGIN
   using namespace migan;
   MIGAN_CHECK(h, MIGAN_EINVAL, "null handle");
-  rt_check(rt::set_device(h->device), "hipSetDevice");
+  DeviceGuard guard(h->device);
   for (const auto& s : h->slots) MIGAN_CHECK(s.ptr != nullptr, MIGAN_ESTATE, std::string("missing key in state_dict: ") + s.name);
   static const double taps[4] = {1.0, 3.0, 3.0, 1.0};
   float host[16];
@@ -716,7 +726,7 @@ static int comodgan_forward_impl(comodgan_handle* h, const void* x, const void* 
       h->events.push_back(e);
     }
   }
-  rt_check(rt::set_device(h->device), "hipSetDevice");
+  DeviceGuard guard(h->device);
   h->walk(batch, (const float*)x, (const float*)z, (float*)y, psi, noise_mode, (const float*)noise, ws, (rt::stream_t)stream, false, ms, n_ms);
   MIGAN_API_END
 }

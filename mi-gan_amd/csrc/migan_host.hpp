@@ -12,11 +12,13 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <stdexcept>
 #include <string>
 #include <vector>
 
 #include "../../include/migan_hip.h"
+#include "migan_table.hpp"
 
 namespace migan {
 
@@ -50,6 +52,7 @@ struct Geo {
   bool maing = true;               // compile-time tile geometry (8x16 pixels, one image)
   bool persist = false;            // kernel variant whose workgroups walk several tiles
   int gemmv = 0;                   // 0 exact fp32 MFMA, 1 bf16x3-split MFMA, 2 f16x2-split MFMA
+  int stv = 0;                     // activation storage format: 0 fp32, 1 bf16, 2 fp16
   bool torgb = false;              // kernel variant with the ToRGB tail in its epilogue
   bool wide = false;               // sepconv_wide_kernel: 128 pixels x 256 channels, 512 threads, specialised wave groups
   int a_stride = 0;
@@ -79,6 +82,11 @@ struct Tuning {
   int ablate = 0;              // MIGAN_ABLATE (measurement builds compiled with -DMIGAN_ABLATE only)
   int persist_min = 8192;      // MIGAN_PERSIST_MIN: launches with at least this many tiles run persistent workgroups
   int persist_grid = 512;      // MIGAN_PERSIST_GRID: ... that many (2 per CU on MI355X), each walking its share of tiles
+  int kc16 = 0;                // MIGAN_KC16 bit mask: 16-channel K chunks for the 64-output-channel main-geometry layers (f16x2 GEMM):
+                               // 1 plain / ToRGB layers, 2 fused-FromRGB layer, 4 FIR-up layers
+  int kc16_minw = 3;           // MIGAN_KC16_MINW=2|3|4: workgroups per CU those kernels are built for
+  int streams = 2;             // MIGAN_STREAMS=1|2: default of migan_set_streams
+  int stagger = -1;            // MIGAN_STAGGER: launch index of the first half after which the second half starts (-1: plan default)
 };
 inline Tuning& tuning() {
   static Tuning t = [] {
@@ -90,57 +98,73 @@ inline Tuning& tuning() {
     if (const char* e = std::getenv("MIGAN_ABLATE")) v.ablate = std::atoi(e);
     if (const char* e = std::getenv("MIGAN_PERSIST_MIN")) v.persist_min = std::max(1, std::atoi(e));
     if (const char* e = std::getenv("MIGAN_PERSIST_GRID")) v.persist_grid = std::max(8, std::atoi(e) / 8 * 8);   // multiple of 8: one share per XCD
+    if (const char* e = std::getenv("MIGAN_KC16")) v.kc16 = std::atoi(e);
+    if (const char* e = std::getenv("MIGAN_KC16_MINW")) v.kc16_minw = std::min(4, std::max(2, std::atoi(e)));
+    if (const char* e = std::getenv("MIGAN_STREAMS")) v.streams = std::atoi(e) >= 2 ? 2 : 1;
+    if (const char* e = std::getenv("MIGAN_STAGGER")) v.stagger = std::atoi(e);
     return v;
   }();
   return t;
 }
 
-inline Geo choose_geo(int mode, int cin, int cout, int res_in, bool fromrgb, bool with_torgb = false, int gemmv = -1) {
+// Tile geometry for a layer whose GEMM runs on an h_in x w_in pixel grid.  Square power-of-two sizes (the reference's
+// fixed resolutions) get the tuned geometries; any other size (migan_forward_hw) gets 8x16 tiles with ragged edges.
+inline Geo choose_geo(int mode, int cin, int cout, int h_in, int w_in, bool fromrgb, bool with_torgb = false, int gemmv = -1, int stv = 0) {
   Geo g;
   g.gemmv = gemmv < 0 ? tuning().gemm : gemmv;
+  g.stv = stv;
+  MIGAN_CHECK(stv == 0 || g.gemmv == 2, MIGAN_EINVAL, "16-bit activation storage is built for the f16x2 GEMM variant only");
   g.mode = mode;
   g.fromrgb = fromrgb;
   MIGAN_CHECK(cin % 32 == 0 && cout % 64 == 0, MIGAN_EINVAL,
               "channel counts must be multiples of 32 (in) / 64 (out)");
-  MIGAN_CHECK(res_in >= 4 && (res_in & (res_in - 1)) == 0, MIGAN_EINVAL, "resolution must be a power of two >= 4");
+  MIGAN_CHECK(h_in >= 1 && w_in >= 1, MIGAN_EINVAL, "empty image");
+  const bool sq2 = h_in == w_in && (h_in & (h_in - 1)) == 0;      // square power of two
+  const bool full = h_in % 8 == 0 && w_in % 16 == 0;               // whole 8x16 tiles
   g.NT = (cout % 128 == 0) ? 128 : 64;
   int GH, GW, IMGS;
   if (mode == MODE_NORMAL) {
     g.MT = 128; g.KC = 32;
-    if (res_in >= 16 && cout % 256 == 0 && !fromrgb && g.gemmv == 2 && tuning().wide) {
+    if (full && cout % 256 == 0 && !fromrgb && g.gemmv == 2 && tuning().wide) {
       // wide layers: one 8-wave workgroup owns 256 output channels of 8x16 pixels; half of its waves run the
       // depthwise stage of the next K chunk while the other half keeps the matrix cores busy (sepconv_wide_kernel)
       g.wide = true; g.NT = 256; GH = 8; GW = 16; IMGS = 1;
-    } else if (res_in >= 16 && cout == 256 && with_torgb && tuning().nt256) {
+    } else if (full && cout == 256 && with_torgb && tuning().nt256) {
       // 256-channel layer followed by ToRGB: one workgroup owns all 256 output channels of 4x16 pixels so the
       // ToRGB tail fuses into its epilogue (saves the feature re-read of torgb_kernel).  Measured on its own the
       // 64 x 256 tile is ~7 % slower than 128 x 128 (2-row depthwise strips, twice the weight-tile traffic), so
       // it is used only where it removes a launch.
       g.MT = 64; g.NT = 256; GH = 4; GW = 16; IMGS = 1;
-    } else if (res_in >= 16) { GH = 8; GW = 16; IMGS = 1; }
-    else if (res_in == 8) { GH = 8; GW = 8; IMGS = 2; }
-    else { GH = 4; GW = 4; IMGS = 8; }
+    } else if (sq2 && h_in == 8) { GH = 8; GW = 8; IMGS = 2; }
+    else if (sq2 && h_in == 4) { GH = 4; GW = 4; IMGS = 8; }
+    else { GH = 8; GW = 16; IMGS = 1; }
     g.sy = GH; g.sx = GW; g.off = 0;
-    g.tiles_y = res_in / GH; g.tiles_x = res_in / GW;
+    g.tiles_y = cdiv(h_in, GH); g.tiles_x = cdiv(w_in, GW);
   } else if (mode == MODE_PW) {
-    // pointwise GEMM at res_in (second half of a down=2 layer; its input is dwfir_kernel's output)
+    // pointwise GEMM at h_in x w_in (second half of a down=2 layer; its input is dwfir_kernel's output)
     MIGAN_CHECK(!fromrgb, MIGAN_EINVAL, "fromrgb is only fused into plain layers");
     g.MT = 128; g.KC = 32;
-    if (res_in >= 16) { GH = 8; GW = 16; IMGS = 1; }
-    else if (res_in == 8) { GH = 8; GW = 8; IMGS = 2; }
-    else { GH = 4; GW = 4; IMGS = 8; }
+    if (sq2 && h_in == 8) { GH = 8; GW = 8; IMGS = 2; }
+    else if (sq2 && h_in == 4) { GH = 4; GW = 4; IMGS = 8; }
+    else { GH = 8; GW = 16; IMGS = 1; }
     g.sy = GH; g.sx = GW; g.off = 0;
-    g.tiles_y = res_in / GH; g.tiles_x = res_in / GW;
+    g.tiles_y = cdiv(h_in, GH); g.tiles_x = cdiv(w_in, GW);
   } else {
     MIGAN_CHECK(!fromrgb, MIGAN_EINVAL, "fromrgb is only fused into plain layers");
     g.MT = 128; g.KC = 32;
-    if (res_in >= 8) { GH = 8; GW = 16; IMGS = 1; }
-    else { GH = 8; GW = 8; IMGS = 2; }
+    if (sq2 && h_in < 8) { GH = 8; GW = 8; IMGS = 2; }
+    else { GH = 8; GW = 16; IMGS = 1; }
     g.sy = GH - 2; g.sx = GW - 2; g.off = 1;     // 1-pixel halo of GEMM outputs is recomputed per tile
-    g.tiles_y = cdiv(res_in, g.sy); g.tiles_x = cdiv(res_in, g.sx);
+    g.tiles_y = cdiv(h_in, g.sy); g.tiles_x = cdiv(w_in, g.sx);
   }
   g.nchunks = cout / g.NT;
   g.lgGH = ilog2(GH); g.lgGW = ilog2(GW); g.lgIMGS = ilog2(IMGS);
+  g.MINW = 2;                                    // 2 workgroups per CU
+  // 64-output-channel layers on main tiles (the 512x512 layers): optionally 16-channel K chunks at 3-4 workgroups per CU
+  if (g.gemmv == 2 && g.NT == 64 && g.MT == 128 && !g.wide && IMGS == 1 && GW == 16 && GH == 8 && mode != MODE_PW) {
+    const int bit = fromrgb ? 2 : (mode == MODE_UP ? 4 : 1);
+    if (tuning().kc16 & bit) { g.KC = 16; g.MINW = tuning().kc16_minw; }
+  }
   MIGAN_CHECK(IMGS * GH * GW == g.MT, MIGAN_EINVAL, "internal: tile geometry does not fill the GEMM tile");
   const int QC = g.KC / 4;
   const int rs = GH / 4 > 0 ? GH / 4 : 1;        // depthwise strips are 4 output rows tall
@@ -148,11 +172,13 @@ inline Geo choose_geo(int mode, int cin, int cout, int res_in, bool fromrgb, boo
   const int halo = (mode == MODE_PW) ? 0 : 1;
   g.npix_in = IMGS * (GH + 2 * halo) * (GW + 2 * halo);
   const int items = cdiv(g.npix_in * QC, kThreads);
-  g.maing = (IMGS == 1 && GW == 16 && GH == (g.MT == 64 ? 4 : 8));
+  // compile-time tile geometry: plain / pointwise tiles must be whole (no bounds checks in that epilogue), FIR-up tiles
+  // are ragged by construction
+  g.maing = (IMGS == 1 && GW == 16 && GH == (g.MT == 64 ? 4 : 8)) && (full || mode == MODE_UP);
   if (mode == MODE_PW || g.MT == 64) g.NI = 4;
+  else if (g.KC == 16) g.NI = 3;
   else g.NI = g.maing ? 6 : 9;
   MIGAN_CHECK(items <= g.NI, MIGAN_EINVAL, "internal: input tile too large");
-  g.MINW = 2;                                    // 2 workgroups per CU (3 measured slower: profiles/r01 notes)
   const int AS = g.KC + 4, GS = g.NT + 4;
   // operand tiles in floats: fp32 rows of pitch KC+4, or three unpadded (XOR-swizzled) bf16 planes
   const int npl = g.gemmv == 2 ? 2 : 3;
@@ -188,62 +214,37 @@ inline Geo choose_geo(int mode, int cin, int cout, int res_in, bool fromrgb, boo
   return g;
 }
 
-typedef void (*SepKernelFn)(const SepArgs);
-
-struct KernelEntry {
-  int mode, MT, NT, KC;
-  bool fromrgb;
-  int NI, MINW;
-  bool maing, persist;
-  int gemmv;
-  bool torgb;
-  SepKernelFn fn;
-  const char* name;
-};
-
-#define MIGAN_KERNEL1(MODE, MT, NT, KC, RGB, NI, MINW, MAING, PERSIST, GEMMV, TORGB)                                                      \
-  {MODE, MT, NT, KC, RGB, NI, MINW, MAING, PERSIST, GEMMV, TORGB,                                                                        \
-   sepconv_kernel<MODE, MT, NT, KC, RGB, NI, MINW, MAING, PERSIST, GEMMV, TORGB>,                                                        \
-   "migan::sepconv_kernel<" #MODE ", " #MT ", " #NT ", " #KC ", " #RGB ", " #NI ", " #MINW ", " #MAING ", " #PERSIST ", " #GEMMV ", " #TORGB ">"}
-#define MIGAN_KERNEL(MODE, MT, NT, KC, RGB, NI, MINW, MAING, PERSIST)                                                          \
-  MIGAN_KERNEL1(MODE, MT, NT, KC, RGB, NI, MINW, MAING, PERSIST, 0, false), MIGAN_KERNEL1(MODE, MT, NT, KC, RGB, NI, MINW, MAING, PERSIST, 1, false), \
-  MIGAN_KERNEL1(MODE, MT, NT, KC, RGB, NI, MINW, MAING, PERSIST, 2, false)
-#define MIGAN_KERNEL_TORGB(MT, NT, NI, MAING, PERSIST)                                                                            \
-  MIGAN_KERNEL1(0, MT, NT, 32, false, NI, 2, MAING, PERSIST, 0, true), MIGAN_KERNEL1(0, MT, NT, 32, false, NI, 2, MAING, PERSIST, 1, true), \
-  MIGAN_KERNEL1(0, MT, NT, 32, false, NI, 2, MAING, PERSIST, 2, true)
-
+// one slice per (GEMM variant, storage format): migan_k_slice.inc
+KernelSlice slice_g0s0();
+KernelSlice slice_g1s0();
+KernelSlice slice_g2s0();
+KernelSlice slice_g2s1();
+KernelSlice slice_g2s2();
 inline const std::vector<KernelEntry>& kernel_table() {
-  static const std::vector<KernelEntry> t = {
-      // plain layers (MODE 0): main 8x16 tiles (NI 6) and small-resolution multi-image tiles (NI 9)
-      MIGAN_KERNEL(0, 128, 128, 32, false, 6, 2, true, false), MIGAN_KERNEL(0, 128, 128, 32, false, 9, 2, false, false),
-      MIGAN_KERNEL(0, 128, 64, 32, false, 6, 2, true, false),  MIGAN_KERNEL(0, 128, 64, 32, false, 9, 2, false, false),
-      MIGAN_KERNEL(0, 128, 64, 32, false, 6, 2, true, true),
-      MIGAN_KERNEL(0, 128, 128, 32, true, 6, 2, true, false),  MIGAN_KERNEL(0, 128, 128, 32, true, 9, 2, false, false),
-      MIGAN_KERNEL(0, 128, 64, 32, true, 6, 2, true, false),   MIGAN_KERNEL(0, 128, 64, 32, true, 9, 2, false, false),
-      MIGAN_KERNEL(0, 128, 64, 32, true, 6, 2, true, true),
-      // plain layers whose epilogue also produces the running RGB image (CO == NT)
-      MIGAN_KERNEL_TORGB(128, 128, 6, true, false), MIGAN_KERNEL_TORGB(128, 128, 9, false, false), MIGAN_KERNEL_TORGB(128, 64, 6, true, false),
-      MIGAN_KERNEL_TORGB(128, 64, 9, false, false),
-      // 256-channel layer + ToRGB: 64 pixels x 256 channels
-      MIGAN_KERNEL_TORGB(64, 256, 4, true, false),
-      // FIR-up layers (MODE 2)
-      MIGAN_KERNEL(2, 128, 128, 32, false, 6, 2, true, false), MIGAN_KERNEL(2, 128, 128, 32, false, 9, 2, false, false),
-      MIGAN_KERNEL(2, 128, 64, 32, false, 6, 2, true, false),  MIGAN_KERNEL(2, 128, 64, 32, false, 9, 2, false, false),
-      MIGAN_KERNEL(2, 128, 64, 32, false, 6, 2, true, true),
-      // pointwise GEMM (MODE 3): second half of FIR-down layers
-      MIGAN_KERNEL(3, 128, 128, 32, false, 4, 2, true, false), MIGAN_KERNEL(3, 128, 128, 32, false, 4, 2, false, false),
-      MIGAN_KERNEL(3, 128, 128, 32, false, 4, 2, true, true),
-      MIGAN_KERNEL(3, 128, 64, 32, false, 4, 2, true, false),  MIGAN_KERNEL(3, 128, 64, 32, false, 4, 2, false, false),
-  };
+  static const std::vector<KernelEntry> t = [] {
+    std::vector<KernelEntry> v;
+    for (const KernelSlice& sl : {slice_g0s0(), slice_g1s0(), slice_g2s0(), slice_g2s1(), slice_g2s2()})
+      v.insert(v.end(), sl.entries, sl.entries + sl.n);
+    return v;
+  }();
   return t;
 }
 
-inline const char* wide_name(const Geo& g) { return g.torgb ? "migan::sepconv_wide_kernel<true>" : "migan::sepconv_wide_kernel<false>"; }
+inline const char* wide_name(const Geo& g) {
+  static const char* n[2][3] = {{"migan::sepconv_wide_kernel<false, 0>", "migan::sepconv_wide_kernel<false, 1>", "migan::sepconv_wide_kernel<false, 2>"},
+                                {"migan::sepconv_wide_kernel<true, 0>", "migan::sepconv_wide_kernel<true, 1>", "migan::sepconv_wide_kernel<true, 2>"}};
+  return n[g.torgb ? 1 : 0][g.stv];
+}
+inline SepKernelFn wide_fn(bool torgb, int stv) {
+  static const SepKernelFn f[2][3] = {{sepconv_wide_kernel<false, 0>, sepconv_wide_kernel<false, 1>, sepconv_wide_kernel<false, 2>},
+                                      {sepconv_wide_kernel<true, 0>, sepconv_wide_kernel<true, 1>, sepconv_wide_kernel<true, 2>}};
+  return f[torgb ? 1 : 0][stv];
+}
 inline const char* kernel_name(const Geo& g);
 inline const KernelEntry& pick_kernel(const Geo& g) {
   for (const auto& e : kernel_table())
     if (e.mode == g.mode && e.MT == g.MT && e.NT == g.NT && e.KC == g.KC && e.fromrgb == g.fromrgb && e.NI == g.NI &&
-        e.MINW == g.MINW && e.maing == g.maing && e.persist == g.persist && e.gemmv == g.gemmv && e.torgb == g.torgb)
+        e.MINW == g.MINW && e.maing == g.maing && e.persist == g.persist && e.gemmv == g.gemmv && e.torgb == g.torgb && e.stv == g.stv)
       return e;
   throw Error(MIGAN_EINVAL, "internal: no kernel instantiation for this geometry");
 }
@@ -252,7 +253,7 @@ inline const char* kernel_name(const Geo& g) { return g.wide ? wide_name(g) : pi
 
 // persistent variants exist where they fit the register budget without spilling
 inline bool has_persistent_variant(const Geo& g) {
-  return g.maing && g.MINW == 2 && ((g.NT == 64 && g.mode != MODE_PW) || (g.mode == MODE_PW && g.NT == 128));
+  return g.maing && ((g.NT == 64 && g.mode != MODE_PW) || (g.mode == MODE_PW && g.NT == 128 && g.MINW == 2));
 }
 
 // ---- depthwise + FIR-down kernel (first half of down=2 layers) ----
@@ -262,19 +263,20 @@ struct DwGeo {
   int off_d = 0, off_w = 0;
   size_t lds_bytes = 0;
 };
-inline DwGeo choose_dwfir_geo(int c, int res_in) {
+inline DwGeo choose_dwfir_geo(int c, int h_in, int w_in) {
   DwGeo g;
-  MIGAN_CHECK(c % 16 == 0 && res_in >= 8 && (res_in & (res_in - 1)) == 0, MIGAN_EINVAL, "dwfir: bad shape");
-  const int ro = res_in / 2;
+  MIGAN_CHECK(c % 16 == 0 && h_in >= 2 && w_in >= 2 && h_in % 2 == 0 && w_in % 2 == 0, MIGAN_EINVAL, "dwfir: bad shape");
+  const int ho = h_in / 2, wo = w_in / 2;
+  const bool sq2 = ho == wo && (ho & (ho - 1)) == 0;
   int GH = 4, GW, IMGS;
-  if (ro >= 16) { GW = 16; IMGS = 1; }
-  else if (ro == 8) { GW = 8; IMGS = 2; }
-  else { GW = 4; IMGS = 4; }
+  if (sq2 && ho == 8) { GW = 8; IMGS = 2; }
+  else if (sq2 && ho <= 4) { GW = 4; IMGS = 4; }
+  else { GW = 16; IMGS = 1; }
   g.lgGH = 2; g.lgGW = ilog2(GW); g.lgIMGS = ilog2(IMGS);
-  g.tiles_y = ro / GH; g.tiles_x = ro / GW;
+  g.tiles_y = cdiv(ho, GH); g.tiles_x = cdiv(wo, GW);
   g.kpw = (c / 16) % 4 == 0 ? 4 : ((c / 16) % 2 == 0 ? 2 : 1);   // chunks walked per workgroup (software pipelined)
   g.nkg = (c / 16) / g.kpw;
-  g.maing = (IMGS == 1 && GW == 16);
+  g.maing = (IMGS == 1 && GW == 16) && ho % 4 == 0 && wo % 16 == 0;
   const int npix = IMGS * (2 * GH + 4) * (2 * GW + 4);
   const int items = cdiv(npix * 4, kThreads);
   g.NI = g.maing ? 7 : 9;
@@ -285,19 +287,64 @@ inline DwGeo choose_dwfir_geo(int c, int res_in) {
   return g;
 }
 inline unsigned dwfir_grid(const DwGeo& g, int batch) { return (unsigned)(g.tiles_x * g.tiles_y * cdiv(batch, 1 << g.lgIMGS) * g.nkg); }
-inline const char* dwfir_name(const DwGeo& g) { return g.maing ? "migan::dwfir_kernel<7, true>" : "migan::dwfir_kernel<9, false>"; }
-
-// Raise the dynamic-LDS limit of every instantiation once per process (tiles use up to ~74 KiB).
-inline void prepare_kernels() {
-  static bool done = false;
-  if (done) return;
-  for (const auto& e : kernel_table()) rt_check(rt::allow_dynamic_lds((const void*)e.fn, 96 * 1024), "hipFuncSetAttribute");
-  rt_check(rt::allow_dynamic_lds((const void*)sepconv_wide_kernel<true>, 160 * 1024), "hipFuncSetAttribute");
-  rt_check(rt::allow_dynamic_lds((const void*)sepconv_wide_kernel<false>, 160 * 1024), "hipFuncSetAttribute");
-  rt_check(rt::allow_dynamic_lds((const void*)dwfir_kernel<7, true>, 96 * 1024), "hipFuncSetAttribute");
-  rt_check(rt::allow_dynamic_lds((const void*)dwfir_kernel<9, false>, 96 * 1024), "hipFuncSetAttribute");
-  done = true;
+typedef void (*DwFirKernelFn)(const DwFirArgs);
+inline const char* dwfir_name(const DwGeo& g, int stv = 0) {
+  static const char* n[2][3] = {{"migan::dwfir_kernel<9, false, 0>", "migan::dwfir_kernel<9, false, 1>", "migan::dwfir_kernel<9, false, 2>"},
+                                {"migan::dwfir_kernel<7, true, 0>", "migan::dwfir_kernel<7, true, 1>", "migan::dwfir_kernel<7, true, 2>"}};
+  return n[g.maing ? 1 : 0][stv];
 }
+inline DwFirKernelFn dwfir_fn(bool maing, int stv) {
+  static const DwFirKernelFn f[2][3] = {{dwfir_kernel<9, false, 0>, dwfir_kernel<9, false, 1>, dwfir_kernel<9, false, 2>},
+                                        {dwfir_kernel<7, true, 0>, dwfir_kernel<7, true, 1>, dwfir_kernel<7, true, 2>}};
+  return f[maing ? 1 : 0][stv];
+}
+typedef void (*RgbKernelFn)(const RgbArgs);
+inline RgbKernelFn torgb_fn(int stv) {
+  static const RgbKernelFn f[3] = {torgb_kernel<0>, torgb_kernel<1>, torgb_kernel<2>};
+  return f[stv];
+}
+inline const char* torgb_name(int stv) {
+  static const char* n[3] = {"migan::torgb_kernel<0>", "migan::torgb_kernel<1>", "migan::torgb_kernel<2>"};
+  return n[stv];
+}
+
+// Raise the dynamic-LDS limit of every instantiation (tiles use up to 145 KiB).  The attribute is per device, so
+// this runs once per device ordinal (the caller has made that device current).
+inline void prepare_kernels() {
+  static std::vector<char> done;
+  static std::mutex mu;
+  int dev = 0;
+  rt_check(rt::get_device(&dev), "hipGetDevice");
+  std::lock_guard<std::mutex> lock(mu);
+  if (dev >= 0 && dev < (int)done.size() && done[dev]) return;
+  for (const auto& e : kernel_table()) rt_check(rt::allow_dynamic_lds((const void*)e.fn, 96 * 1024), "hipFuncSetAttribute");
+  for (int t = 0; t < 2; ++t)
+    for (int sv = 0; sv < 3; ++sv) {
+      rt_check(rt::allow_dynamic_lds((const void*)wide_fn(t != 0, sv), 160 * 1024), "hipFuncSetAttribute");
+      rt_check(rt::allow_dynamic_lds((const void*)dwfir_fn(t != 0, sv), 96 * 1024), "hipFuncSetAttribute");
+    }
+  if (dev >= (int)done.size()) done.resize(dev + 1, 0);
+  if (dev >= 0) done[dev] = 1;
+}
+
+// Every C ABI entry point that touches the device runs on the handle's device and leaves the caller's current
+// device as it found it.
+struct DeviceGuard {
+  int prev = -1;
+  bool restore = false;
+  explicit DeviceGuard(int device) {
+    rt_check(rt::get_device(&prev), "hipGetDevice");
+    if (prev != device) {
+      rt_check(rt::set_device(device), "hipSetDevice");
+      restore = true;
+    }
+  }
+  ~DeviceGuard() {
+    if (restore) rt::set_device(prev);
+  }
+  DeviceGuard(const DeviceGuard&) = delete;
+  DeviceGuard& operator=(const DeviceGuard&) = delete;
+};
 
 #ifdef MIGAN_PHASE_PROF
 inline unsigned long long* prof_buffer() {
@@ -351,21 +398,19 @@ inline void launch_sepconv(Geo g, const SepArgs& a, rt::stream_t stream) {
               "ToRGB can only be fused into a plain layer whose output channels fit one column tile");
   if (g.wide) {
     MIGAN_CHECK(a.wsplit != nullptr, MIGAN_EINVAL, "internal: the wide kernel needs the fp16 weight planes");
-    void (*fn)(const SepArgs) = fused_rgb ? sepconv_wide_kernel<true> : sepconv_wide_kernel<false>;
-    rt_check(rt::launch(fn, a, tiles_of(g, a.B), kWideThreads, g.lds_bytes, stream), wide_name(g));
+    rt_check(rt::launch(wide_fn(fused_rgb, g.stv), a, tiles_of(g, a.B), kWideThreads, g.lds_bytes, stream), wide_name(g));
     return;
   }
   const KernelEntry& k = pick_kernel(g);
   rt_check(rt::launch(k.fn, a, grid_of(g, a.B, fused_rgb), kThreads, g.lds_bytes, stream), k.name);
 }
 
-inline void launch_dwfir(const DwGeo& g, DwFirArgs a, rt::stream_t stream) {
+inline void launch_dwfir(const DwGeo& g, DwFirArgs a, rt::stream_t stream, int stv = 0) {
   prepare_kernels();
   a.lgGH = g.lgGH; a.lgGW = g.lgGW; a.lgIMGS = g.lgIMGS;
   a.tiles_x = g.tiles_x; a.tiles_y = g.tiles_y; a.nkg = g.nkg; a.kpw = g.kpw;
   a.off_d = g.off_d; a.off_w = g.off_w;
-  if (g.maing) rt_check(rt::launch(dwfir_kernel<7, true>, a, dwfir_grid(g, a.B), kThreads, g.lds_bytes, stream), dwfir_name(g));
-  else rt_check(rt::launch(dwfir_kernel<9, false>, a, dwfir_grid(g, a.B), kThreads, g.lds_bytes, stream), dwfir_name(g));
+  rt_check(rt::launch(dwfir_fn(g.maing, stv), a, dwfir_grid(g, a.B), kThreads, g.lds_bytes, stream), dwfir_name(g, stv));
 }
 
 // 16-bit elements one tensor occupies in a weight-split buffer: header + planes, rounded to 16 bytes
@@ -377,10 +422,10 @@ inline void launch_split(const SplitArgs& a, rt::stream_t stream) {
   rt_check(rt::launch(split_weights_kernel, a, (unsigned)(a.n * kSplitBlocksPerTensor), kThreads, 0, stream), "migan::split_weights_kernel");
 }
 
-inline void launch_torgb(const RgbArgs& a, rt::stream_t stream) {
+inline void launch_torgb(const RgbArgs& a, rt::stream_t stream, int stv = 0) {
   const size_t npix = (size_t)a.B * a.H * a.W;
   const unsigned grid = (unsigned)((npix * 16 + kThreads - 1) / kThreads);
-  rt_check(rt::launch(torgb_kernel, a, grid, kThreads, 0, stream), "migan::torgb_kernel");
+  rt_check(rt::launch(torgb_fn(stv), a, grid, kThreads, 0, stream), torgb_name(stv));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -409,8 +454,7 @@ inline int channels_at(int res) {
 
 struct Buf {
   std::string name;
-  size_t floats_per_image;
-  size_t fixed_floats = 0;     // batch-independent part (bf16 weight planes)
+  size_t bytes_per_image = 0;
 };
 enum : int { BUF_NONE = -1, BUF_X = -2, BUF_Y = -3 };
 
@@ -421,34 +465,56 @@ struct Launch {
   bool is_dwfir = false;
   Geo g;
   DwGeo dg;
-  int cin = 0, cout = 0, res_in = 0, res_out = 0;
+  int cin = 0, cout = 0, hin = 0, win = 0, hout = 0, wout = 0;
   int in_buf = BUF_NONE, out_buf = BUF_NONE, skip_buf = BUF_NONE, imgprev_buf = BUF_NONE, imgout_buf = BUF_NONE;
   int w_dw = -1, b_dw = -1, w_pw = -1, w_noise = -1, w_ns = -1, w_frgb = -1, b_frgb = -1, w_trgb = -1, b_trgb = -1;
+  long long noise_plane_off = -1;    // arbitrary-size plans: byte offset (shared region) of this layer's [hout][wout] noise plane
   double flops = 0, mfma_flops = 0, bytes = 0;
   int wgs_batch1 = 0;
-  size_t wsplit_off = 0;             // element offset of this layer's bf16 weight planes in the wsplit buffer
+  size_t wsplit_off = 0;             // element offset of this layer's 16-bit weight planes in the shared region
 };
+
+// Launch sequence + workspace layout of one forward at H x W (H = W = resolution for the reference's fixed-size forward).
+//   workspace = [ shared region: 16-bit weight planes of every 1x1 conv, noise planes of arbitrary-size plans ]
+//               [ sub-batch 0: skip tensors, ping-pong activations, dwfir scratch, RGB ping-pong ] [ sub-batch 1: the same ]
+struct Plan {
+  int H = 0, W = 0;
+  std::vector<Buf> bufs;
+  std::vector<Launch> launches;
+  std::vector<std::pair<std::string, int>> debug_tensors;   // layer name -> buffer id
+  size_t shared_bytes = 0;
+  size_t wsplit_elems = 0;
+  int stagger = 0;                   // launch index of the first sub-batch after which the second one starts
+};
+
+inline size_t align256(size_t b) { return (b + 255) / 256 * 256; }
 
 }  // namespace migan
 
 struct migan_handle {
   int resolution = 0, device = 0;
+  int stv = 0;                        // activation storage format (MIGAN_DTYPE_*)
+  int gemm = 2;                       // MIGAN_GEMM_*
+  int streams = 2;                    // 2: batches of >= 16 images run as two staggered sub-batches on two streams
+  bool static_weights = false;        // caller asserts conv2 weights are unchanged between forwards on the same workspace
   bool committed = false, debug = false;
   std::vector<migan::Slot> slots;
-  std::vector<migan::Buf> bufs;
-  std::vector<migan::Launch> launches;
-  std::vector<std::pair<std::string, int>> debug_tensors;   // layer name -> buffer id
+  migan::Plan plan;                   // H = W = resolution
+  std::vector<migan::Plan> hw_plans;  // migan_forward_hw sizes seen so far
   std::vector<rt::event_t> events;
-  int wsplit_buf = -1;
+  // two-stream execution
+  rt::stream_t aux_stream{};
+  rt::event_t ev_fork{}, ev_mid{}, ev_join{};
+  bool aux_ready = false;
+  // static weights: where and when the operand planes were last written
+  const void* prepared_ws = nullptr;
+  rt::stream_t prepared_stream{};
+  unsigned long long weight_epoch = 1, prepared_epoch = 0;
 
   int slot_index(const std::string& n) const {
     for (size_t i = 0; i < slots.size(); ++i)
       if (slots[i].name == n) return (int)i;
     return -1;
-  }
-  int add_buf(const std::string& n, size_t fpi) {
-    bufs.push_back({n, fpi});
-    return (int)bufs.size() - 1;
   }
   void add_slot(const std::string& n, std::initializer_list<int64_t> shp, bool is_buf, migan::Role role) {
     migan::Slot s;
@@ -476,10 +542,36 @@ struct migan_handle {
     }
   }
   void build_schema();
-  void build_plan();
-  size_t buf_offset_bytes(int id, int batch) const;
-  size_t workspace_bytes(int batch) const;
-  void forward(const float* x, float* y, int batch, void* ws, size_t ws_bytes, rt::stream_t stream, float* ms, int n_ms);
+  void build_plan(migan::Plan& P, int H, int W) const;
+  void rebuild() {
+    build_plan(plan, resolution, resolution);
+    hw_plans.clear();
+    prepared_epoch = 0;
+  }
+  migan::Plan& plan_for(int H, int W);
+  void split(int batch, int& n0, int& n1) const {
+    n0 = batch; n1 = 0;
+    if (streams >= 2 && !debug && batch >= 16) {
+      n0 = (batch / 2 + 7) / 8 * 8;      // whole 8-image groups (the 4x4 tiles hold 8 images)
+      n1 = batch - n0;
+    }
+  }
+  static size_t sub_offset(const migan::Plan& P, int id, int n) {
+    size_t off = 0;
+    for (int i = 0; i < id; ++i) off += migan::align256(P.bufs[i].bytes_per_image * (size_t)n);
+    return off;
+  }
+  static size_t sub_bytes(const migan::Plan& P, int n) { return sub_offset(P, (int)P.bufs.size(), n); }
+  size_t workspace_bytes(const migan::Plan& P, int batch) const {
+    int n0, n1;
+    split(batch, n0, n1);
+    return migan::align256(P.shared_bytes) + sub_bytes(P, n0) + (n1 ? sub_bytes(P, n1) : 0);
+  }
+  void ensure_aux();
+  void run_range(const migan::Plan& P, const float* x, float* y, int n, char* sub_ws, char* shared, rt::stream_t stream,
+                 bool timed, int mid_after, const migan_io_u8* u8);
+  void forward(migan::Plan& P, const float* x, float* y, int batch, void* ws, size_t ws_bytes, rt::stream_t stream, float* ms,
+               int n_ms, const migan_io_u8* u8 = nullptr);
 };
 
 namespace migan {
@@ -521,67 +613,78 @@ inline void migan_handle::build_schema() {
   }
 }
 
-inline void migan_handle::build_plan() {
+// Block "b<res>" of the reference runs at res x res; fed an H x W input (H, W multiples of resolution / 4) the same block
+// runs at (H * res / resolution) x (W * res / resolution): the network is fully convolutional except for its two fixed-size
+// constants (reference README.md:87; noise_const :149, filter_const :85), which migan_forward_hw crops / tiles.
+inline void migan_handle::build_plan(migan::Plan& P, int H, int W) const {
   using namespace migan;
-  bufs.clear();
-  launches.clear();
-  debug_tensors.clear();
+  P = Plan();
+  P.H = H; P.W = W;
   const int R = resolution;
+  const bool fixed = (H == R && W == R);
+  auto hs = [&](int res) { return (int)((long long)H * res / R); };
+  auto ws = [&](int res) { return (int)((long long)W * res / R); };
+  const size_t esz = stv == 0 ? 4 : 2;
+  auto add_buf = [&](const std::string& n, size_t bytes_per_image) {
+    P.bufs.push_back({n, bytes_per_image});
+    return (int)P.bufs.size() - 1;
+  };
   size_t max_act = 0;
-  for (int res = 4; res <= R; res *= 2) {
-    const size_t e = (size_t)res * res * channels_at(res);
-    if (e > max_act) max_act = e;
-  }
+  for (int res = 4; res <= R; res *= 2) max_act = std::max(max_act, (size_t)hs(res) * ws(res) * channels_at(res));
   std::vector<int> feat(16, BUF_NONE);
-  for (int res = R; res >= 4; res /= 2) feat[ilog2(res)] = add_buf("feat" + std::to_string(res), (size_t)res * res * channels_at(res));
+  for (int res = R; res >= 4; res /= 2) feat[ilog2(res)] = add_buf("feat" + std::to_string(res), (size_t)hs(res) * ws(res) * channels_at(res) * esz);
   size_t max_dwt = 16;
-  for (int res = R; res > 4; res /= 2) max_dwt = std::max(max_dwt, (size_t)(res / 2) * (res / 2) * channels_at(res));
-  const int DWT = add_buf("dwfir_tmp", max_dwt);
-  wsplit_buf = add_buf("wsplit", 0);
-  size_t wsplit_elems = 0;
+  for (int res = R; res > 4; res /= 2) max_dwt = std::max(max_dwt, (size_t)hs(res / 2) * ws(res / 2) * channels_at(res));
+  const int DWT = add_buf("dwfir_tmp", max_dwt * sizeof(float));      // intermediate of one SeparableConv2d: always fp32
   int P0 = BUF_NONE, P1 = BUF_NONE, I0 = BUF_NONE, I1 = BUF_NONE;
   if (!debug) {
-    P0 = add_buf("act0", max_act);
-    P1 = add_buf("act1", max_act);
-    I0 = add_buf("img0", (size_t)3 * (R / 2) * (R / 2));
-    I1 = add_buf("img1", (size_t)3 * (R / 2) * (R / 2));
+    P0 = add_buf("act0", max_act * esz);
+    P1 = add_buf("act1", max_act * esz);
+    I0 = add_buf("img0", (size_t)3 * hs(R / 2) * ws(R / 2) * sizeof(float));
+    I1 = add_buf("img1", (size_t)3 * hs(R / 2) * ws(R / 2) * sizeof(float));
   }
+  size_t noise_bytes = 0;
   auto out_for = [&](const std::string& layer, int res, int c, int pingpong) -> int {
     if (!debug) return pingpong;
-    const int id = add_buf(layer, (size_t)res * res * c);
-    return id;
+    return add_buf(layer, (size_t)hs(res) * ws(res) * c * esz);
   };
   auto add_sep = [&](const std::string& layer, int mode, int cin, int cout, int res_in, int res_out, bool fromrgb,
                      bool noise, int in_buf, int out_buf, int skip_buf, bool with_torgb = false) -> Launch& {
     Launch L;
     L.layer = layer;
-    L.g = choose_geo(mode, cin, cout, res_in, fromrgb, with_torgb);
+    L.hin = hs(res_in); L.win = ws(res_in); L.hout = hs(res_out); L.wout = ws(res_out);
+    L.g = choose_geo(mode, cin, cout, L.hin, L.win, fromrgb, with_torgb, gemm, stv);
     L.g.torgb = with_torgb && L.g.nchunks == 1;        // one workgroup owns all channels of its pixels: ToRGB fuses
     L.kernel = kernel_name(L.g);
-    L.cin = cin; L.cout = cout; L.res_in = res_in; L.res_out = res_out;
+    L.cin = cin; L.cout = cout;
     L.in_buf = in_buf; L.out_buf = out_buf; L.skip_buf = skip_buf;
     L.w_dw = slot_index(layer + ".conv1.weight");
     L.b_dw = slot_index(layer + ".conv1.bias");
     L.w_pw = slot_index(layer + ".conv2.weight");
-    L.wsplit_off = wsplit_elems + kSplitHeader;      // planes start after the 16-byte header
-    wsplit_elems += wsplit_elems_of(cin, cout);
+    L.wsplit_off = P.wsplit_elems + kSplitHeader;      // planes start after the 16-byte header
+    P.wsplit_elems += wsplit_elems_of(cin, cout);
     if (noise) {
       L.w_noise = slot_index(layer + ".noise_const");
       L.w_ns = slot_index(layer + ".noise_strength");
+      if (!fixed) {
+        L.noise_plane_off = (long long)noise_bytes;
+        noise_bytes += align256((size_t)L.hout * L.wout * sizeof(float));
+      }
     }
-    const double pin = (double)res_in * res_in, pout = (double)res_out * res_out;
+    const double pin = (double)L.hin * L.win, pout = (double)L.hout * L.wout;
     const double pgemm = (mode == MODE_UP) ? pin : pout;
+    const double e = (double)esz;
     L.mfma_flops = 2.0 * cin * cout * pgemm;
     L.flops = L.mfma_flops + 2.0 * 9 * cin * pin;
     if (mode == MODE_PW) L.flops = L.mfma_flops;     // depthwise + FIR are accounted to the dwfir launch
     if (mode == MODE_UP) L.flops += 2.0 * 4 * cout * pout;
-    L.bytes = 4.0 * ((fromrgb ? 4.0 : (double)cin) * pin + (double)cout * pout + (skip_buf != BUF_NONE ? (double)cout * pout : 0.0));
-    if (mode == MODE_PW) L.bytes = 4.0 * (double)cout * pout;   // algorithmic input read is accounted to the dwfir launch
+    L.bytes = (fromrgb ? 4.0 * 4.0 : e * cin) * pin + e * cout * pout + (skip_buf != BUF_NONE ? e * cout * pout : 0.0);
+    if (mode == MODE_PW) L.bytes = e * cout * pout;   // algorithmic input read is accounted to the dwfir launch
     if (fromrgb) L.flops += 2.0 * 4 * cin * pin;
     L.wgs_batch1 = (int)grid_of(L.g, 1);
-    launches.push_back(L);
-    if (debug) debug_tensors.push_back({layer, out_buf});
-    return launches.back();
+    P.launches.push_back(L);
+    if (debug) P.debug_tensors.push_back({layer, out_buf});
+    return P.launches.back();
   };
 
   // ---- encoder (reference :235-246, :192-200) ----
@@ -595,7 +698,7 @@ inline void migan_handle::build_plan() {
       l1.w_frgb = slot_index(b + ".fromrgb.weight");
       l1.b_frgb = slot_index(b + ".fromrgb.bias");
     }
-    if (debug) debug_tensors.back().second = feat[ilog2(res)];
+    if (debug) P.debug_tensors.back().second = feat[ilog2(res)];
     if (res > 4) {
       const int cn = channels_at(res / 2);
       // down=2 layer = depthwise+FIR kernel (writes the half-resolution cin-channel tensor) + pointwise GEMM
@@ -603,17 +706,18 @@ inline void migan_handle::build_plan() {
         Launch L;
         L.layer = b + ".conv2.dwfir";
         L.is_dwfir = true;
-        L.dg = choose_dwfir_geo(c, res);
-        L.kernel = dwfir_name(L.dg);
-        L.cin = c; L.cout = c; L.res_in = res; L.res_out = res / 2;
+        L.hin = hs(res); L.win = ws(res); L.hout = hs(res / 2); L.wout = ws(res / 2);
+        L.dg = choose_dwfir_geo(c, L.hin, L.win);
+        L.kernel = dwfir_name(L.dg, stv);
+        L.cin = c; L.cout = c;
         L.in_buf = feat[ilog2(res)]; L.out_buf = DWT;
         L.w_dw = slot_index(b + ".conv2.conv1.weight");
         L.b_dw = slot_index(b + ".conv2.conv1.bias");
-        const double pin = (double)res * res, pout = pin / 4;
+        const double pin = (double)L.hin * L.win, pout = (double)L.hout * L.wout;
         L.flops = 2.0 * 9 * c * pin + 2.0 * 16 * c * pout;
-        L.bytes = 4.0 * c * pin;
+        L.bytes = (double)esz * c * pin;
         L.wgs_batch1 = (int)dwfir_grid(L.dg, 1);
-        launches.push_back(L);
+        P.launches.push_back(L);
       }
       const int ob = out_for(b + ".conv2", res / 2, cn, P0);
       add_sep(b + ".conv2", MODE_PW, c, cn, res / 2, res / 2, false, false, DWT, ob, BUF_NONE);
@@ -637,10 +741,10 @@ inline void migan_handle::build_plan() {
     cur = o2;
     int img_out;
     if (res == R) img_out = BUF_Y;
-    else if (debug) img_out = add_buf(b + ".img", (size_t)3 * res * res);
+    else if (debug) img_out = add_buf(b + ".img", (size_t)3 * hs(res) * ws(res) * sizeof(float));
     else img_out = (img_cur == I0) ? I1 : I0;
     const int wt = slot_index(b + ".torgb.weight"), bt = slot_index(b + ".torgb.bias");
-    const double pout = (double)res * res;
+    const double pout = (double)hs(res) * ws(res);
     const double rgb_flops = 2.0 * 3 * c * pout + (img_cur != BUF_NONE ? 2.0 * 4 * 3 * pout : 0.0);
     const double rgb_bytes = 4.0 * (3.0 * pout + (img_cur != BUF_NONE ? 3.0 * pout / 4 : 0.0));
     if (l2.g.nchunks == 1) {
@@ -653,116 +757,192 @@ inline void migan_handle::build_plan() {
     } else {
       Launch L;
       L.layer = b + ".torgb";
-      L.kernel = "migan::torgb_kernel";
+      L.kernel = torgb_name(stv);
       L.is_rgb = true;
-      L.cin = c; L.cout = 3; L.res_in = res; L.res_out = res;
+      L.cin = c; L.cout = 3;
+      L.hin = L.hout = hs(res); L.win = L.wout = ws(res);
       L.in_buf = o2; L.imgprev_buf = img_cur; L.imgout_buf = img_out;
       L.w_trgb = wt; L.b_trgb = bt;
       L.flops = rgb_flops; L.bytes = rgb_bytes;
-      L.wgs_batch1 = (int)(((size_t)res * res * 16 + kThreads - 1) / kThreads);
-      launches.push_back(L);
+      L.wgs_batch1 = (int)(((size_t)hs(res) * ws(res) * 16 + kThreads - 1) / kThreads);
+      P.launches.push_back(L);
     }
-    if (debug && res != R) debug_tensors.push_back({b + ".img", img_out});
+    if (debug && res != R) P.debug_tensors.push_back({b + ".img", img_out});
     img_cur = img_out;
   }
-  bufs[wsplit_buf].fixed_floats = (wsplit_elems * sizeof(unsigned short) + 3) / 4 + 64;
-}
-
-inline size_t migan_handle::buf_offset_bytes(int id, int batch) const {
-  size_t off = 0;
-  for (int i = 0; i < id; ++i) {
-    const size_t b = (bufs[i].floats_per_image * (size_t)batch + bufs[i].fixed_floats) * sizeof(float);
-    off += (b + 255) / 256 * 256;
+  // shared region: [16-bit weight planes][noise planes]
+  const size_t wbytes = align256(P.wsplit_elems * sizeof(unsigned short) + 256);
+  for (Launch& L : P.launches)
+    if (L.noise_plane_off >= 0) L.noise_plane_off += (long long)wbytes;
+  P.shared_bytes = wbytes + noise_bytes;
+  // second sub-batch starts once the first one is through its first three 512-class layers' worth of work: by default
+  // after ~30 % of the launches' algorithmic bytes, so the small-resolution middle of one half overlaps big layers of the other
+  {
+    double total = 0, acc = 0;
+    for (const Launch& L : P.launches) total += L.bytes;
+    P.stagger = 0;
+    for (size_t i = 0; i < P.launches.size(); ++i) {
+      acc += P.launches[i].bytes;
+      if (acc >= 0.30 * total) { P.stagger = (int)i; break; }
+    }
+    if (tuning().stagger >= 0) P.stagger = std::min((int)P.launches.size() - 1, tuning().stagger);
   }
-  return off;
 }
-inline size_t migan_handle::workspace_bytes(int batch) const { return buf_offset_bytes((int)bufs.size(), batch); }
 
-inline void migan_handle::forward(const float* x, float* y, int batch, void* ws, size_t ws_bytes, rt::stream_t stream,
-                                  float* ms, int n_ms) {
+inline migan::Plan& migan_handle::plan_for(int H, int W) {
+  if (H == resolution && W == resolution) return plan;
+  for (auto& P : hw_plans)
+    if (P.H == H && P.W == W) return P;
+  hw_plans.emplace_back();
+  build_plan(hw_plans.back(), H, W);
+  return hw_plans.back();
+}
+
+inline void migan_handle::ensure_aux() {
+  if (aux_ready) return;
+  migan::rt_check(rt::stream_create(&aux_stream), "hipStreamCreate");
+  migan::rt_check(rt::event_create_sync(&ev_fork), "hipEventCreate");
+  migan::rt_check(rt::event_create_sync(&ev_mid), "hipEventCreate");
+  migan::rt_check(rt::event_create_sync(&ev_join), "hipEventCreate");
+  aux_ready = true;
+}
+
+// launches of one sub-batch of n images on `stream`
+inline void migan_handle::run_range(const migan::Plan& P, const float* x, float* y, int n, char* sub_ws, char* shared,
+                                    rt::stream_t stream, bool timed, int mid_after, const migan_io_u8* u8) {
+  using namespace migan;
+  std::vector<size_t> offs(P.bufs.size());
+  for (size_t i = 0; i < P.bufs.size(); ++i) offs[i] = sub_offset(P, (int)i, n);
+  auto bptr = [&](int id) -> void* {
+    if (id == BUF_NONE) return nullptr;
+    if (id == BUF_X) return const_cast<float*>(x);
+    if (id == BUF_Y) return y;
+    return sub_ws + offs[id];
+  };
+  auto wptr = [&](int s) -> const float* { return s < 0 ? nullptr : slots[s].ptr; };
+  unsigned short* wsplit = reinterpret_cast<unsigned short*>(shared);
+  for (size_t li = 0; li < P.launches.size(); ++li) {
+    const Launch& L = P.launches[li];
+    if (timed) rt_check(rt::event_record(events[2 * li], stream), "hipEventRecord");
+    if (L.is_dwfir) {
+      DwFirArgs a{};
+      a.x = bptr(L.in_buf); a.y = (float*)bptr(L.out_buf); a.wdw = wptr(L.w_dw); a.bdw = wptr(L.b_dw);
+      a.B = n; a.H = L.hin; a.W = L.win; a.C = L.cin;
+      launch_dwfir(L.dg, a, stream, stv);
+    } else if (L.is_rgb) {
+      RgbArgs a{};
+      a.x = bptr(L.in_buf); a.w = wptr(L.w_trgb); a.b = wptr(L.b_trgb);
+      a.img_prev = (const float*)bptr(L.imgprev_buf); a.img_out = (float*)bptr(L.imgout_buf);
+      a.B = n; a.H = L.hout; a.W = L.wout; a.C = L.cin;
+      if (u8 && L.imgout_buf == BUF_Y) { a.u8_img = (const unsigned char*)u8->img; a.u8_mask = (const unsigned char*)u8->mask; a.u8_out = (unsigned char*)u8->out; }
+      launch_torgb(a, stream, stv);
+    } else {
+      SepArgs a{};
+      a.x = bptr(L.in_buf); a.y = bptr(L.out_buf); a.skip = bptr(L.skip_buf);
+      a.wdw = wptr(L.w_dw); a.bdw = wptr(L.b_dw); a.wpw = wptr(L.w_pw);
+      a.wsplit = L.g.gemmv ? wsplit + L.wsplit_off : nullptr;
+      a.noise = L.noise_plane_off >= 0 ? reinterpret_cast<const float*>(shared + L.noise_plane_off) : wptr(L.w_noise);
+      a.noise_strength = wptr(L.w_ns);
+      a.frgb_w = wptr(L.w_frgb); a.frgb_b = wptr(L.b_frgb);
+      a.trgb_w = wptr(L.w_trgb); a.trgb_b = wptr(L.b_trgb);
+      a.img_prev = (const float*)bptr(L.imgprev_buf); a.img_out = (float*)bptr(L.imgout_buf);
+      if (u8 && L.in_buf == BUF_X) { a.u8_img = (const unsigned char*)u8->img; a.u8_mask = (const unsigned char*)u8->mask; }
+      if (u8 && L.imgout_buf == BUF_Y && a.trgb_w) {
+        a.u8_img = (const unsigned char*)u8->img; a.u8_mask = (const unsigned char*)u8->mask; a.u8_out = (unsigned char*)u8->out;
+      }
+      a.B = n; a.H = L.hin; a.W = L.win; a.CI = L.cin; a.CO = L.cout; a.HO = L.hout; a.WO = L.wout;
+      fill_geo(a, L.g);
+      launch_sepconv(L.g, a, stream);
+      Geo gl = L.g;
+      gl.persist = use_persistent(gl, n, a.trgb_w != nullptr);
+      gl.torgb = a.trgb_w != nullptr;
+      L.kernel_last = kernel_name(gl);
+    }
+    if (timed) rt_check(rt::event_record(events[2 * li + 1], stream), "hipEventRecord");
+    if (!timed && (int)li == mid_after) rt_check(rt::event_record(ev_mid, stream), "hipEventRecord");
+#ifdef MIGAN_PHASE_PROF
+    if (timed) {
+      prof_layers().resize(P.launches.size());
+      rt_check(rt::prof_read(prof_buffer(), prof_layers()[li].v, 16, true), "prof read");
+    }
+#endif
+  }
+}
+
+inline void migan_handle::forward(migan::Plan& P, const float* x, float* y, int batch, void* ws, size_t ws_bytes,
+                                  rt::stream_t stream, float* ms, int n_ms, const migan_io_u8* u8) {
   using namespace migan;
   MIGAN_CHECK(committed, MIGAN_ESTATE, "migan_forward before migan_commit");
-  MIGAN_CHECK(x && y && batch > 0, MIGAN_EINVAL, "null tensor or empty batch");
-  MIGAN_CHECK(ws_bytes >= workspace_bytes(batch), MIGAN_EINVAL, "workspace too small for this batch");
+  MIGAN_CHECK((x || u8) && (y || u8) && batch > 0, MIGAN_EINVAL, "null tensor or empty batch");
   MIGAN_CHECK(ws != nullptr, MIGAN_EINVAL, "null workspace");
+  MIGAN_CHECK(ws_bytes >= workspace_bytes(P, batch), MIGAN_EINVAL, "workspace too small for this batch");
+  DeviceGuard guard(device);
   const bool timed = ms != nullptr;
   if (timed) {
-    MIGAN_CHECK(n_ms >= (int)launches.size(), MIGAN_EINVAL, "layer_ms array too small");
-    while (events.size() < 2 * launches.size()) {
+    MIGAN_CHECK(n_ms >= (int)P.launches.size(), MIGAN_EINVAL, "layer_ms array too small");
+    while (events.size() < 2 * P.launches.size()) {
       rt::event_t e;
       rt_check(rt::event_create(&e), "hipEventCreate");
       events.push_back(e);
     }
   }
-  std::vector<size_t> offs(bufs.size());
-  for (size_t i = 0; i < bufs.size(); ++i) offs[i] = buf_offset_bytes((int)i, batch);
-  auto bptr = [&](int id) -> float* {
-    if (id == BUF_NONE) return nullptr;
-    if (id == BUF_X) return const_cast<float*>(x);
-    if (id == BUF_Y) return y;
-    return reinterpret_cast<float*>(static_cast<char*>(ws) + offs[id]);
-  };
-  auto wptr = [&](int s) -> const float* { return s < 0 ? nullptr : slots[s].ptr; };
-  unsigned short* wsplit = reinterpret_cast<unsigned short*>(static_cast<char*>(ws) + offs[wsplit_buf]);
-  if (tuning().gemm) {
-    // conv2.weight of every layer -> 16-bit operand planes (one launch; the weights are read in place every forward,
-    // so in-place parameter updates are always picked up)
+  char* shared = static_cast<char*>(ws);
+  char* sub0 = shared + align256(P.shared_bytes);
+  // conv2.weight of every layer -> 16-bit operand planes.  Re-done every forward (the weights are read in place, so
+  // in-place parameter updates are always picked up) unless the caller asserted static weights and these planes were
+  // written, in this workspace and stream order, since the last (re)binding of a weight.
+  const bool planes_valid = static_weights && prepared_ws == ws && prepared_epoch == weight_epoch && prepared_stream == stream;
+  if (gemm && !planes_valid) {
     SplitArgs sa{};
-    sa.dst = wsplit;
-    sa.f16 = tuning().gemm == 2;
-    for (const Launch& L : launches) {
+    sa.dst = reinterpret_cast<unsigned short*>(shared);
+    sa.f16 = gemm == 2;
+    for (const Launch& L : P.launches) {
       if (L.is_rgb || L.is_dwfir) continue;
       MIGAN_CHECK(sa.n < 40, MIGAN_EINVAL, "internal: too many layers for the weight-split table");
-      sa.src[sa.n] = wptr(L.w_pw);
+      sa.src[sa.n] = slots[L.w_pw].ptr;
       sa.dst_off[sa.n] = L.wsplit_off;
       sa.count[sa.n] = (unsigned)(L.cin * L.cout);
       sa.ci[sa.n] = (unsigned)L.cin;
       ++sa.n;
     }
     launch_split(sa, stream);
+    prepared_ws = ws; prepared_epoch = weight_epoch; prepared_stream = stream;     // only reached when every launch succeeded
   }
-  for (size_t li = 0; li < launches.size(); ++li) {
-    const Launch& L = launches[li];
-    if (timed) rt_check(rt::event_record(events[2 * li], stream), "hipEventRecord");
-    if (L.is_dwfir) {
-      DwFirArgs a{};
-      a.x = bptr(L.in_buf); a.y = bptr(L.out_buf); a.wdw = wptr(L.w_dw); a.bdw = wptr(L.b_dw);
-      a.B = batch; a.H = L.res_in; a.W = L.res_in; a.C = L.cin;
-      launch_dwfir(L.dg, a, stream);
-    } else if (L.is_rgb) {
-      RgbArgs a{};
-      a.x = bptr(L.in_buf); a.w = wptr(L.w_trgb); a.b = wptr(L.b_trgb);
-      a.img_prev = bptr(L.imgprev_buf); a.img_out = bptr(L.imgout_buf);
-      a.B = batch; a.H = L.res_out; a.W = L.res_out; a.C = L.cin;
-      launch_torgb(a, stream);
-    } else {
-      SepArgs a{};
-      a.x = bptr(L.in_buf); a.y = bptr(L.out_buf); a.skip = bptr(L.skip_buf);
-      a.wdw = wptr(L.w_dw); a.bdw = wptr(L.b_dw); a.wpw = wptr(L.w_pw);
-      a.wsplit = L.g.gemmv ? wsplit + L.wsplit_off : nullptr;
-      a.noise = wptr(L.w_noise); a.noise_strength = wptr(L.w_ns);
-      a.frgb_w = wptr(L.w_frgb); a.frgb_b = wptr(L.b_frgb);
-      a.trgb_w = wptr(L.w_trgb); a.trgb_b = wptr(L.b_trgb);
-      a.img_prev = bptr(L.imgprev_buf); a.img_out = bptr(L.imgout_buf);
-      a.B = batch; a.H = L.res_in; a.W = L.res_in; a.CI = L.cin; a.CO = L.cout; a.HO = L.res_out; a.WO = L.res_out;
-      fill_geo(a, L.g);
-      launch_sepconv(L.g, a, stream);
-      Geo gl = L.g;
-      gl.persist = use_persistent(gl, batch, a.trgb_w != nullptr);
-      gl.torgb = a.trgb_w != nullptr;
-      L.kernel_last = kernel_name(gl);
+  // arbitrary-size plans: crop / tile every noise_const to its layer's plane
+  for (const Launch& L : P.launches) {
+    if (L.noise_plane_off < 0) continue;
+    NoiseArgs na{};
+    na.src = slots[L.w_noise].ptr;
+    na.dst = reinterpret_cast<float*>(shared + L.noise_plane_off);
+    na.r = (int)slots[L.w_noise].shape[0]; na.h = L.hout; na.w = L.wout;
+    rt_check(rt::launch(noise_plane_kernel, na, (unsigned)cdiv(L.hout * L.wout, kThreads), kThreads, 0, stream), "migan::noise_plane_kernel");
+  }
+  int n0, n1;
+  split(batch, n0, n1);
+  if (timed) { n0 = batch; n1 = 0; }     // per-launch durations: one stream, whole-batch launches (the split workspace always fits them)
+  const size_t in_img = (size_t)4 * P.H * P.W, out_img = (size_t)3 * P.H * P.W;
+  if (n1 > 0) {
+    // two staggered sub-batches on two streams: the second half starts when the first is `stagger` launches in, so the
+    // small-resolution layers of one half (a few dozen workgroups each) run beside full-size layers of the other
+    ensure_aux();
+    migan_io_u8 u1{};
+    if (u8) {
+      u1.img = (const unsigned char*)u8->img + (size_t)n0 * P.H * P.W * 3;
+      u1.mask = (const unsigned char*)u8->mask + (size_t)n0 * P.H * P.W;
+      u1.out = (unsigned char*)u8->out + (size_t)n0 * P.H * P.W * 3;
     }
-    if (timed) rt_check(rt::event_record(events[2 * li + 1], stream), "hipEventRecord");
-#ifdef MIGAN_PHASE_PROF
-    if (timed) {
-      prof_layers().resize(launches.size());
-      rt_check(rt::prof_read(prof_buffer(), prof_layers()[li].v, 16, true), "prof read");
-    }
-#endif
+    run_range(P, x, y, n0, sub0, shared, stream, false, P.stagger, u8);
+    rt_check(rt::stream_wait_event(aux_stream, ev_mid), "hipStreamWaitEvent");
+    run_range(P, x ? x + (size_t)n0 * in_img : nullptr, y ? y + (size_t)n0 * out_img : nullptr, n1, sub0 + sub_bytes(P, n0), shared,
+              aux_stream, false, -1, u8 ? &u1 : nullptr);
+    rt_check(rt::event_record(ev_join, aux_stream), "hipEventRecord");
+    rt_check(rt::stream_wait_event(stream, ev_join), "hipStreamWaitEvent");
+  } else {
+    run_range(P, x, y, n0, sub0, shared, stream, timed, -1, u8);
   }
   if (timed) {
     rt_check(rt::stream_sync(stream), "hipStreamSynchronize");
-    for (size_t li = 0; li < launches.size(); ++li)
+    for (size_t li = 0; li < P.launches.size(); ++li)
       rt_check(rt::event_elapsed(&ms[li], events[2 * li], events[2 * li + 1]), "hipEventElapsedTime");
   }
 }
@@ -793,14 +973,23 @@ int migan_create(int resolution, int dtype, int device, migan_handle** out) {
   MIGAN_CHECK(resolution > 0 && (resolution & (resolution - 1)) == 0, MIGAN_EINVAL,
               "resolution must be a power of two (reference migan_inference.py:215-216)");
   MIGAN_CHECK(resolution >= 8 && resolution <= 512, MIGAN_EINVAL, "resolution must be in [8, 512]");
-  MIGAN_CHECK(dtype == MIGAN_DTYPE_F32, MIGAN_EINVAL, "only MIGAN_DTYPE_F32 is implemented");
-  rt_check(rt::set_device(device), "hipSetDevice");
+  MIGAN_CHECK(dtype == MIGAN_DTYPE_F32 || dtype == MIGAN_DTYPE_BF16 || dtype == MIGAN_DTYPE_F16, MIGAN_EINVAL,
+              "dtype must be MIGAN_DTYPE_F32, MIGAN_DTYPE_BF16 or MIGAN_DTYPE_F16 (activation storage format)");
+  DeviceGuard guard(device);
   prepare_kernels();
   migan_handle* h = new migan_handle();
   h->resolution = resolution;
   h->device = device;
+  h->stv = dtype;
+  h->gemm = dtype == MIGAN_DTYPE_F32 ? tuning().gemm : MIGAN_GEMM_F16X2;
+  h->streams = tuning().streams;
   h->build_schema();
-  h->build_plan();
+  try {
+    h->rebuild();
+  } catch (...) {
+    delete h;
+    throw;
+  }
   *out = h;
   MIGAN_API_END
 }
@@ -808,9 +997,50 @@ int migan_create(int resolution, int dtype, int device, migan_handle** out) {
 int migan_destroy(migan_handle* h) {
   MIGAN_API_BEGIN
   if (h) {
+    migan::DeviceGuard guard(h->device);
     for (auto& e : h->events) rt::event_destroy(e);
+    if (h->aux_ready) {
+      rt::event_destroy(h->ev_fork);
+      rt::event_destroy(h->ev_mid);
+      rt::event_destroy(h->ev_join);
+      rt::stream_destroy(h->aux_stream);
+    }
     delete h;
   }
+  MIGAN_API_END
+}
+
+int migan_set_gemm(migan_handle* h, int variant) {
+  MIGAN_API_BEGIN
+  MIGAN_CHECK(h, MIGAN_EINVAL, "null handle");
+  MIGAN_CHECK(variant == MIGAN_GEMM_F32 || variant == MIGAN_GEMM_BF16X3 || variant == MIGAN_GEMM_F16X2, MIGAN_EINVAL, "unknown GEMM variant");
+  MIGAN_CHECK(h->stv == MIGAN_DTYPE_F32 || variant == MIGAN_GEMM_F16X2, MIGAN_EINVAL,
+              "16-bit activation storage runs on the f16x2 GEMM variant only");
+  h->gemm = variant;
+  h->rebuild();
+  MIGAN_API_END
+}
+
+int migan_get_gemm(const migan_handle* h, int* variant) {
+  MIGAN_API_BEGIN
+  MIGAN_CHECK(h && variant, MIGAN_EINVAL, "null argument");
+  *variant = h->gemm;
+  MIGAN_API_END
+}
+
+int migan_assume_static_weights(migan_handle* h, int on) {
+  MIGAN_API_BEGIN
+  MIGAN_CHECK(h, MIGAN_EINVAL, "null handle");
+  h->static_weights = on != 0;
+  h->prepared_epoch = 0;          // the next forward prepares the planes once more, then keeps them
+  MIGAN_API_END
+}
+
+int migan_set_streams(migan_handle* h, int streams) {
+  MIGAN_API_BEGIN
+  MIGAN_CHECK(h, MIGAN_EINVAL, "null handle");
+  MIGAN_CHECK(streams == 1 || streams == 2, MIGAN_EINVAL, "streams must be 1 or 2");
+  h->streams = streams;
   MIGAN_API_END
 }
 
@@ -847,6 +1077,7 @@ int migan_set_weight(migan_handle* h, const char* name, const void* dev_ptr, con
               std::string("tensor must be 16-byte aligned: ") + name);
   s.ptr = static_cast<const float*>(dev_ptr);
   h->committed = false;
+  ++h->weight_epoch;              // (re)bound weights: operand planes prepared earlier are stale
   MIGAN_API_END
 }
 
@@ -854,7 +1085,8 @@ int migan_commit(migan_handle* h, void* stream) {
   MIGAN_API_BEGIN
   using namespace migan;
   MIGAN_CHECK(h, MIGAN_EINVAL, "null handle");
-  rt_check(rt::set_device(h->device), "hipSetDevice");
+  DeviceGuard guard(h->device);
+  ++h->weight_epoch;
   for (const auto& s : h->slots) MIGAN_CHECK(s.ptr != nullptr, MIGAN_ESTATE, std::string("missing key in state_dict: ") + s.name);
   std::vector<float> host;
   static const double taps[4] = {1.0, 3.0, 3.0, 1.0};
@@ -888,14 +1120,14 @@ int migan_commit(migan_handle* h, void* stream) {
 int migan_workspace_bytes(const migan_handle* h, int batch, size_t* bytes) {
   MIGAN_API_BEGIN
   MIGAN_CHECK(h && bytes && batch > 0, MIGAN_EINVAL, "bad argument");
-  *bytes = h->workspace_bytes(batch);
+  *bytes = h->workspace_bytes(h->plan, batch);
   MIGAN_API_END
 }
 
 int migan_forward(migan_handle* h, const void* x, void* y, int batch, void* ws, size_t ws_bytes, void* stream) {
   MIGAN_API_BEGIN
   MIGAN_CHECK(h, MIGAN_EINVAL, "null handle");
-  h->forward(static_cast<const float*>(x), static_cast<float*>(y), batch, ws, ws_bytes, (rt::stream_t)stream, nullptr, 0);
+  h->forward(h->plan, static_cast<const float*>(x), static_cast<float*>(y), batch, ws, ws_bytes, (rt::stream_t)stream, nullptr, 0);
   MIGAN_API_END
 }
 
@@ -903,14 +1135,50 @@ int migan_forward_timed(migan_handle* h, const void* x, void* y, int batch, void
                         float* layer_ms, int n_layer_ms) {
   MIGAN_API_BEGIN
   MIGAN_CHECK(h && layer_ms, MIGAN_EINVAL, "null argument");
-  h->forward(static_cast<const float*>(x), static_cast<float*>(y), batch, ws, ws_bytes, (rt::stream_t)stream, layer_ms, n_layer_ms);
+  h->forward(h->plan, static_cast<const float*>(x), static_cast<float*>(y), batch, ws, ws_bytes, (rt::stream_t)stream, layer_ms, n_layer_ms);
+  MIGAN_API_END
+}
+
+// fully convolutional forward
+static void migan_check_hw(const migan_handle* h, int height, int width) {
+  const int q = h->resolution / 4;
+  MIGAN_CHECK(height >= q && width >= q && height % q == 0 && width % q == 0, MIGAN_EINVAL,
+              "height and width must be positive multiples of resolution / 4 (the network halves its input log2(resolution) - 2 times)");
+  MIGAN_CHECK((long long)height * width <= 4096ll * 4096ll, MIGAN_EINVAL, "image too large");
+}
+int migan_workspace_bytes_hw(migan_handle* h, int batch, int height, int width, size_t* bytes) {
+  MIGAN_API_BEGIN
+  MIGAN_CHECK(h && bytes && batch > 0, MIGAN_EINVAL, "bad argument");
+  migan_check_hw(h, height, width);
+  *bytes = h->workspace_bytes(h->plan_for(height, width), batch);
+  MIGAN_API_END
+}
+int migan_forward_hw(migan_handle* h, const void* x, void* y, int batch, int height, int width, void* ws, size_t ws_bytes, void* stream) {
+  MIGAN_API_BEGIN
+  MIGAN_CHECK(h, MIGAN_EINVAL, "null handle");
+  migan_check_hw(h, height, width);
+  h->forward(h->plan_for(height, width), static_cast<const float*>(x), static_cast<float*>(y), batch, ws, ws_bytes, (rt::stream_t)stream,
+             nullptr, 0);
+  MIGAN_API_END
+}
+
+// uint8 in, uint8 out: demo.py's preprocess() fused into the first layer's tile builder, its postprocess + compose fused
+// into the last ToRGB epilogue
+int migan_forward_u8(migan_handle* h, const void* img_hwc_u8, const void* mask_u8, void* out_hwc_u8, int batch, void* ws, size_t ws_bytes,
+                     void* stream) {
+  MIGAN_API_BEGIN
+  MIGAN_CHECK(h && img_hwc_u8 && mask_u8 && out_hwc_u8, MIGAN_EINVAL, "null argument");
+  MIGAN_CHECK(((uintptr_t)img_hwc_u8 % 4) == 0 && ((uintptr_t)mask_u8 % 4) == 0 && ((uintptr_t)out_hwc_u8 % 4) == 0, MIGAN_EINVAL,
+              "uint8 tensors must be 4-byte aligned");
+  migan_io_u8 io{img_hwc_u8, mask_u8, out_hwc_u8};
+  h->forward(h->plan, nullptr, nullptr, batch, ws, ws_bytes, (rt::stream_t)stream, nullptr, 0, &io);
   MIGAN_API_END
 }
 
 int migan_num_launches(const migan_handle* h, int* n) {
   MIGAN_API_BEGIN
   MIGAN_CHECK(h && n, MIGAN_EINVAL, "null argument");
-  *n = (int)h->launches.size();
+  *n = (int)h->plan.launches.size();
   MIGAN_API_END
 }
 
@@ -918,8 +1186,8 @@ int migan_launch_info(const migan_handle* h, int index, const char** layer, cons
                       double* mfma_flops, double* bytes, int* wgs) {
   MIGAN_API_BEGIN
   MIGAN_CHECK(h, MIGAN_EINVAL, "null handle");
-  MIGAN_CHECK(index >= 0 && index < (int)h->launches.size(), MIGAN_EINVAL, "launch index out of range");
-  const migan::Launch& L = h->launches[index];
+  MIGAN_CHECK(index >= 0 && index < (int)h->plan.launches.size(), MIGAN_EINVAL, "launch index out of range");
+  const migan::Launch& L = h->plan.launches[index];
   if (layer) *layer = L.layer.c_str();
   if (kernel) *kernel = L.kernel_last.empty() ? L.kernel.c_str() : L.kernel_last.c_str();
   if (flops) *flops = L.flops;
@@ -933,7 +1201,7 @@ int migan_set_debug(migan_handle* h, int keep) {
   MIGAN_API_BEGIN
   MIGAN_CHECK(h, MIGAN_EINVAL, "null handle");
   h->debug = keep != 0;
-  h->build_plan();
+  h->rebuild();
   MIGAN_API_END
 }
 
@@ -941,16 +1209,17 @@ int migan_debug_tensor(const migan_handle* h, int batch, const char* layer, size
   MIGAN_API_BEGIN
   MIGAN_CHECK(h && layer && byte_offset && shape, MIGAN_EINVAL, "null argument");
   MIGAN_CHECK(h->debug, MIGAN_ESTATE, "migan_set_debug(h, 1) first");
-  for (const auto& kv : h->debug_tensors) {
+  const migan::Plan& P = h->plan;
+  for (const auto& kv : P.debug_tensors) {
     if (kv.first != layer) continue;
-    *byte_offset = h->buf_offset_bytes(kv.second, batch);
+    *byte_offset = migan::align256(P.shared_bytes) + migan_handle::sub_offset(P, kv.second, batch);     // debug plans never split the batch
     const std::string& n = kv.first;
     const bool is_img = n.size() > 4 && n.compare(n.size() - 4, 4, ".img") == 0;
-    for (const auto& L : h->launches) {
+    for (const auto& L : P.launches) {
       if (is_img) {
-        if (L.imgout_buf == kv.second) { shape[0] = batch; shape[1] = 3; shape[2] = L.res_out; shape[3] = L.res_out; return MIGAN_OK; }
+        if (L.imgout_buf == kv.second) { shape[0] = batch; shape[1] = 3; shape[2] = L.hout; shape[3] = L.wout; return MIGAN_OK; }
       } else if (!L.is_rgb && !L.is_dwfir && L.layer == n) {
-        shape[0] = batch; shape[1] = L.res_out; shape[2] = L.res_out; shape[3] = L.cout;
+        shape[0] = batch; shape[1] = L.hout; shape[2] = L.wout; shape[3] = L.cout;
         return MIGAN_OK;
       }
     }
@@ -967,29 +1236,38 @@ int migan_sepconv_forward(const migan_sepconv_desc* d, void* stream) {
   MIGAN_CHECK((d->down == 1 || d->down == 2) && (d->up == 1 || d->up == 2) && !(d->down == 2 && d->up == 2), MIGAN_EINVAL,
               "down/up must be 1 or 2 and not both 2");
   MIGAN_CHECK(d->batch > 0, MIGAN_EINVAL, "empty batch");
-  const int res_out = d->down == 2 ? d->res_in / 2 : (d->up == 2 ? d->res_in * 2 : d->res_in);
+  MIGAN_CHECK(d->dtype >= 0 && d->dtype <= 2, MIGAN_EINVAL, "dtype must be a MIGAN_DTYPE_* value");
+  const int stv = d->dtype;
+  const int h_in = d->res_in, w_in = d->width_in > 0 ? d->width_in : d->res_in;
+  MIGAN_CHECK(d->down == 1 || (h_in % 2 == 0 && w_in % 2 == 0), MIGAN_EINVAL, "down=2 needs even sizes");
+  const int h_out = d->down == 2 ? h_in / 2 : (d->up == 2 ? h_in * 2 : h_in);
+  const int w_out = d->down == 2 ? w_in / 2 : (d->up == 2 ? w_in * 2 : w_in);
   MIGAN_CHECK(d->noise_const == nullptr || d->noise_strength != nullptr, MIGAN_EINVAL, "noise_const without noise_strength");
-  const float* gemm_in = (const float*)d->x;
-  int mode = d->up == 2 ? MODE_UP : MODE_NORMAL, gemm_res = d->res_in;
+  const void* gemm_in = d->x;
+  int mode = d->up == 2 ? MODE_UP : MODE_NORMAL, gemm_h = h_in, gemm_w = w_in;
   if (d->down == 2) {
     // reference :155-161: depthwise+act+FIR at res_in (dwfir kernel), then the 1x1 at res_in/2
     MIGAN_CHECK(d->fromrgb_weight == nullptr, MIGAN_EINVAL, "fromrgb is only fused into plain layers");
-    const size_t need = (size_t)d->batch * res_out * res_out * d->cin * sizeof(float);
+    const size_t need = (size_t)d->batch * h_out * w_out * d->cin * sizeof(float);
     MIGAN_CHECK(d->scratch != nullptr && d->scratch_bytes >= need, MIGAN_EINVAL,
                 "down=2 needs scratch of batch*(res_in/2)^2*cin floats");
-    const DwGeo dg = choose_dwfir_geo(d->cin, d->res_in);
+    const DwGeo dg = choose_dwfir_geo(d->cin, h_in, w_in);
     DwFirArgs fa{};
-    fa.x = (const float*)d->x; fa.y = (float*)d->scratch; fa.wdw = (const float*)d->conv1_weight; fa.bdw = (const float*)d->conv1_bias;
-    fa.B = d->batch; fa.H = d->res_in; fa.W = d->res_in; fa.C = d->cin;
-    launch_dwfir(dg, fa, (rt::stream_t)stream);
-    gemm_in = (const float*)d->scratch;
+    fa.x = d->x; fa.y = (float*)d->scratch; fa.wdw = (const float*)d->conv1_weight; fa.bdw = (const float*)d->conv1_bias;
+    fa.B = d->batch; fa.H = h_in; fa.W = w_in; fa.C = d->cin;
+    launch_dwfir(dg, fa, (rt::stream_t)stream, stv);
+    gemm_in = d->scratch;
     mode = MODE_PW;
-    gemm_res = res_out;
+    gemm_h = h_out; gemm_w = w_out;
   }
-  // bf16x3-split GEMM needs room for the three bf16 weight planes; without it the exact fp32 MFMA path runs
+  // split GEMM variants need room for the 16-bit weight planes; without it the exact fp32 MFMA path runs
   const size_t wsplit_need = wsplit_elems_of(d->cin, d->cout) * sizeof(unsigned short);
-  const int gemmv = (d->wsplit != nullptr && d->wsplit_bytes >= wsplit_need) ? tuning().gemm : 0;
-  const Geo g = choose_geo(mode, d->cin, d->cout, gemm_res, d->fromrgb_weight != nullptr, d->torgb_weight != nullptr, gemmv);
+  const int want = stv != 0 ? 2 : (d->gemm >= 0 ? d->gemm : tuning().gemm);
+  MIGAN_CHECK(want >= 0 && want <= 2, MIGAN_EINVAL, "unknown GEMM variant");
+  const bool have_planes = d->wsplit != nullptr && d->wsplit_bytes >= wsplit_need;
+  MIGAN_CHECK(stv == 0 || have_planes, MIGAN_EINVAL, "16-bit activation storage needs the wsplit buffer (f16x2 GEMM)");
+  const int gemmv = have_planes ? want : 0;
+  const Geo g = choose_geo(mode, d->cin, d->cout, gemm_h, gemm_w, d->fromrgb_weight != nullptr, d->torgb_weight != nullptr, gemmv, stv);
   if (gemmv) {
     SplitArgs sa{};
     sa.dst = (unsigned short*)d->wsplit;
@@ -998,16 +1276,16 @@ int migan_sepconv_forward(const migan_sepconv_desc* d, void* stream) {
     launch_split(sa, (rt::stream_t)stream);
   }
   MIGAN_CHECK(d->torgb_weight == nullptr || (g.nchunks == 1 && mode != MODE_UP && d->img_out), MIGAN_EINVAL,
-              "fused ToRGB needs cout <= 128 (or 256 at >= 16x16), up == 1 and img_out");
+              "fused ToRGB needs cout <= 128 (or 256 on whole 8x16 tiles), up == 1 and img_out");
   SepArgs a{};
-  a.x = gemm_in; a.y = (float*)d->y; a.skip = (const float*)d->skip;
+  a.x = gemm_in; a.y = d->y; a.skip = d->skip;
   a.wdw = (const float*)d->conv1_weight; a.bdw = (const float*)d->conv1_bias; a.wpw = (const float*)d->conv2_weight;
   a.wsplit = gemmv ? (const unsigned short*)d->wsplit + kSplitHeader : nullptr;
   a.noise = (const float*)d->noise_const; a.noise_strength = (const float*)d->noise_strength;
   a.frgb_w = (const float*)d->fromrgb_weight; a.frgb_b = (const float*)d->fromrgb_bias;
   a.trgb_w = (const float*)d->torgb_weight; a.trgb_b = (const float*)d->torgb_bias;
   a.img_prev = (const float*)d->img_prev; a.img_out = (float*)d->img_out;
-  a.B = d->batch; a.H = gemm_res; a.W = gemm_res; a.CI = d->cin; a.CO = d->cout; a.HO = res_out; a.WO = res_out;
+  a.B = d->batch; a.H = gemm_h; a.W = gemm_w; a.CI = d->cin; a.CO = d->cout; a.HO = h_out; a.WO = w_out;
   fill_geo(a, g);
   launch_sepconv(g, a, (rt::stream_t)stream);
   MIGAN_API_END
@@ -1064,6 +1342,6 @@ const char* migan_gemm_variant(void) {
   const int g = migan::tuning().gemm;
   return g == 2 ? "f16x2" : (g == 1 ? "bf16x3" : "f32");
 }
-int migan_version(void) { return 1; }
+int migan_version(void) { return 2; }
 
 }  // extern "C"

@@ -33,6 +33,7 @@ namespace migan {
 
 typedef float f4 __attribute__((ext_vector_type(4)));
 typedef float f16v __attribute__((ext_vector_type(16)));
+typedef unsigned u2v __attribute__((ext_vector_type(2)));
 
 constexpr int kThreads = 256;          // 4 wave64 per workgroup, one per SIMD
 
@@ -42,9 +43,11 @@ struct FalseT { static constexpr bool value = false; };
 
 struct SepArgs {
   // activations
-  const float* x;              // NHWC [B][H][W][CI]  (FROMRGB: network input, NCHW [B][4][H][W])
-  float* y;                    // NHWC [B][HO][WO][CO]
-  const float* skip;           // NHWC like y, added after the activation, or null
+  // activation tensors are stored as the kernel's STV template parameter says: 0 = fp32, 1 = bf16, 2 = fp16 (all
+  // arithmetic is fp32 either way; 16-bit storage rounds once, when a layer output is written)
+  const void* x;               // NHWC [B][H][W][CI]  (FROMRGB: network input, fp32 NCHW [B][4][H][W]; MODE_PW: fp32, dwfir_kernel's output)
+  void* y;                     // NHWC [B][HO][WO][CO]
+  const void* skip;            // NHWC like y, added after the activation, or null
   // SeparableConv2d parameters in the reference's native layouts
   const float* wdw;            // conv1.weight [CI][1][3][3]
   const float* bdw;            // conv1.bias   [CI]
@@ -61,6 +64,10 @@ struct SepArgs {
   const float* img_prev;       // planar [B][3][HO/2][WO/2] or null
   float* img_out;              // planar [B][3][HO][WO]
   unsigned long long* prof;    // phase-cycle accumulators (MIGAN_PHASE_PROF builds only), else null
+  // uint8 network I/O (migan_forward_u8; reference scripts/demo.py:56-66,135-140), else null
+  const unsigned char* u8_img; // [B][H][W][3] HWC: FROMRGB builds x = cat([mask - 0.5, img * mask]) from it instead of reading p.x;
+  const unsigned char* u8_mask;// [B][H][W], 255 = known pixel      the fused ToRGB tail composes its output with it
+  unsigned char* u8_out;       // [B][HO][WO][3]: written by the fused ToRGB tail instead of img_out
   int B, H, W, CI, CO, HO, WO;
   // GEMM pixel grid of one workgroup: IMGS images x GH x GW (all powers of two), MT = IMGS*GH*GW rows
   int lgGH, lgGW, lgIMGS;
@@ -75,12 +82,21 @@ struct SepArgs {
 };
 
 struct RgbArgs {
-  const float* x;        // NHWC [B][H][W][C]
+  const void* x;         // NHWC [B][H][W][C], stored as Io<STV>
   const float* w;        // [3][C]
   const float* b;        // [3]
   const float* img_prev; // planar [B][3][H/2][W/2] or null
   float* img_out;        // planar [B][3][H][W]
+  const unsigned char* u8_img;   // uint8 network output (see SepArgs), else null
+  const unsigned char* u8_mask;
+  unsigned char* u8_out;
   int B, H, W, C;
+};
+
+struct NoiseArgs {
+  const float* src;      // noise_const [r][r]
+  float* dst;            // [h][w] = src tiled periodically and cropped
+  int r, h, w;
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -116,7 +132,6 @@ MIGAN_DEVICE MIGAN_INLINE f4 act4g(f4 v, float gain) {
 // order <= 2^-16 (a1b1, a1b2, a2b1, a1b3, a2b2, a3b1), each exact in the MFMA's fp32 accumulator:
 // fp32-grade accuracy (whole-generator error vs fp64 7.7e-6, same as the fp32 path) at 6/16 of the
 // fp32-MFMA cost.
-typedef unsigned u2v __attribute__((ext_vector_type(2)));
 MIGAN_DEVICE MIGAN_INLINE float bf16lo_f32(unsigned pk) { return __builtin_bit_cast(float, pk << 16); }
 MIGAN_DEVICE MIGAN_INLINE float bf16hi_f32(unsigned pk) { return __builtin_bit_cast(float, pk & 0xffff0000u); }
 // split 4 floats into three planes of 4 bf16 (8 bytes each)
@@ -172,6 +187,50 @@ MIGAN_DEVICE MIGAN_INLINE const float* at_bytes(const float* base, unsigned byte
 }
 MIGAN_DEVICE MIGAN_INLINE f4 ld4once(const float* p) { return MIGAN_LOAD_NT(reinterpret_cast<const f4*>(p)); }
 
+// ---- activation storage formats -------------------------------------------------------------------
+// Io<STV>: four consecutive channels of an NHWC activation tensor <-> one f4 of fp32 values.  `raw4` is what a
+// thread keeps in its prefetch registers (16 bytes for fp32 storage, 8 bytes for the 16-bit formats); every
+// address is (wave-uniform base pointer) + (32-bit lane BYTE offset), the saddr + voffset form of global_load.
+//   STV 0: fp32
+//   STV 1: bf16, round to nearest even on store (v_cvt_pk_bf16_f32), exact widening on load
+//   STV 2: fp16, round to nearest even on store (v_cvt_pk_f16_f32); layer outputs are bounded by the +-256 clamp of
+//          lrelu_agc (+ one skip tensor), far inside fp16's range
+template <int STV> struct Io;
+template <> struct Io<0> {
+  typedef f4 raw4;
+  static constexpr unsigned ESZ = 4;
+  static MIGAN_DEVICE MIGAN_INLINE raw4 ld(const char* base, unsigned off) { return *reinterpret_cast<const f4*>(base + off); }
+  static MIGAN_DEVICE MIGAN_INLINE raw4 ld_once(const char* base, unsigned off) { return MIGAN_LOAD_NT(reinterpret_cast<const f4*>(base + off)); }
+  static MIGAN_DEVICE MIGAN_INLINE f4 cvt(raw4 r) { return r; }
+  static MIGAN_DEVICE MIGAN_INLINE f4 rounded(f4 v) { return v; }      // the value a consumer of the stored tensor reads back
+  static MIGAN_DEVICE MIGAN_INLINE raw4 zero() { return f4{0.f, 0.f, 0.f, 0.f}; }
+  static MIGAN_DEVICE MIGAN_INLINE void st(char* base, unsigned off, f4 v) { MIGAN_STORE_NT(reinterpret_cast<f4*>(base + off), v); }
+};
+template <> struct Io<1> {
+  typedef u2v raw4;
+  static constexpr unsigned ESZ = 2;
+  static MIGAN_DEVICE MIGAN_INLINE raw4 ld(const char* base, unsigned off) { return *reinterpret_cast<const u2v*>(base + off); }
+  static MIGAN_DEVICE MIGAN_INLINE raw4 ld_once(const char* base, unsigned off) { return MIGAN_LOAD_NT(reinterpret_cast<const u2v*>(base + off)); }
+  static MIGAN_DEVICE MIGAN_INLINE f4 cvt(raw4 r) { return f4{bf16lo_f32(r.x), bf16hi_f32(r.x), bf16lo_f32(r.y), bf16hi_f32(r.y)}; }
+  static MIGAN_DEVICE MIGAN_INLINE f4 rounded(f4 v) { return cvt(u2v{MIGAN_PACK_BF16(v.x, v.y), MIGAN_PACK_BF16(v.z, v.w)}); }
+  static MIGAN_DEVICE MIGAN_INLINE raw4 zero() { return u2v{0u, 0u}; }
+  static MIGAN_DEVICE MIGAN_INLINE void st(char* base, unsigned off, f4 v) {
+    MIGAN_STORE_NT(reinterpret_cast<u2v*>(base + off), (u2v{MIGAN_PACK_BF16(v.x, v.y), MIGAN_PACK_BF16(v.z, v.w)}));
+  }
+};
+template <> struct Io<2> {
+  typedef u2v raw4;
+  static constexpr unsigned ESZ = 2;
+  static MIGAN_DEVICE MIGAN_INLINE raw4 ld(const char* base, unsigned off) { return *reinterpret_cast<const u2v*>(base + off); }
+  static MIGAN_DEVICE MIGAN_INLINE raw4 ld_once(const char* base, unsigned off) { return MIGAN_LOAD_NT(reinterpret_cast<const u2v*>(base + off)); }
+  static MIGAN_DEVICE MIGAN_INLINE f4 cvt(raw4 r) { return f4{MIGAN_F16LO_F32(r.x), MIGAN_F16HI_F32(r.x), MIGAN_F16LO_F32(r.y), MIGAN_F16HI_F32(r.y)}; }
+  static MIGAN_DEVICE MIGAN_INLINE f4 rounded(f4 v) { return cvt(u2v{MIGAN_PACK_F16(v.x, v.y), MIGAN_PACK_F16(v.z, v.w)}); }
+  static MIGAN_DEVICE MIGAN_INLINE raw4 zero() { return u2v{0u, 0u}; }
+  static MIGAN_DEVICE MIGAN_INLINE void st(char* base, unsigned off, f4 v) {
+    MIGAN_STORE_NT(reinterpret_cast<u2v*>(base + off), (u2v{MIGAN_PACK_F16(v.x, v.y), MIGAN_PACK_F16(v.z, v.w)}));
+  }
+};
+
 // XCD-aware workgroup order (MI355X: block b runs on XCD b%8, each XCD has a private 4 MiB L2):
 // give every XCD one contiguous range of logical tiles so halo rows shared by neighbouring tiles
 // and the Cout chunks of one tile hit the same L2.  Bijective for any grid size.
@@ -216,6 +275,37 @@ MIGAN_DEVICE MIGAN_INLINE float up_combine(const float (&t)[4], int oy, int ox, 
   return (vy0 ? wy0 * r0 : 0.0f) + (vy1 ? (1.0f - wy0) * r1 : 0.0f);
 }
 
+// scripts/demo.py of the reference, at network resolution
+MIGAN_DEVICE MIGAN_INLINE float unit_image(unsigned b) {
+  // demo.py:61: torch.Tensor(img).float() * 2 / 255 - 1, three fp32 roundings in that order
+  float v = (float)b;
+  v = v * 2.0f;
+  v = v / 255.0f;
+  return v - 1.0f;
+}
+MIGAN_DEVICE MIGAN_INLINE unsigned char unit_to_u8(float v) {
+  // demo.py:135-136: (y * 0.5 + 0.5).clamp(0, 1) * 255 -> .to(torch.uint8) (truncation)
+  float t = v * 0.5f + 0.5f;                       // y * 0.5 is exact, so a contracted FMA rounds identically
+  t = fminf(fmaxf(t, 0.0f), 1.0f);
+  return (unsigned char)(int)(t * 255.0f);
+}
+// x = cat([mask - 0.5, img * mask]) of one pixel (demo.py:56-66)
+MIGAN_DEVICE MIGAN_INLINE f4 pack_pixel(const unsigned char* img, const unsigned char* mask, size_t pix) {
+  const float mk = mask[pix] == 255 ? 1.0f : 0.0f;                               // demo.py:60: np.array(mask) // 255
+  const unsigned char* q = img + pix * 3;
+  return f4{mk - 0.5f, unit_image(q[0]) * mk, unit_image(q[1]) * mk, unit_image(q[2]) * mk};
+}
+// composed = img * mask + result * (1 - mask) of one pixel, mask in {0, 1} (demo.py:139-140)
+MIGAN_DEVICE MIGAN_INLINE void compose_pixel(const unsigned char* img, const unsigned char* mask, unsigned char* out, size_t pix, float y0,
+                                             float y1, float y2) {
+  const bool keep = mask[pix] == 255;
+  const unsigned char* q = img + pix * 3;
+  unsigned char* o = out + pix * 3;
+  o[0] = keep ? q[0] : unit_to_u8(y0);
+  o[1] = keep ? q[1] : unit_to_u8(y1);
+  o[2] = keep ? q[2] : unit_to_u8(y2);
+}
+
 #ifdef MIGAN_ABLATE
 #define MIGAN_ABL(bit) ((p.ablate & (bit)) != 0)
 #else
@@ -251,7 +341,8 @@ MIGAN_DEVICE MIGAN_INLINE float up_combine(const float (&t)[4], int oy, int ox, 
 //            compensated fp16 MFMA (v_mfma_f32_32x32x16_f16 x 3 on scaled 2-way split operands)
 //
 // Waves are laid out 2x2 over the MT x NT tile; each wave owns (MT/2)x(NT/2) as 32x32 MFMA tiles.
-template <int MODE, int MT, int NT, int KC, bool FROMRGB, int NI, int MINW, bool MAING, bool PERSIST, int GEMMV, bool TORGB>
+//   STV    : activation storage format (Io<STV>): 0 fp32, 1 bf16, 2 fp16
+template <int MODE, int MT, int NT, int KC, bool FROMRGB, int NI, int MINW, bool MAING, bool PERSIST, int GEMMV, bool TORGB, int STV = 0>
 MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, MINW) sepconv_kernel(const SepArgs p) {
   static_assert(MODE != MODE_DOWN, "FIR-down layers run as dwfir_kernel + a MODE_PW pointwise GEMM");
   MIGAN_DYN_SMEM(smem);
@@ -275,14 +366,17 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, MINW) sepconv_kernel(const SepArgs p)
   constexpr int NSLOT = PB / 16;
   constexpr int NB = BF ? NPL * NT * NSLOT / kThreads : NT * QC / kThreads;   // float4 items of the 1x1 weight tile per thread
   static_assert(NB >= 1 && NB * kThreads == (BF ? NPL * NT * NSLOT : NT * QC), "weight tile must split evenly over the threads");
-  static_assert(!BF || KC == 32, "the split GEMM variants are built for 32-channel chunks");
+  static_assert(!BF || KC == 32 || KC == 16, "the split GEMM variants are built for 32- or 16-channel chunks");
+  // input tensor format: the network input planes (FROMRGB) and dwfir_kernel's output (MODE_PW) are always fp32
+  typedef Io<(FROMRGB || MODE == MODE_PW) ? 0 : STV> IoIn;
+  typedef Io<STV> IoOut;
   constexpr int NW4 = KC * 10 / 4;                 // float4s of depthwise weights (9 taps) + bias per chunk
   constexpr int NF4 = FROMRGB ? KC * 5 / 4 : 0;    // float4s of fromrgb weights (4 per channel) + bias
   constexpr int SEGH = (MT >= 128) ? 4 : 2;        // output rows per depthwise strip (NORMAL / UP)
 
-  const float* __restrict__ gx_ = p.x;
-  float* __restrict__ gy_ = p.y;
-  const float* __restrict__ gskip = p.skip;
+  const char* __restrict__ gx_ = reinterpret_cast<const char*>(p.x);
+  char* __restrict__ gy_ = reinterpret_cast<char*>(p.y);
+  const char* __restrict__ gskip = reinterpret_cast<const char*>(p.skip);
   const float* __restrict__ gwdw = p.wdw;
   const float* __restrict__ gbdw = p.bdw;
   const float* __restrict__ gwpw = p.wpw;
@@ -339,18 +433,22 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, MINW) sepconv_kernel(const SepArgs p)
   float* w_s = smem + p.off_w;              // [KC*9] depthwise taps, [KC] bias, (FROMRGB: [KC*4] + [KC])
   float* g_s = smem;                        // after the K loop: [MT][GS], aliases the buffers above
   // A-operand row m, channels 4*c4..4*c4+3 of the current chunk
+  // XOR swizzle of the 16-byte slots of a row of a 16-bit operand plane (conflict-free ds_read_b128 of 32 consecutive
+  // rows): 64-byte rows (KC 32) rotate through their 4 slots every 4 rows, 32-byte rows (KC 16) swap their 2 slots
+  // every 8 rows
+  auto swz = [](int row) { return NSLOT == 4 ? ((row >> 2) & 3) : ((row >> 3) & 1); };
   auto emit_a = [&](float* abase, int m, int c4, f4 v) {
     if constexpr (F16) {
       // v already carries the 2^7 activation scale
       u2v h1, h2;
       split2_f16(v, h1, h2);
-      char* d = reinterpret_cast<char*>(abase) + m * PB + (((c4 >> 1) ^ ((m >> 2) & (NSLOT - 1))) << 4) + ((c4 & 1) << 3);
+      char* d = reinterpret_cast<char*>(abase) + m * PB + (((c4 >> 1) ^ swz(m)) << 4) + ((c4 & 1) << 3);
       *reinterpret_cast<u2v*>(d) = h1;
       *reinterpret_cast<u2v*>(d + MT * PB) = h2;
     } else if constexpr (BF) {
       u2v h1, h2, h3;
       split3_bf16(v, h1, h2, h3);
-      char* d = reinterpret_cast<char*>(abase) + m * PB + (((c4 >> 1) ^ ((m >> 2) & (NSLOT - 1))) << 4) + ((c4 & 1) << 3);
+      char* d = reinterpret_cast<char*>(abase) + m * PB + (((c4 >> 1) ^ swz(m)) << 4) + ((c4 & 1) << 3);
       *reinterpret_cast<u2v*>(d) = h1;
       *reinterpret_cast<u2v*>(d + MT * PB) = h2;
       *reinterpret_cast<u2v*>(d + 2 * MT * PB) = h3;
@@ -389,7 +487,7 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, MINW) sepconv_kernel(const SepArgs p)
         const int yy = gy0_ - HALO + iy, xx = gx0_ - HALO + ix;
         if (yy >= 0 && yy < p.H && xx >= 0 && xx < p.W && (b0_ + img) < p.B) {
           vmask_ |= 1u << j;
-          g = FROMRGB ? 0u : (unsigned)(((img * p.H + yy) * p.W + xx) * p.CI + c4 * 4) * 4u;     // bytes
+          g = FROMRGB ? 0u : (unsigned)(((img * p.H + yy) * p.W + xx) * p.CI + c4 * 4) * IoIn::ESZ;     // bytes
         }
       }
       goff_[j] = g;
@@ -401,10 +499,10 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, MINW) sepconv_kernel(const SepArgs p)
     for (int j = 0; j < NB; ++j) {
       const int i = tid + j * kThreads;
       if constexpr (BF) {
-        // item = (plane, row n, 16-byte slot of 8 pieces); offset in 16-bit elements inside one K chunk of the
-        // chunk-major planes [NPL][CI/KC][CO][KC] (a workgroup's weight tile of a chunk is one contiguous run)
+        // item = (plane, row n, 16-byte slot of 8 pieces); offset in 16-bit elements inside one 32-channel block of the
+        // chunk-major planes [NPL][CI/32][CO][32] (the weight tile of a 32-channel K chunk is one contiguous run)
         const int plane = i / (NT * NSLOT), rem = i % (NT * NSLOT);
-        boff_[j] = (unsigned)(plane * p.CO * p.CI + (n0_ + rem / NSLOT) * KC + (rem % NSLOT) * 8) * 2u;    // bytes
+        boff_[j] = (unsigned)(plane * p.CO * p.CI + (n0_ + rem / NSLOT) * 32 + (rem % NSLOT) * 8) * 2u;    // bytes
       } else {
         boff_[j] = (unsigned)((n0_ + (i >> LG_QC)) * p.CI + (i & (QC - 1)) * 4) * 4u;                      // bytes
       }
@@ -420,9 +518,13 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, MINW) sepconv_kernel(const SepArgs p)
       const int iy = r % IGH, img = r / IGH;
       const int yy = gy0_ - HALO + iy, xx = gx0_ - HALO + ix;
       if (yy >= 0 && yy < p.H && xx >= 0 && xx < p.W && (b0_ + img) < p.B) {
-        const float* src = gx_ + ((size_t)(b0_ + img) * 4 * p.H + yy) * p.W + xx;
-        const size_t plane = (size_t)p.H * p.W;
-        v = f4{src[0], src[plane], src[2 * plane], src[3 * plane]};
+        if (p.u8_img) {
+          v = pack_pixel(p.u8_img, p.u8_mask, ((size_t)(b0_ + img) * p.H + yy) * p.W + xx);
+        } else {
+          const float* src = reinterpret_cast<const float*>(gx_) + ((size_t)(b0_ + img) * 4 * p.H + yy) * p.W + xx;
+          const size_t plane = (size_t)p.H * p.W;
+          v = f4{src[0], src[plane], src[2 * plane], src[3 * plane]};
+        }
       }
     }
     return v;
@@ -434,22 +536,23 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, MINW) sepconv_kernel(const SepArgs p)
   f16v acc[MTI][NTI];
 
   // prefetch registers: one K chunk of the input tile, of the 1x1 weights and of the small weights
-  f4 rin[NI], rb[NB], rw, rraw;
+  typename IoIn::raw4 rin[NI];
+  f4 rb[NB], rw, rraw;
   // every global access below is (wave-uniform base pointer, held in SGPRs) + (32-bit lane offset):
   // no 64-bit VALU address arithmetic in the K loop.
   auto issue_loads = [&](int b0_, const unsigned (&goff_)[NI], const unsigned (&boff_)[NB], int k0) {
     if constexpr (!FROMRGB) {
-      const float* __restrict__ xk = gx_ + (size_t)b0_ * p.H * p.W * p.CI + k0;
+      const char* __restrict__ xk = gx_ + ((size_t)b0_ * p.H * p.W * p.CI + k0) * IoIn::ESZ;
       if (MIGAN_ABL(16)) {
 #pragma unroll
-        for (int j = 0; j < NI; ++j) rin[j] = f4{0.5f, 0.25f, -0.5f, 1.0f};
+        for (int j = 0; j < NI; ++j) rin[j] = IoIn::zero();
       } else {
 #pragma unroll
-        for (int j = 0; j < NI; ++j) rin[j] = ld4(at_bytes(xk, goff_[j]));
+        for (int j = 0; j < NI; ++j) rin[j] = IoIn::ld(xk, goff_[j]);
       }
     }
     if constexpr (BF) {
-      const unsigned short* __restrict__ wk = p.wsplit + (size_t)k0 * p.CO;       // chunk k0/KC starts at (k0/KC) * CO * KC
+      const unsigned short* __restrict__ wk = p.wsplit + (size_t)(k0 >> 5) * 32 * p.CO + (k0 & 31);   // 32-channel block k0/32, column k0%32
 #pragma unroll
       for (int j = 0; j < NB; ++j) rb[j] = ld4(at_bytes(reinterpret_cast<const float*>(wk), boff_[j]));
     } else {
@@ -519,7 +622,7 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, MINW) sepconv_kernel(const SepArgs p)
       if constexpr (BF) {
         const int plane = i / (NT * NSLOT), rem = i % (NT * NSLOT);
         const int n = rem / NSLOT, slot = rem % NSLOT;
-        char* dst = reinterpret_cast<char*>(bcur) + (plane * NT + n) * PB + ((slot ^ ((n >> 2) & (NSLOT - 1))) << 4);
+        char* dst = reinterpret_cast<char*>(bcur) + (plane * NT + n) * PB + ((slot ^ swz(n)) << 4);
         st4(reinterpret_cast<float*>(dst), rb[j]);
       } else {
         st4(bcur + (i >> LG_QC) * AS + (i & (QC - 1)) * 4, rb[j]);
@@ -553,7 +656,7 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, MINW) sepconv_kernel(const SepArgs p)
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
           const int i = tid + j * kThreads;
-          f4 v = rin[j];
+          f4 v = IoIn::cvt(rin[j]);
           if (!(vmask & (1u << j))) v = f4{0.f, 0.f, 0.f, 0.f};
           if constexpr (F16) v = v * kF16AScale;
           emit_a(acur, i >> LG_QC, i & (QC - 1), v);
@@ -561,12 +664,12 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, MINW) sepconv_kernel(const SepArgs p)
       } else if (wave_all_valid) {
 #pragma unroll
         for (int j = 0; j < NI; ++j)
-          if (emask & (1u << j)) st4(in_s + (tid + j * kThreads) * 4, rin[j]);
+          if (emask & (1u << j)) st4(in_s + (tid + j * kThreads) * 4, IoIn::cvt(rin[j]));
       } else {
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
           if (emask & (1u << j)) {
-            f4 v = rin[j];
+            f4 v = IoIn::cvt(rin[j]);
             if (!(vmask & (1u << j))) v = f4{0.f, 0.f, 0.f, 0.f};
             st4(in_s + (tid + j * kThreads) * 4, v);
           }
@@ -650,14 +753,14 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, MINW) sepconv_kernel(const SepArgs p)
 #pragma unroll
         for (int i = 0; i < MTI; ++i) {
           const int row = wm * WROWS + i * 32 + l31;
-          const char* q = ab + row * PB + (((2 * ks + half) ^ ((row >> 2) & (NSLOT - 1))) << 4);
+          const char* q = ab + row * PB + (((2 * ks + half) ^ swz(row)) << 4);
 #pragma unroll
           for (int pl = 0; pl < NPL; ++pl) av[i][pl] = ld4(reinterpret_cast<const float*>(q + pl * MT * PB));
         }
 #pragma unroll
         for (int j = 0; j < NTI; ++j) {
           const int row = wn * WCOLS + j * 32 + l31;
-          const char* q = bb + row * PB + (((2 * ks + half) ^ ((row >> 2) & (NSLOT - 1))) << 4);
+          const char* q = bb + row * PB + (((2 * ks + half) ^ swz(row)) << 4);
 #pragma unroll
           for (int pl = 0; pl < NPL; ++pl) bv[j][pl] = ld4(reinterpret_cast<const float*>(q + pl * NT * PB));
         }
@@ -755,8 +858,9 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, MINW) sepconv_kernel(const SepArgs p)
   const int m0 = tide >> LG_QN;
   const int gxt = m0 & (GW - 1), gyt = (m0 >> lgGW) & (GH - 1);
   const size_t img_elems = (size_t)p.HO * p.WO * p.CO;
-  float* __restrict__ yb = gy_ + (size_t)b0 * img_elems;
-  const float* __restrict__ sb = gskip ? gskip + (size_t)b0 * img_elems : nullptr;
+  char* __restrict__ yb = gy_ + (size_t)b0 * img_elems * IoOut::ESZ;
+  const char* __restrict__ sb = gskip ? gskip + (size_t)b0 * img_elems * IoOut::ESZ : nullptr;
+  constexpr unsigned OE = IoOut::ESZ;
 
   if constexpr (MODE != MODE_UP) {
     constexpr bool do_rgb = TORGB;          // ToRGB fused into this epilogue (host: CO == NT, trgb_w set)
@@ -775,7 +879,7 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, MINW) sepconv_kernel(const SepArgs p)
       rgb_oy = gy0 + ((m >> lgGW) & (GH - 1));
       rgb_ox = gx0 + (m & (GW - 1));
       rgb_b = b0 + (m >> (lgGW + lgGH));
-      rgb_ok = (tide & 1) == 0 && rgb_b < p.B && tide < 2 * MT;
+      rgb_ok = (tide & 1) == 0 && rgb_b < p.B && tide < 2 * MT && rgb_oy < p.HO && rgb_ox < p.WO;
       if (rgb_ok && p.img_prev) {
         const size_t plane4 = ((size_t)p.HO * p.WO) >> 2;
 #pragma unroll
@@ -788,7 +892,8 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, MINW) sepconv_kernel(const SepArgs p)
       constexpr bool HN = decltype(hn_)::value, HS = decltype(hs_)::value;
 #pragma unroll
     for (int it0 = 0; it0 < ITEMS; it0 += UB) {
-      f4 val[UB], sk[UB];
+      f4 val[UB];
+      typename IoOut::raw4 sk[UB];
       float nz[UB];
       unsigned loff[UB];     // lane part of the offset, in BYTES
       int upix[UB];          // uniform part, in pixels
@@ -800,18 +905,18 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, MINW) sepconv_kernel(const SepArgs p)
         val[u] = ld4(g_s + m * GS + c4 * 4);
         if constexpr (MAINGEO) {
           upix[u] = (dm >> lgGW) * p.WO + (dm & (GW - 1));
-          loff[u] = off_t * 4u;
+          loff[u] = off_t * OE;
           ok[u] = true;
           if constexpr (HN) nz[u] = *at_bytes(gnoise + upix[u], pix_t * 4u);
         } else {
           const int gx = m & (GW - 1), gy = (m >> lgGW) & (GH - 1), img = m >> (lgGW + lgGH);
-          ok[u] = (b0 + img) < p.B;
-          const unsigned pix = (unsigned)((gy0 + gy) * p.WO + gx0 + gx);
+          ok[u] = (b0 + img) < p.B && (gy0 + gy) < p.HO && (gx0 + gx) < p.WO;       // ragged batch / ragged image edge
+          const unsigned pix = ok[u] ? (unsigned)((gy0 + gy) * p.WO + gx0 + gx) : 0u;
           upix[u] = 0;
-          loff[u] = ((unsigned)(ok[u] ? img : 0) * (unsigned)img_elems + pix * (unsigned)p.CO + (unsigned)(n0 + c4 * 4)) * 4u;
+          loff[u] = ((unsigned)(ok[u] ? img : 0) * (unsigned)img_elems + pix * (unsigned)p.CO + (unsigned)(n0 + c4 * 4)) * OE;
           if constexpr (HN) nz[u] = gnoise[pix];
         }
-        if constexpr (HS) sk[u] = ld4once(at_bytes(sb + (size_t)upix[u] * p.CO, loff[u]));
+        if constexpr (HS) sk[u] = IoOut::ld_once(sb + (size_t)upix[u] * p.CO * OE, loff[u]);
       }
 #pragma unroll
       for (int u = 0; u < UB; ++u) {
@@ -824,11 +929,13 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, MINW) sepconv_kernel(const SepArgs p)
           v = F16 ? act4g(v, gain_s) : act4(v);
         }
         f4 outv = v;
-        if constexpr (HS) outv = v + sk[u];
-        if (ok[u] && !MIGAN_ABL(1)) st4o(at_bytes(yb + (size_t)upix[u] * p.CO, loff[u]), outv);
+        if constexpr (HS) outv = v + IoOut::cvt(sk[u]);
+        if (ok[u] && !MIGAN_ABL(1)) IoOut::st(yb + (size_t)upix[u] * p.CO * OE, loff[u], outv);
         if constexpr (do_rgb) {
           // ToRGB (reference :312): this lane's share of the 3 dot products over the CO channels of the pixel
           // goes into the g_s slot the item just consumed; the per-pixel sums are formed in the tail pass below.
+          // (16-bit storage: ToRGB sees the stored, i.e. rounded, activations, like torgb_kernel reading the tensor back)
+          v = IoOut::rounded(outv);
           const float r0 = v.x * tw0.x + v.y * tw0.y + v.z * tw0.z + v.w * tw0.w;
           const float r1 = v.x * tw1.x + v.y * tw1.y + v.z * tw1.z + v.w * tw1.w;
           const float r2 = v.x * tw2.x + v.y * tw2.y + v.z * tw2.z + v.w * tw2.w;
@@ -854,9 +961,15 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, MINW) sepconv_kernel(const SepArgs p)
       if (rgb_ok) {   // (tide < 2 * MT is part of rgb_ok)
         const float rgb[3] = {sum.x + p.trgb_b[0], sum.y + p.trgb_b[1], sum.z + p.trgb_b[2]};
         const size_t plane = (size_t)p.HO * p.WO;
+        float o3[3];
 #pragma unroll
-        for (int ch = 0; ch < 3; ++ch)
-          p.img_out[((size_t)rgb_b * 3 + ch) * plane + (size_t)rgb_oy * p.WO + rgb_ox] = up_combine(pv[ch], rgb_oy, rgb_ox, p.HO >> 1, p.WO >> 1) + rgb[ch];
+        for (int ch = 0; ch < 3; ++ch) o3[ch] = up_combine(pv[ch], rgb_oy, rgb_ox, p.HO >> 1, p.WO >> 1) + rgb[ch];
+        if (p.u8_out) {
+          compose_pixel(p.u8_img, p.u8_mask, p.u8_out, (size_t)rgb_b * plane + (size_t)rgb_oy * p.WO + rgb_ox, o3[0], o3[1], o3[2]);
+        } else {
+#pragma unroll
+          for (int ch = 0; ch < 3; ++ch) p.img_out[((size_t)rgb_b * 3 + ch) * plane + (size_t)rgb_oy * p.WO + rgb_ox] = o3[ch];
+        }
       }
     }
   } else {
@@ -895,7 +1008,7 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, MINW) sepconv_kernel(const SepArgs p)
         lpix = (2 * ly) * p.WO + 2 * lx;
         loff = img * (int)img_elems + lpix * p.CO + n0 + c4 * 4;
       }
-      f4 sk[2][2];
+      typename IoOut::raw4 sk[2][2];
       float nz[2][2];
 #pragma unroll
       for (int a = 0; a < 2; ++a)
@@ -903,7 +1016,7 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, MINW) sepconv_kernel(const SepArgs p)
         for (int bb = 0; bb < 2; ++bb) {
           const int dp = upix + a * p.WO + bb;                      // uniform
           if constexpr (HN) nz[a][bb] = gnoise[(unsigned)(lpix + dp)];
-          if constexpr (HS) sk[a][bb] = ld4once(sb + (unsigned)(loff + dp * p.CO));
+          if constexpr (HS) sk[a][bb] = IoOut::ld_once(sb, (unsigned)(loff + dp * p.CO) * OE);
         }
       f4 e[3], o[3];
 #pragma unroll
@@ -930,8 +1043,8 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, MINW) sepconv_kernel(const SepArgs p)
           } else {
             v = F16 ? act4g(v, gain_s) : act4(v);
           }
-          if constexpr (HS) v += sk[a][bb];
-          if (!MIGAN_ABL(1)) st4o(yb + (unsigned)(loff + (upix + a * p.WO + bb) * p.CO), v);
+          if constexpr (HS) v += IoOut::cvt(sk[a][bb]);
+          if (!MIGAN_ABL(1)) IoOut::st(yb, (unsigned)(loff + (upix + a * p.WO + bb) * p.CO) * OE, v);
         }
     }
     };
@@ -965,8 +1078,10 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, MINW) sepconv_kernel(const SepArgs p)
 // Everything the K loop touches is double buffered (input tile, taps, A planes, B planes: 145 KB), so one
 // barrier per chunk suffices.  MFMA wave grid 2 x 4, each wave 64 x 64 (same fragments as sepconv_kernel).
 constexpr int kWideThreads = 512;
-template <bool TORGB>
+template <bool TORGB, int STV = 0>
 MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(kWideThreads, 2) sepconv_wide_kernel(const SepArgs p) {
+  typedef Io<STV> IoT;
+  constexpr unsigned OE = IoT::ESZ;
   MIGAN_DYN_SMEM(smem);
   constexpr int MT = 128, NT = 256, KC = 32, QC = 8, LG_QC = 3;
   constexpr int GS = NT + 4, QN = NT / 4, LG_QN = 6;
@@ -985,9 +1100,9 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(kWideThreads, 2) sepconv_wide_kernel(const
   static_assert((OFF_B + 2 * B_SZ) * 4 <= 160 * 1024 && MT * GS * 4 <= 160 * 1024, "LDS budget");
   float* g_s = smem;                                                        // after the K loop: [MT][GS]
 
-  const float* __restrict__ gx_ = p.x;
-  float* __restrict__ gy_ = p.y;
-  const float* __restrict__ gskip = p.skip;
+  const char* __restrict__ gx_ = reinterpret_cast<const char*>(p.x);
+  char* __restrict__ gy_ = reinterpret_cast<char*>(p.y);
+  const char* __restrict__ gskip = reinterpret_cast<const char*>(p.skip);
   const float* __restrict__ gnoise = p.noise;
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -1023,7 +1138,7 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(kWideThreads, 2) sepconv_wide_kernel(const
       const int yy = gy0 - 1 + iy, xx = gx0 - 1 + ix;
       if (yy >= 0 && yy < p.H && xx >= 0 && xx < p.W) {
         vmask |= 1u << j;
-        g = (unsigned)((yy * p.W + xx) * p.CI + c4 * 4) * 4u;      // bytes
+        g = (unsigned)((yy * p.W + xx) * p.CI + c4 * 4) * OE;      // bytes
       }
     }
     goff[j] = g;
@@ -1034,11 +1149,12 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(kWideThreads, 2) sepconv_wide_kernel(const
     const int plane = i / (NT * NSLOT), rem = i % (NT * NSLOT);
     boff[j] = (unsigned)(plane * p.CO * p.CI + (n0 + rem / NSLOT) * KC + (rem % NSLOT) * 8) * 2u;    // bytes
   }
-  const float* __restrict__ xb = gx_ + (size_t)b0 * p.H * p.W * p.CI;
-  f4 rin[NI], rb[NB], rw;
+  const char* __restrict__ xb = gx_ + (size_t)b0 * p.H * p.W * p.CI * OE;
+  typename IoT::raw4 rin[NI];
+  f4 rb[NB], rw;
   auto load_in = [&](int k0) {                     // input tile + depthwise taps of one chunk
 #pragma unroll
-    for (int j = 0; j < NI; ++j) rin[j] = ld4(at_bytes(xb + k0, goff[j]));
+    for (int j = 0; j < NI; ++j) rin[j] = IoT::ld(xb + (size_t)k0 * OE, goff[j]);
     if (tid < KC * 9 / 4) rw = ld4(p.wdw + (size_t)k0 * 9 + (unsigned)(tid * 4));
     else if (tid < NW4) rw = ld4(p.bdw + k0 + (unsigned)((tid - KC * 9 / 4) * 4));
   };
@@ -1062,7 +1178,7 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(kWideThreads, 2) sepconv_wide_kernel(const
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
       if (emask & (1u << j)) {
-        f4 v = rin[j];
+        f4 v = IoT::cvt(rin[j]);
         if (!(vmask & (1u << j))) v = f4{0.f, 0.f, 0.f, 0.f};
         st4(in_s + (tid + j * kWideThreads) * 4, v);
       }
@@ -1222,8 +1338,8 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(kWideThreads, 2) sepconv_wide_kernel(const
   const int m0 = tide >> LG_QN;
   const int gxt = m0 & (GW - 1), gyt = m0 >> lgGW;
   const size_t img_elems = (size_t)p.HO * p.WO * p.CO;
-  float* __restrict__ yb = gy_ + (size_t)b0 * img_elems;
-  const float* __restrict__ sb = gskip ? gskip + (size_t)b0 * img_elems : nullptr;
+  char* __restrict__ yb = gy_ + (size_t)b0 * img_elems * OE;
+  const char* __restrict__ sb = gskip ? gskip + (size_t)b0 * img_elems * OE : nullptr;
   f4 tw0 = {0.f, 0.f, 0.f, 0.f}, tw1 = tw0, tw2 = tw0;
   int rgb_oy = 0, rgb_ox = 0;
   bool rgb_ok = false;
@@ -1243,12 +1359,13 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(kWideThreads, 2) sepconv_wide_kernel(const
     }
   }
   const unsigned pix_t = (unsigned)((gy0 + gyt) * p.WO + gx0 + gxt);
-  const unsigned off_t = (pix_t * (unsigned)p.CO + (unsigned)(n0 + c4 * 4)) * 4u;      // lane byte offset
+  const unsigned off_t = (pix_t * (unsigned)p.CO + (unsigned)(n0 + c4 * 4)) * OE;      // lane byte offset
   auto epi_items = [&](auto hn_, auto hs_) {
     constexpr bool HN = decltype(hn_)::value, HS = decltype(hs_)::value;
 #pragma unroll
     for (int it0 = 0; it0 < ITEMS; it0 += UB) {
-      f4 val[UB], sk[UB];
+      f4 val[UB];
+      typename IoT::raw4 sk[UB];
       float nz[UB];
       int upix[UB];
 #pragma unroll
@@ -1257,7 +1374,7 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(kWideThreads, 2) sepconv_wide_kernel(const
         val[u] = ld4(g_s + (m0 + dm) * GS + c4 * 4);
         upix[u] = (dm >> lgGW) * p.WO + (dm & (GW - 1));
         if constexpr (HN) nz[u] = *at_bytes(gnoise + upix[u], pix_t * 4u);
-        if constexpr (HS) sk[u] = ld4once(at_bytes(sb + (size_t)upix[u] * p.CO, off_t));
+        if constexpr (HS) sk[u] = IoT::ld_once(sb + (size_t)upix[u] * p.CO * OE, off_t);
       }
 #pragma unroll
       for (int u = 0; u < UB; ++u) {
@@ -1269,9 +1386,10 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(kWideThreads, 2) sepconv_wide_kernel(const
           v = act4g(v, gain_s);
         }
         f4 outv = v;
-        if constexpr (HS) outv = v + sk[u];
-        st4o(at_bytes(yb + (size_t)upix[u] * p.CO, off_t), outv);
+        if constexpr (HS) outv = v + IoT::cvt(sk[u]);
+        IoT::st(yb + (size_t)upix[u] * p.CO * OE, off_t, outv);
         if constexpr (TORGB) {
+          v = IoT::rounded(outv);
           const float r0 = v.x * tw0.x + v.y * tw0.y + v.z * tw0.z + v.w * tw0.w;
           const float r1 = v.x * tw1.x + v.y * tw1.y + v.z * tw1.z + v.w * tw1.w;
           const float r2 = v.x * tw2.x + v.y * tw2.y + v.z * tw2.z + v.w * tw2.w;
@@ -1294,9 +1412,15 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(kWideThreads, 2) sepconv_wide_kernel(const
     if (rgb_ok) {
       const float rgb[3] = {sum.x + p.trgb_b[0], sum.y + p.trgb_b[1], sum.z + p.trgb_b[2]};
       const size_t plane = (size_t)p.HO * p.WO;
+      float o3[3];
 #pragma unroll
-      for (int ch = 0; ch < 3; ++ch)
-        p.img_out[((size_t)b0 * 3 + ch) * plane + (size_t)rgb_oy * p.WO + rgb_ox] = up_combine(pv[ch], rgb_oy, rgb_ox, p.HO >> 1, p.WO >> 1) + rgb[ch];
+      for (int ch = 0; ch < 3; ++ch) o3[ch] = up_combine(pv[ch], rgb_oy, rgb_ox, p.HO >> 1, p.WO >> 1) + rgb[ch];
+      if (p.u8_out) {
+        compose_pixel(p.u8_img, p.u8_mask, p.u8_out, (size_t)b0 * plane + (size_t)rgb_oy * p.WO + rgb_ox, o3[0], o3[1], o3[2]);
+      } else {
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) p.img_out[((size_t)b0 * 3 + ch) * plane + (size_t)rgb_oy * p.WO + rgb_ox] = o3[ch];
+      }
     }
   }
 }
@@ -1311,8 +1435,8 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(kWideThreads, 2) sepconv_wide_kernel(const
 // computed exactly once per pixel here (memory-bound, 3 workgroups per CU) instead of once per
 // Cout tile inside the MFMA loop.
 struct DwFirArgs {
-  const float* x;      // NHWC [B][H][W][C]
-  float* y;            // NHWC [B][H/2][W/2][C]
+  const void* x;       // NHWC [B][H][W][C], stored as Io<STV>
+  float* y;            // NHWC [B][H/2][W/2][C], always fp32 (intermediate of one SeparableConv2d, never rounded)
   const float* wdw;    // conv1.weight [C][1][3][3]
   const float* bdw;    // conv1.bias [C]
   int B, H, W, C;
@@ -1321,8 +1445,9 @@ struct DwFirArgs {
   int off_d, off_w;                // LDS carve (floats)
 };
 
-template <int NI, bool MAING>
+template <int NI, bool MAING, int STV = 0>
 MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, 3) dwfir_kernel(const DwFirArgs p) {
+  typedef Io<STV> IoIn;
   MIGAN_DYN_SMEM(smem);
   constexpr int KC = 16, QC = 4, LG_QC = 2, MT = 64;
   const int tid = threadIdx.x;
@@ -1342,7 +1467,7 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, 3) dwfir_kernel(const DwFirArgs p) {
   float* in_s = smem;
   float* d_s = smem + p.off_d;
   float* w_s = smem + p.off_w;
-  const float* __restrict__ xb = p.x + (size_t)b0 * p.H * p.W * p.C;
+  const char* __restrict__ xb = reinterpret_cast<const char*>(p.x) + (size_t)b0 * p.H * p.W * p.C * IoIn::ESZ;
   float* __restrict__ yb = p.y + (size_t)b0 * HO * WO * p.C;
 
   // per-thread item descriptors (constant across the channel chunks this workgroup walks)
@@ -1362,16 +1487,17 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, 3) dwfir_kernel(const DwFirArgs p) {
       const int yy = iy0 + iy, xx = ix0 + ix;
       if (yy >= 0 && yy < p.H && xx >= 0 && xx < p.W && (b0 + img) < p.B) {
         vmask |= 1u << j;
-        g = (unsigned)(((img * p.H + yy) * p.W + xx) * p.C + c4 * 4);
+        g = (unsigned)(((img * p.H + yy) * p.W + xx) * p.C + c4 * 4) * IoIn::ESZ;     // bytes
       }
     }
     goff[j] = g;
   }
-  f4 rin[NI], rw;
+  typename IoIn::raw4 rin[NI];
+  f4 rw;
   auto issue_loads = [&](int k0) {
-    const float* __restrict__ xk = xb + k0;
+    const char* __restrict__ xk = xb + (size_t)k0 * IoIn::ESZ;
 #pragma unroll
-    for (int j = 0; j < NI; ++j) rin[j] = ld4(xk + goff[j]);
+    for (int j = 0; j < NI; ++j) rin[j] = IoIn::ld(xk, goff[j]);
     if (tid < KC * 9 / 4) rw = ld4(p.wdw + (size_t)k0 * 9 + (unsigned)(tid * 4));
     else if (tid < KC * 10 / 4) rw = ld4(p.bdw + k0 + (unsigned)((tid - KC * 9 / 4) * 4));
   };
@@ -1394,7 +1520,7 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, 3) dwfir_kernel(const DwFirArgs p) {
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
       if (emask & (1u << j)) {
-        f4 v = rin[j];
+        f4 v = IoIn::cvt(rin[j]);
         if (!(vmask & (1u << j))) v = f4{0.f, 0.f, 0.f, 0.f};
         st4(in_s + (tid + j * kThreads) * 4, v);
       }
@@ -1447,7 +1573,7 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, 3) dwfir_kernel(const DwFirArgs p) {
       const int c4 = it & (QC - 1);
       const int m = it >> LG_QC;
       const int ox = m & (GW - 1), oy = (m >> lgGW) & (GH - 1), img = m >> (lgGW + lgGH);
-      if (b0 + img >= p.B) continue;
+      if (b0 + img >= p.B || gy0 + oy >= HO || gx0 + ox >= WO) continue;          // ragged batch / ragged image edge
       const float* dp = d_s + ((img * DH + 2 * oy) * DW + 2 * ox) * KC + c4 * 4;
       f4 a = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -1478,6 +1604,7 @@ struct SplitArgs {
 };
 constexpr int kSplitHeader = 8;     // 16-bit elements of header in front of the planes: float[0] = accumulator scale, float[2] = weight scale
 constexpr int kSplitBlocksPerTensor = 32;
+#ifndef MIGAN_TEMPLATE_KERNELS_ONLY   // (the kernel-table slice translation units only instantiate sepconv_kernel)
 // f16x2 only: one workgroup per tensor finds max|w| and derives the power-of-two scales.
 MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, 2) weight_absmax_kernel(const SplitArgs p) {
   MIGAN_DYN_SMEM(red);
@@ -1531,20 +1658,36 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, 2) split_weights_kernel(const SplitAr
   }
 }
 
+#endif  // MIGAN_TEMPLATE_KERNELS_ONLY
+
+// ------------------------------------------------------------------------------------------------
+// Arbitrary-size forward (reference README.md:87): the [h][w] noise plane of a layer = noise_const [r][r] tiled periodically
+// and cropped (what `self.register_buffer('noise_const', ...)`, reference :149, would have to become).
+#ifndef MIGAN_TEMPLATE_KERNELS_ONLY
+MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, 2) noise_plane_kernel(const NoiseArgs p) {
+  const int i = (int)(blockIdx.x * kThreads + threadIdx.x);
+  if (i >= p.h * p.w) return;
+  const int y = i / p.w, x = i % p.w;
+  p.dst[i] = p.src[(y % p.r) * p.r + (x % p.r)];
+}
+#endif
+
 // ------------------------------------------------------------------------------------------------
 // Un-fused ToRGB (reference torgb 1x1 conv with bias + Upsample2d of the running image, :308-313)
 // for layers whose output channels are split over several workgroups.  16 lanes per pixel, each
 // lane strides over the channel float4s, then a 4-step wave-shuffle butterfly.
+template <int STV>
 MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, 2) torgb_kernel(const RgbArgs p) {
+  typedef Io<STV> IoIn;
   const int sub = threadIdx.x & 15;
   const size_t pixel = ((size_t)blockIdx.x * kThreads + threadIdx.x) >> 4;
   const size_t npix = (size_t)p.B * p.H * p.W;
   const bool ok = pixel < npix;
   float r0 = 0.f, r1 = 0.f, r2 = 0.f;
   if (ok) {
-    const float* xp = p.x + pixel * p.C;
+    const char* xp = reinterpret_cast<const char*>(p.x) + pixel * p.C * IoIn::ESZ;
     for (int q = sub; q < (p.C >> 2); q += 16) {
-      const f4 v = ld4(xp + q * 4);
+      const f4 v = IoIn::cvt(IoIn::ld(xp, (unsigned)(q * 4) * IoIn::ESZ));
       const f4 w0 = ld4(p.w + q * 4), w1 = ld4(p.w + p.C + q * 4), w2 = ld4(p.w + 2 * p.C + q * 4);
       r0 += v.x * w0.x + v.y * w0.y + v.z * w0.z + v.w * w0.w;
       r1 += v.x * w1.x + v.y * w1.y + v.z * w1.z + v.w * w1.w;
@@ -1563,11 +1706,18 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, 2) torgb_kernel(const RgbArgs p) {
     const int rem = (int)(pixel % plane);
     const int oy = rem / p.W, ox = rem % p.W;
     const float rgb[3] = {r0 + p.b[0], r1 + p.b[1], r2 + p.b[2]};
+    float o3[3];
 #pragma unroll
     for (int ch = 0; ch < 3; ++ch) {
       float up = 0.0f;
       if (p.img_prev) up = up_prev3(p.img_prev + ((size_t)b * 3 + ch) * (plane >> 2), p.H >> 1, p.W >> 1, oy, ox);
-      p.img_out[((size_t)b * 3 + ch) * plane + rem] = up + rgb[ch];
+      o3[ch] = up + rgb[ch];
+    }
+    if (p.u8_out) {
+      compose_pixel(p.u8_img, p.u8_mask, p.u8_out, pixel, o3[0], o3[1], o3[2]);
+    } else {
+#pragma unroll
+      for (int ch = 0; ch < 3; ++ch) p.img_out[((size_t)b * 3 + ch) * plane + rem] = o3[ch];
     }
   }
 }
@@ -1586,13 +1736,7 @@ struct PrePostArgs {
   unsigned nquads;             // N * R * R / 4
   unsigned plane;              // R * R
 };
-MIGAN_DEVICE MIGAN_INLINE float unit_image(unsigned b) {
-  // demo.py:61: torch.Tensor(img).float() * 2 / 255 - 1, three fp32 roundings in that order
-  float v = (float)b;
-  v = v * 2.0f;
-  v = v / 255.0f;
-  return v - 1.0f;
-}
+#ifndef MIGAN_TEMPLATE_KERNELS_ONLY
 MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, 2) pack_input_kernel(const PrePostArgs p) {
   const unsigned q = blockIdx.x * kThreads + threadIdx.x;
   if (q >= p.nquads) return;
@@ -1632,12 +1776,7 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, 2) compose_output_kernel(const PrePos
   unsigned char rgb[12], o[12];
 #pragma unroll
   for (int i = 0; i < 4; ++i) { rgb[i] = (unsigned char)(w0 >> (8 * i)); rgb[4 + i] = (unsigned char)(w1 >> (8 * i)); rgb[8 + i] = (unsigned char)(w2 >> (8 * i)); }
-  auto to_u8 = [](float v) {
-    // demo.py:135-136: (y * 0.5 + 0.5).clamp(0, 1) * 255 -> .to(torch.uint8) (truncation)
-    float t = v * 0.5f + 0.5f;                       // y * 0.5 is exact, so a contracted FMA rounds identically
-    t = fminf(fmaxf(t, 0.0f), 1.0f);
-    return (unsigned char)(int)(t * 255.0f);
-  };
+  auto to_u8 = [](float v) { return unit_to_u8(v); };
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const bool keep = ((mw >> (8 * i)) & 0xffu) == 255u;
@@ -1651,6 +1790,7 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, 2) compose_output_kernel(const PrePos
   for (int wd = 0; wd < 3; ++wd)
     op[wd] = (unsigned)o[4 * wd] | ((unsigned)o[4 * wd + 1] << 8) | ((unsigned)o[4 * wd + 2] << 16) | ((unsigned)o[4 * wd + 3] << 24);
 }
+#endif  // MIGAN_TEMPLATE_KERNELS_ONLY
 
 
 }  // namespace migan

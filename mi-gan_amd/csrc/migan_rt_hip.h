@@ -60,6 +60,12 @@ typedef hipEvent_t event_t;
 inline const char* backend_name() { return "hip:gfx950"; }
 inline std::string error_string(int rc) { return hipGetErrorString((hipError_t)rc); }
 inline int set_device(int dev) { return (int)hipSetDevice(dev); }
+inline int get_device(int* dev) { return (int)hipGetDevice(dev); }
+inline int stream_create(stream_t* s) { return (int)hipStreamCreateWithFlags(s, hipStreamNonBlocking); }
+inline int stream_destroy(stream_t s) { return (int)hipStreamDestroy(s); }
+// event used only to order streams (no timestamps)
+inline int event_create_sync(event_t* e) { return (int)hipEventCreateWithFlags(e, hipEventDisableTiming); }
+inline int stream_wait_event(stream_t s, event_t e) { return (int)hipStreamWaitEvent(s, e, 0); }
 inline int allow_dynamic_lds(const void* fn, size_t bytes) {
   return (int)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }

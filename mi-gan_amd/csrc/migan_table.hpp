@@ -1,0 +1,67 @@
+// Table of sepconv_kernel instantiations.  The product library compiles one translation unit per
+// (GEMM variant, activation storage format) slice (migan_k_g*s*.hip, in parallel); the CPU test harness
+// includes all slices into its single translation unit.  Needs migan_kernels.hpp.
+#pragma once
+
+namespace migan {
+
+typedef void (*SepKernelFn)(const SepArgs);
+
+struct KernelEntry {
+  int mode, MT, NT, KC;
+  bool fromrgb;
+  int NI, MINW;
+  bool maing, persist;
+  int gemmv;
+  bool torgb;
+  int stv;
+  SepKernelFn fn;
+  const char* name;     // the symbol as rocprofv3 prints it
+};
+
+#define MIGAN_K(MODE, MT, NT, KC, RGB, NI, MINW, MAING, PERSIST, GEMMV, TORGB, STV)                                              \
+  {MODE, MT, NT, KC, RGB, NI, MINW, MAING, PERSIST, GEMMV, TORGB, STV,                                                           \
+   sepconv_kernel<MODE, MT, NT, KC, RGB, NI, MINW, MAING, PERSIST, GEMMV, TORGB, STV>,                                            \
+   "migan::sepconv_kernel<" #MODE ", " #MT ", " #NT ", " #KC ", " #RGB ", " #NI ", " #MINW ", " #MAING ", " #PERSIST ", " #GEMMV ", " #TORGB ", " #STV ">"}
+
+// Every tile geometry the host plan can pick (choose_geo), for one GEMM variant G and one storage format S.
+//   MODE 0 plain / 2 FIR-up / 3 pointwise GEMM (second half of FIR-down layers); MT x NT GEMM tile; KC channels per K chunk;
+//   RGB fused FromRGB; NI prefetch items; MINW workgroups per CU the kernel is built for; MAING compile-time 8x16 tiles;
+//   PERSIST workgroups walk several tiles; TORGB fused ToRGB tail.
+#define MIGAN_GEOMETRIES(G, S)                                                                                                   \
+  /* plain layers: main 8x16 tiles (NI 6) and small-resolution multi-image tiles (NI 9) */                                      \
+  MIGAN_K(0, 128, 128, 32, false, 6, 2, true, false, G, false, S), MIGAN_K(0, 128, 128, 32, false, 9, 2, false, false, G, false, S), \
+  MIGAN_K(0, 128, 64, 32, false, 6, 2, true, false, G, false, S), MIGAN_K(0, 128, 64, 32, false, 9, 2, false, false, G, false, S),   \
+  MIGAN_K(0, 128, 64, 32, false, 6, 2, true, true, G, false, S),                                                                 \
+  /* first encoder layer: fused FromRGB */                                                                                       \
+  MIGAN_K(0, 128, 128, 32, true, 6, 2, true, false, G, false, S), MIGAN_K(0, 128, 128, 32, true, 9, 2, false, false, G, false, S),   \
+  MIGAN_K(0, 128, 64, 32, true, 6, 2, true, false, G, false, S), MIGAN_K(0, 128, 64, 32, true, 9, 2, false, false, G, false, S),     \
+  MIGAN_K(0, 128, 64, 32, true, 6, 2, true, true, G, false, S),                                                                  \
+  /* plain layers whose epilogue also produces the running RGB image (CO == NT) */                                              \
+  MIGAN_K(0, 128, 128, 32, false, 6, 2, true, false, G, true, S), MIGAN_K(0, 128, 128, 32, false, 9, 2, false, false, G, true, S),   \
+  MIGAN_K(0, 128, 64, 32, false, 6, 2, true, false, G, true, S), MIGAN_K(0, 128, 64, 32, false, 9, 2, false, false, G, true, S),     \
+  MIGAN_K(0, 64, 256, 32, false, 4, 2, true, false, G, true, S),                                                                 \
+  /* FIR-up layers */                                                                                                            \
+  MIGAN_K(2, 128, 128, 32, false, 6, 2, true, false, G, false, S), MIGAN_K(2, 128, 128, 32, false, 9, 2, false, false, G, false, S), \
+  MIGAN_K(2, 128, 64, 32, false, 6, 2, true, false, G, false, S), MIGAN_K(2, 128, 64, 32, false, 9, 2, false, false, G, false, S),   \
+  MIGAN_K(2, 128, 64, 32, false, 6, 2, true, true, G, false, S),                                                                 \
+  /* pointwise GEMM: second half of FIR-down layers */                                                                          \
+  MIGAN_K(3, 128, 128, 32, false, 4, 2, true, false, G, false, S), MIGAN_K(3, 128, 128, 32, false, 4, 2, false, false, G, false, S), \
+  MIGAN_K(3, 128, 128, 32, false, 4, 2, true, true, G, false, S),                                                                \
+  MIGAN_K(3, 128, 64, 32, false, 4, 2, true, false, G, false, S), MIGAN_K(3, 128, 64, 32, false, 4, 2, false, false, G, false, S)
+
+// 16-channel K chunks (f16x2 GEMM only): half the K-loop LDS and prefetch registers of the 32-channel tiles, built for
+// 3 or 4 workgroups per CU -- the 64-output-channel layers at 512x512 (encoder first layer, last FIR-up layer, last plain
+// layer + ToRGB), which are latency- / issue-bound rather than matrix-bound.
+#define MIGAN_GEOMETRIES_KC16(S, W)                                                                                              \
+  MIGAN_K(0, 128, 64, 16, false, 3, W, true, false, 2, true, S), MIGAN_K(0, 128, 64, 16, false, 3, W, true, false, 2, false, S),   \
+  MIGAN_K(0, 128, 64, 16, false, 3, W, true, true, 2, false, S),                                                                 \
+  MIGAN_K(0, 128, 64, 16, true, 3, W, true, false, 2, false, S), MIGAN_K(0, 128, 64, 16, true, 3, W, true, true, 2, false, S),     \
+  MIGAN_K(2, 128, 64, 16, false, 3, W, true, false, 2, false, S), MIGAN_K(2, 128, 64, 16, false, 3, W, true, true, 2, false, S)
+
+struct KernelSlice {
+  const KernelEntry* entries;
+  int n;
+};
+
+}  // namespace migan

@@ -16,6 +16,23 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIBNAME = "libmigan_hip.so"
 
 MIGAN_OK, MIGAN_EINVAL, MIGAN_ESTATE, MIGAN_ERUNTIME, MIGAN_EUNSUPPORTED = 0, 1, 2, 3, 4
+# activation storage formats (MIGAN_DTYPE_*) and GEMM variants (MIGAN_GEMM_*) of include/migan_hip.h
+DTYPES = {"f32": 0, "fp32": 0, "float32": 0, "bf16": 1, "bfloat16": 1, "f16": 2, "fp16": 2, "float16": 2}
+DTYPE_NAMES = {0: "f32", 1: "bf16", 2: "f16"}
+GEMMS = {"default": -1, "f32": 0, "bf16x3": 1, "f16x2": 2}
+GEMM_NAMES = {0: "f32", 1: "bf16x3", 2: "f16x2"}
+
+
+def dtype_code(dtype) -> int:
+    """'f32' | 'bf16' | 'f16' | a MIGAN_DTYPE_* int | anything whose str() ends in one of those names (torch.bfloat16)"""
+    if isinstance(dtype, int):
+        if dtype not in DTYPE_NAMES:
+            raise ValueError(f"unknown activation dtype code {dtype}")
+        return dtype
+    key = str(dtype).split(".")[-1].lower()
+    if key not in DTYPES:
+        raise ValueError(f"activation dtype must be one of f32 / bf16 / f16, got {dtype!r}")
+    return DTYPES[key]
 
 
 class MiganError(RuntimeError):
@@ -34,12 +51,15 @@ class SepConvDesc(C.Structure):
         "x", "y", "skip", "conv1_weight", "conv1_bias", "conv2_weight", "noise_const", "noise_strength",
         "fromrgb_weight", "fromrgb_bias", "torgb_weight", "torgb_bias", "img_prev", "img_out")] + [
         (n, C.c_int) for n in ("batch", "cin", "cout", "res_in", "down", "up")] + [
-        ("scratch", C.c_void_p), ("scratch_bytes", C.c_size_t), ("wsplit", C.c_void_p), ("wsplit_bytes", C.c_size_t)]
+        ("scratch", C.c_void_p), ("scratch_bytes", C.c_size_t), ("wsplit", C.c_void_p), ("wsplit_bytes", C.c_size_t)] + [
+        (n, C.c_int) for n in ("gemm", "dtype", "width_in")]
 
 
 EXPORTS = (
-    "migan_create", "migan_destroy", "migan_num_weights", "migan_weight_info", "migan_set_weight",
-    "migan_commit", "migan_workspace_bytes", "migan_forward", "migan_num_launches", "migan_launch_info",
+    "migan_create", "migan_destroy", "migan_set_gemm", "migan_get_gemm", "migan_assume_static_weights", "migan_set_streams",
+    "migan_num_weights", "migan_weight_info", "migan_set_weight",
+    "migan_commit", "migan_workspace_bytes", "migan_forward", "migan_workspace_bytes_hw", "migan_forward_hw", "migan_forward_u8",
+    "migan_num_launches", "migan_launch_info",
     "migan_forward_timed", "migan_set_debug", "migan_debug_tensor", "migan_sepconv_forward",
     "migan_pack_input", "migan_compose_output",
     "migan_last_error", "migan_backend", "migan_gemm_variant", "migan_version",
@@ -80,6 +100,13 @@ class MiganLib:
         vp, ci = C.c_void_p, C.c_int
         L.migan_create.argtypes = [ci, ci, ci, C.POINTER(vp)]
         L.migan_destroy.argtypes = [vp]
+        L.migan_set_gemm.argtypes = [vp, ci]
+        L.migan_get_gemm.argtypes = [vp, C.POINTER(ci)]
+        L.migan_assume_static_weights.argtypes = [vp, ci]
+        L.migan_set_streams.argtypes = [vp, ci]
+        L.migan_workspace_bytes_hw.argtypes = [vp, ci, ci, ci, C.POINTER(C.c_size_t)]
+        L.migan_forward_hw.argtypes = [vp, vp, vp, ci, ci, ci, vp, C.c_size_t, vp]
+        L.migan_forward_u8.argtypes = [vp, vp, vp, vp, ci, vp, C.c_size_t, vp]
         L.migan_num_weights.argtypes = [vp, C.POINTER(ci)]
         L.migan_weight_info.argtypes = [vp, ci, C.POINTER(C.c_char_p), C.POINTER(C.c_int64), C.POINTER(ci), C.POINTER(ci)]
         L.migan_set_weight.argtypes = [vp, C.c_char_p, vp, C.POINTER(C.c_int64), ci]
@@ -150,7 +177,8 @@ class MiganLib:
     def sepconv_forward(self, stream: int = 0, **kw) -> None:
         d = SepConvDesc()
         for f, _ in SepConvDesc._fields_:
-            setattr(d, f, kw.pop(f, None if f not in ("batch", "cin", "cout", "res_in", "down", "up", "scratch_bytes", "wsplit_bytes") else 0))
+            setattr(d, f, kw.pop(f, None if f not in ("batch", "cin", "cout", "res_in", "down", "up", "scratch_bytes", "wsplit_bytes",
+                                                      "gemm", "dtype", "width_in") else (-1 if f == "gemm" else 0)))
         if kw:
             raise TypeError(f"unknown sepconv fields: {sorted(kw)}")
         d.down = d.down or 1
@@ -161,11 +189,28 @@ class MiganLib:
 class MiganHandle:
     """RAII wrapper of ``migan_handle*`` (one Generator(resolution) instance)."""
 
-    def __init__(self, lib: MiganLib, resolution: int, device: int = 0):
+    def __init__(self, lib: MiganLib, resolution: int, device: int = 0, dtype=0):
         self.lib = lib
         self._h = C.c_void_p()
-        lib.check(lib.lib.migan_create(int(resolution), 0, int(device), C.byref(self._h)))
+        self.dtype = dtype_code(dtype)
+        lib.check(lib.lib.migan_create(int(resolution), self.dtype, int(device), C.byref(self._h)))
         self.resolution = int(resolution)
+
+    # -- per-handle options
+    def set_gemm(self, variant) -> None:
+        code = GEMMS[variant] if isinstance(variant, str) else int(variant)
+        self.lib.check(self.lib.lib.migan_set_gemm(self._h, code))
+
+    def gemm(self) -> str:
+        v = C.c_int()
+        self.lib.check(self.lib.lib.migan_get_gemm(self._h, C.byref(v)))
+        return GEMM_NAMES[v.value]
+
+    def assume_static_weights(self, on: bool) -> None:
+        self.lib.check(self.lib.lib.migan_assume_static_weights(self._h, 1 if on else 0))
+
+    def set_streams(self, n: int) -> None:
+        self.lib.check(self.lib.lib.migan_set_streams(self._h, int(n)))
 
     def close(self) -> None:
         if getattr(self, "_h", None) is not None and self._h.value:
@@ -205,6 +250,19 @@ class MiganHandle:
     def forward(self, x_ptr: int, y_ptr: int, batch: int, ws_ptr: int, ws_bytes: int, stream: int = 0) -> None:
         self.lib.check(self.lib.lib.migan_forward(self._h, C.c_void_p(x_ptr), C.c_void_p(y_ptr), int(batch),
                                                   C.c_void_p(ws_ptr), C.c_size_t(ws_bytes), C.c_void_p(stream)))
+
+    def workspace_bytes_hw(self, batch: int, height: int, width: int) -> int:
+        n = C.c_size_t()
+        self.lib.check(self.lib.lib.migan_workspace_bytes_hw(self._h, int(batch), int(height), int(width), C.byref(n)))
+        return int(n.value)
+
+    def forward_hw(self, x_ptr: int, y_ptr: int, batch: int, height: int, width: int, ws_ptr: int, ws_bytes: int, stream: int = 0) -> None:
+        self.lib.check(self.lib.lib.migan_forward_hw(self._h, C.c_void_p(x_ptr), C.c_void_p(y_ptr), int(batch), int(height), int(width),
+                                                     C.c_void_p(ws_ptr), C.c_size_t(ws_bytes), C.c_void_p(stream)))
+
+    def forward_u8(self, img_ptr: int, mask_ptr: int, out_ptr: int, batch: int, ws_ptr: int, ws_bytes: int, stream: int = 0) -> None:
+        self.lib.check(self.lib.lib.migan_forward_u8(self._h, C.c_void_p(img_ptr), C.c_void_p(mask_ptr), C.c_void_p(out_ptr), int(batch),
+                                                     C.c_void_p(ws_ptr), C.c_size_t(ws_bytes), C.c_void_p(stream)))
 
     def forward_timed(self, x_ptr: int, y_ptr: int, batch: int, ws_ptr: int, ws_bytes: int, stream: int = 0) -> List[float]:
         n = len(self.launches())

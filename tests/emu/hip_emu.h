@@ -274,6 +274,10 @@ struct event_t {
 inline const char* backend_name() { return "emu:cpu-fibers (test only)"; }
 inline std::string error_string(int rc) { return "emulator error " + std::to_string(rc); }
 inline int set_device(int) { return 0; }
+inline int get_device(int* dev) { *dev = 0; return 0; }
+// the emulator executes every launch synchronously, in enqueue order: streams and ordering events are no-ops
+inline int stream_create(stream_t* s) { *s = reinterpret_cast<stream_t>(0x1); return 0; }
+inline int stream_destroy(stream_t) { return 0; }
 inline int allow_dynamic_lds(const void*, size_t) { return 0; }
 
 template <class Args>
@@ -302,12 +306,14 @@ inline int event_create(event_t* e) {
   e->p = new std::chrono::steady_clock::time_point();
   return 0;
 }
+inline int event_create_sync(event_t* e) { e->p = nullptr; return 0; }
 inline int event_destroy(event_t e) {
   delete e.p;
   return 0;
 }
+inline int stream_wait_event(stream_t, event_t) { return 0; }
 inline int event_record(event_t e, stream_t) {
-  *e.p = std::chrono::steady_clock::now();
+  if (e.p) *e.p = std::chrono::steady_clock::now();
   return 0;
 }
 inline int event_elapsed(float* ms, event_t a, event_t b) {

@@ -4,6 +4,25 @@
 
 #include "../../mi-gan_amd/csrc/migan_kernels.hpp"
 #include "../../mi-gan_amd/csrc/comodgan_kernels.hpp"
+#include "../../mi-gan_amd/csrc/migan_table.hpp"
+// every slice of the sepconv_kernel table (the product compiles one translation unit per slice)
+#define MIGAN_SLICE_G 0
+#define MIGAN_SLICE_S 0
+#include "../../mi-gan_amd/csrc/migan_k_slice.inc"
+#undef MIGAN_SLICE_G
+#define MIGAN_SLICE_G 1
+#include "../../mi-gan_amd/csrc/migan_k_slice.inc"
+#undef MIGAN_SLICE_G
+#define MIGAN_SLICE_G 2
+#include "../../mi-gan_amd/csrc/migan_k_slice.inc"
+#undef MIGAN_SLICE_S
+#define MIGAN_SLICE_S 1
+#include "../../mi-gan_amd/csrc/migan_k_slice.inc"
+#undef MIGAN_SLICE_S
+#define MIGAN_SLICE_S 2
+#include "../../mi-gan_amd/csrc/migan_k_slice.inc"
+#undef MIGAN_SLICE_S
+#undef MIGAN_SLICE_G
 #include "../../mi-gan_amd/csrc/migan_host.hpp"
 #include "../../mi-gan_amd/csrc/comodgan_host.hpp"
 

@@ -159,7 +159,13 @@ def test_bad_arguments_are_rejected(lib):
                             batch=1, cin=48, cout=64, res_in=16)          # cin not a multiple of 32
     with pytest.raises(ValueError):
         lib.sepconv_forward(x=ptr(a), y=ptr(a), conv1_weight=ptr(a), conv1_bias=ptr(a), conv2_weight=ptr(a),
-                            batch=1, cin=64, cout=64, res_in=12)          # not a power of two
+                            batch=1, cin=64, cout=64, res_in=0)           # empty image
+    with pytest.raises(ValueError):
+        lib.sepconv_forward(x=ptr(a), y=ptr(a), conv1_weight=ptr(a), conv1_bias=ptr(a), conv2_weight=ptr(a),
+                            batch=1, cin=64, cout=64, res_in=14, width_in=9, down=2, scratch=ptr(a), scratch_bytes=a.nbytes)   # odd size, down=2
+    with pytest.raises(ValueError):
+        lib.sepconv_forward(x=ptr(a), y=ptr(a), conv1_weight=ptr(a), conv1_bias=ptr(a), conv2_weight=ptr(a),
+                            batch=1, cin=64, cout=64, res_in=16, dtype=1)   # 16-bit storage without the f16x2 weight planes
     with pytest.raises(ValueError, match="scratch"):
         lib.sepconv_forward(x=ptr(a), y=ptr(a), conv1_weight=ptr(a), conv1_bias=ptr(a), conv2_weight=ptr(a),
                             batch=1, cin=64, cout=64, res_in=16, down=2)   # down=2 without scratch
