@@ -1,28 +1,35 @@
 #!/usr/bin/env python3
-"""Benchmark of the north-star path: images/sec of the migan-512 generator forward, batch 32 per
-GPU, fp32, on MI355X -- BASELINE.json's metric/config.
+"""Benchmark of the north-star path: images/sec of the migan-512 generator forward, batch 32 per GPU, fp32, on MI355X --
+BASELINE.json's metric/config.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          # N > 1: spawns its N ranks itself (one process per GPU)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-        --master-port P bench.py --gpus N --steps K --warmup W
+        --master-port P bench.py --gpus N --steps K --warmup W          # or is launched as N ranks (RANK / WORLD_SIZE in the env)
 
-A "step" is one Generator.forward over one synthetic batch already resident in HBM (input tensor on
-device -> output tensor on device).  For N > 1 every rank runs its own batch of 32 (weak scaling:
-BASELINE config 4 = 256 images over 8 GPUs) and each step ends with the RCCL all-gather of the
-output shards, inside the timed region.  Rank 0 prints ONE JSON line.
+A "step" is one Generator.forward over one synthetic batch already resident in HBM (input tensor on device -> output
+tensor on device).  For N > 1 every rank runs its own batch of 32 (weak scaling: BASELINE configs[3] = 256 images over 8
+GPUs) and each step ends with the RCCL all-gather of the output shards, inside the timed region.  Rank 0 prints ONE JSON
+line; it exits non-zero if the number of ranks that took part differs from --gpus.
+
+Other workloads behind the same protocol / JSON schema:
+    --resolution 256 --dtype bf16      BASELINE configs[1] (16-bit activation storage)
+    --model comodgan-512 --batch 16    BASELINE configs[4]
+The default N = 1 run appends them as "secondary" (and the exact-fp32-MFMA variant of the primary workload as
+"value_exact_f32"), so that one driver run times everything; --no-secondary skips that.
 
 Extra objects on the line:
-  roofline     dominant kernel (largest share of GPU time), measured live with hipEvent pairs around
-               every launch on the launch stream: achieved = algorithmic flops (or bytes) of its
-               launches / their summed duration, against the MI355X peak of the binding resource.
-  cpu_baseline the torch-CPU port of the reference module (oracle/migan_torch_cpu.py; the reference
-               itself is Python and is not present on the GPU box) timed on the host cores on a small
-               sample of the same inputs -- reported, not the target.
+  roofline     dominant kernel (largest share of GPU time), measured live with hipEvent pairs around every launch on the
+               launch stream (one stream, whole-batch launches): achieved = algorithmic flops (or bytes) of its launches /
+               their summed duration, against the MI355X peak of the binding resource.
+  cpu_baseline the torch-CPU port of the reference module (oracle/*_torch_cpu.py / comodgan_oracle.py; the reference itself
+               is Python and is not present on the GPU box) timed on the host cores on a small sample of the same inputs --
+               reported, not the target.
 """
 import argparse
 import importlib
 import json
 import os
+import socket
 import sys
 import time
 
@@ -42,22 +49,43 @@ MFMA_PRODUCTS = {"f32": None, "bf16x3": 6.0, "f16x2": 3.0}
 GEMM_TEXT = {"f32": "1x1 convs on exact fp32 MFMA",
              "bf16x3": "1x1 convs on bf16x3-split MFMA (6 bf16 products per fp32 product, fp32 accumulate)",
              "f16x2": "1x1 convs on f16x2-split MFMA (3 fp16 products per fp32 product on scaled operands, fp32 accumulate)"}
+BASELINE_CONFIG = {("migan", 512, "f32"): "BASELINE configs[2]", ("migan", 256, "bf16"): "BASELINE configs[1]",
+                   ("comodgan", 512, "f32"): "BASELINE configs[4]"}
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--resolution", type=int, default=512)
-    ap.add_argument("--batch", type=int, default=32, help="images per GPU per step")
+    ap.add_argument("--model", type=str, default="migan-512", help="migan-<R> | comodgan-<R>")
+    ap.add_argument("--resolution", type=int, default=0, help="overrides the resolution in --model")
+    ap.add_argument("--batch", type=int, default=0, help="images per GPU per step (default 32, comodgan 16)")
+    ap.add_argument("--dtype", type=str, default="f32", choices=["f32", "bf16", "f16"],
+                    help="activation storage between layers (f32 = the reference's precision; bf16 = BASELINE configs[1])")
+    ap.add_argument("--gemm", type=str, default="f16x2", choices=["f16x2", "bf16x3", "f32"])
+    ap.add_argument("--streams", type=int, default=2, choices=[1, 2], help="sub-batches / HIP streams per forward (migan)")
     ap.add_argument("--cpu-images", type=int, default=4, help="sample size of the CPU baseline (0 = skip)")
     ap.add_argument("--no-gather", action="store_true", help="N>1: skip the output all-gather")
+    ap.add_argument("--no-secondary", action="store_true", help="N=1 default run: skip the secondary workloads")
     ap.add_argument("--cpu-threads", type=int, default=16,
                     help="threads of the CPU baseline (0 = all logical cores); 16 is the fastest setting measured for this\n"
                          "graph of small oneDNN convs on the 256-thread GPU-box host (8: 1.04, 16: 0.94, 32: 1.07, 64: 1.72, 128: 4.4 s/img)")
     ap.add_argument("--dump-layers", type=str, default="", help="write per-launch hipEvent durations to this JSON file")
-    return ap.parse_args()
+    ap.add_argument("--backend", type=str, default="nccl", choices=["nccl", "gloo"], help="gloo: only with --dry (CPU box)")
+    ap.add_argument("--dry", action="store_true",
+                    help="exercise rank spawning, the process group, the output gather and the JSON line without a GPU: the forward\n"
+                         "is replaced by a copy (tests only; the line says so and carries no throughput claim)")
+    return ap.parse_args(argv)
+
+
+def split_model(args):
+    name, _, r = args.model.partition("-")
+    if name not in ("migan", "comodgan") or not r.isdigit():
+        raise SystemExit(f"--model must be migan-<R> or comodgan-<R>, got {args.model}")
+    res = args.resolution or int(r)
+    batch = args.batch or (16 if name == "comodgan" else 32)
+    return name, res, batch
 
 
 def roofline_from_launches(launches, ms_rounds, batch, gemm="f32"):
@@ -93,12 +121,15 @@ def roofline_from_launches(launches, ms_rounds, batch, gemm="f32"):
         "kernel": name, "launches": g["n"], "avg_launch_ms": round(g["ms"] / g["n"], 4),
         "share_of_gpu_time": round(g["ms"] / total_ms, 4),
         "alg_per_launch": {"mfma_flop": g["mfma"] / g["n"], "bytes": g["bytes"] / g["n"]},
+        "measured": "hipEvent pair around every launch, one stream, whole-batch launches (per-launch durations are not defined "
+                    "while two sub-batches share the GPU)",
         "whole_forward": {
             "sum_kernel_ms": round(total_ms, 4),
             "mfma_tflops": round(tot_mfma / (total_ms * 1e-3) / 1e12, 3),
             "mfma_frac": round(tot_mfma / (total_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
             "hbm_gbs": round(tot_bytes / (total_ms * 1e-3) / 1e9, 1),
             "hbm_frac": round(tot_bytes / (total_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
+            "alg_bytes": tot_bytes, "alg_mfma_flop": tot_mfma,
         },
         "per_kernel": {k: {"ms": round(v["ms"], 4), "launches": v["n"],
                            "mfma_tflops": round(v["mfma"] / (v["ms"] * 1e-3) / 1e12, 2) if v["ms"] > 0 else 0.0,
@@ -108,40 +139,115 @@ def roofline_from_launches(launches, ms_rounds, batch, gemm="f32"):
     return roof
 
 
-def main():
-    args = parse()
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False (no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
-    if args.gpus != world and rank == 0:
-        print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; reporting n_gpus={world}", file=sys.stderr)
+def attach_traffic(roof, path_rel, applies):
+    """HBM bytes per launch of the dominant kernel from the PMC passes of this same command (rocprofv3 --pmc FETCH_SIZE /
+    WRITE_SIZE in separate runs; scripts/pmc_traffic.py applies the guide's KiB unit and gfx950 x2 read correction),
+    committed under profiles/.  A kernel symbol that is not in the file is reported, not silently dropped."""
+    path = os.path.join(ROOT, path_rel)
+    if not applies:
+        roof["traffic_note"] = "no PMC traffic file for this configuration"
+        return
+    if not os.path.exists(path):
+        roof["traffic_note"] = f"{path_rel} not found"
+        return
+    try:
+        table = json.load(open(path))
+    except Exception as e:   # pragma: no cover
+        roof["traffic_note"] = f"{path_rel}: {e}"
+        return
+    t = table.get(roof["kernel"])
+    if not t:
+        roof["traffic_note"] = f"kernel symbol not in {path_rel} (stale PMC file: re-run scripts/gpu_round.sh); symbols there: {len(table)}"
+        print(f"bench.py: warning: dominant kernel {roof['kernel']} has no entry in {path_rel}", file=sys.stderr)
+        return
+    roof["traffic"] = round(t["hbm_bytes_per_launch"])
+    roof["traffic_source"] = f"{path_rel} (rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE, avg per launch)"
 
-    pkg = importlib.import_module("mi-gan_amd")
-    R, B = args.resolution, args.batch
-    sd = pkg.synth.make_state_dict(R, seed=0, regime="export")
-    model = pkg.Generator(resolution=R)
+
+# ------------------------------------------------------------------------------------------------------------------------
+# workloads: build(dev) -> dict with step(), timed(), parity_and_cpu(), descriptions
+def build_migan(pkg, args, res, batch, dev, rank):
+    sd = pkg.synth.make_state_dict(res, seed=0, regime="export")
+    model = pkg.Generator(resolution=res, activation_dtype=args.dtype)
     model.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd.items()})
     model = model.to(dev).eval()
+    if args.dtype == "f32":
+        model.set_gemm(args.gemm)
+    model.set_streams(args.streams)
+    # repeated inference on fixed weights: the 16-bit operand planes of the 1x1 weights are prepared once (first warm-up
+    # step), like any weight packing; SURVEY 8d "weights pre-packed (packing excluded)"
+    model.freeze_weights()
     # distinct images per rank (weak scaling), demo.py-style mask+image input
-    x_np = pkg.synth.make_input(B, R, seed=100 + rank, kind="demo")
+    x_np = pkg.synth.make_input(batch, res, seed=100 + rank, kind="demo")
     x = torch.from_numpy(x_np).to(dev)
+    gemm = args.gemm if args.dtype == "f32" else "f16x2"
+
+    def cpu_ref(n, threads, timed_runs=2):
+        from oracle import migan_torch_cpu as torc
+        torch.set_num_threads(threads)
+        storage = None if args.dtype == "f32" else args.dtype
+        ref = torc.generator(x_np[:n], sd, res, storage=storage)                    # warm-up + parity reference
+        times = []
+        for _ in range(timed_runs):
+            c0 = time.perf_counter()
+            torc.generator(x_np[:n], sd, res)
+            times.append(time.perf_counter() - c0)
+        ref32 = ref if storage is None else torc.generator(x_np[:n], sd, res)
+        return ref, ref32, float(np.median(times))
+
+    return dict(model=model, x=x, step=lambda: model(x), timed=lambda: model.forward_timed(x), launches=model.launch_info,
+                gemm=gemm, cpu_ref=cpu_ref, out_shape=(batch, 3, res, res),
+                cpu_desc=f"oracle/migan_torch_cpu.py (torch-CPU/oneDNN op-for-op port of the reference module)",
+                traffic=("profiles/pmc_traffic_latest.json", res == 512 and batch == 32 and args.dtype == "f32" and gemm == "f16x2"),
+                data="synthetic (seeded export-like weights, demo.py-style mask+image batches)",
+                gemm_text=GEMM_TEXT.get(gemm, gemm),
+                extra_cfg={"activation_storage": args.dtype, "streams": args.streams,
+                           "weights": "static (migan_assume_static_weights: 1x1 operand planes prepared once)"})
+
+
+def build_comodgan(pkg, args, res, batch, dev, rank):
+    cs, cm = pkg.comodgan_schema, pkg.comodgan
+    cfg = cs.Config(resolution=res, num_ws=cs.default_num_ws(res))
+    sd = pkg.synth.make_comodgan_state_dict(cfg, 0)
+    model = cm.Generator(cm.Mapping(num_ws=cfg.num_ws), cm.Encoder(resolution=res), cm.Synthesis(resolution=res))
+    model.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd.items()})
+    model = model.to(dev).eval()
+    model.freeze_weights()
+    x_np, z_np = pkg.synth.make_input(batch, res, seed=100 + rank), pkg.synth.make_latent(batch, 512, seed=100 + rank)
+    x, z = torch.from_numpy(x_np).to(dev), torch.from_numpy(z_np).to(dev)
+
+    def cpu_ref(n, threads, timed_runs=1):
+        from oracle import comodgan_oracle as orc
+        torch.set_num_threads(threads)
+        # the batch-wide style normalisation (stylegan.py:139) is cancelled by the demodulation up to its epsilon, so a
+        # sub-batch of the same images is the same computation per image
+        ref = torch.from_numpy(orc.generator(x_np[:n], z_np[:n], sd, res, cfg.num_ws))
+        c0 = time.perf_counter()
+        orc.generator(x_np[:n], z_np[:n], sd, res, cfg.num_ws)
+        return ref, ref, time.perf_counter() - c0
+
+    return dict(model=model, x=x, step=lambda: model(x, z=z, noise_mode="const"), timed=lambda: model.forward_timed(x, z),
+                launches=model.launch_info, gemm="f16x2", cpu_ref=cpu_ref, out_shape=(batch, 3, res, res),
+                cpu_desc="oracle/comodgan_oracle.py (torch-CPU port of the reference module)",
+                traffic=("profiles/pmc_traffic_comodgan_latest.json", res == 512 and batch == 16),
+                data="synthetic (seeded N(0,1) weights, demo.py-style mask+image batches, fixed z, noise_mode=const)",
+                gemm_text="3x3 convs as implicit GEMM on f16x2-split MFMA (3 fp16 products per fp32 product, fp32 accumulate)",
+                extra_cfg={"noise_mode": "const (the reference default 'random' adds a torch.randn of every layer's noise per forward)",
+                           "weights": "static (comodgan_assume_static_weights)"})
+
+
+def run_workload(args, rank, local_rank, world, dist, dev):
+    """warm-up, K timed steps (barrier + synchronize on both sides, max over ranks), roofline and CPU baseline on rank 0"""
+    pkg = importlib.import_module("mi-gan_amd")
+    name, res, batch = split_model(args)
+    wl = (build_comodgan if name == "comodgan" else build_migan)(pkg, args, res, batch, dev, rank)
     gather = world > 1 and not args.no_gather
-    # N > 1: every step's output shards are all-gathered (RCCL) into one of two buffers; the gather of step i
-    # runs on RCCL's stream while step i+1 computes, and every gather completes inside the timed region (fence()).
-    pipe = pkg.distributed.OutputGather((B, 3, R, R), torch.float32, dev) if gather else None
+    # N > 1: every step's output shards are all-gathered (RCCL) into one of two buffers; the gather of step i runs on
+    # RCCL's stream while step i+1 computes, and every gather completes inside the timed region (fence()).
+    pipe = pkg.distributed.OutputGather(wl["out_shape"], torch.float32, dev) if gather else None
 
     def step():
-        y = model(x)
+        y = wl["step"]()
         if gather:
             pipe.submit(y)
         return y
@@ -154,91 +260,228 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def timed_loop(fn, steps):
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            y = fn()
+        fence()
+        el = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([el], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return el, y
+
     with torch.no_grad():
         for _ in range(args.warmup):
             step()
-        fence()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            y = step()
-        fence()
-        elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    ms_per_step = elapsed / args.steps * 1e3
-    value = world * B * args.steps / elapsed
-
-    out = None
-    if rank == 0:
-        # ---- roofline of the dominant kernel: hipEvent pair around every launch (same stream) -----
-        launches = model.launch_info()
-        rounds = []
-        with torch.no_grad():
-            for i in range(3 + min(args.steps, 5)):
-                _, ms = model.forward_timed(x)
-                if i >= 3:
-                    rounds.append(ms)
-        gemm = model._lib.gemm_variant()
-        roof = roofline_from_launches(launches, rounds, B, gemm)
-        # HBM bytes per launch of the dominant kernel from the PMC passes of this same command
-        # (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs; scripts/pmc_traffic.py applies the
-        # guide's KiB unit and gfx950 x2 read correction).  Committed under profiles/; null if absent.
-        tpath = os.path.join(ROOT, "profiles", "pmc_traffic_latest.json")
-        if R == 512 and B == 32 and os.path.exists(tpath):
-            try:
-                t = json.load(open(tpath)).get(roof["kernel"])
-                if t:
-                    roof["traffic"] = round(t["hbm_bytes_per_launch"])
-                    roof["traffic_source"] = "profiles/pmc_traffic_latest.json (rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE, avg per launch)"
-            except Exception:
-                pass
-        if args.dump_layers:
-            med = np.median(np.asarray(rounds), axis=0)
-            with open(args.dump_layers, "w") as f:
-                json.dump([dict(L, ms=float(t)) for L, t in zip(launches, med)], f, indent=1)
-
-        # ---- CPU baseline + parity on the same inputs (rank 0, N = 1 protocol) ---------------------
-        cpu = None
-        parity = None
-        if args.cpu_images > 0 and world == 1:      # the CPU baseline is an N = 1 measurement (rank 0 only)
-            from oracle import migan_torch_cpu as torc
-            n = min(args.cpu_images, B)
-            xs = x_np[:n]
-            torch.set_num_threads(min(args.cpu_threads or (os.cpu_count() or 1), os.cpu_count() or 1))
-            ref = torc.generator(xs, sd, R)                    # warm-up + parity reference
-            times = []
+        elapsed, y = timed_loop(step, args.steps)
+        compute_only = None
+        if gather:                                           # the same steps without the collective, for the record
             for _ in range(2):
-                c0 = time.perf_counter()
-                torc.generator(xs, sd, R)
-                times.append(time.perf_counter() - c0)
-            cpu = {"value": round(n / float(np.median(times)), 4), "unit": "images/sec",
-                   "cores": int(torch.get_num_threads()), "kind": "port",
-                   "sample": f"{n} images of the same migan-{R} batch, fp32, oracle/migan_torch_cpu.py "
-                             f"(torch-CPU/oneDNN op-for-op port of the reference module), median of 2 after 1 warm-up, "
-                             f"host has {os.cpu_count()} logical cores"}
-            parity = float((y[:n].cpu() - ref).abs().max())
+                wl["step"]()
+            el2, _ = timed_loop(wl["step"], args.steps)
+            compute_only = el2 / args.steps * 1e3
+    ms_per_step = elapsed / args.steps * 1e3
+    value = world * batch * args.steps / elapsed
+    ranks_seen = world
+    if world > 1:
+        ids = torch.full((1,), rank, dtype=torch.int64, device=dev)
+        got = torch.empty((world,), dtype=torch.int64, device=dev)
+        dist.all_gather_into_tensor(got, ids)
+        ranks_seen = int(torch.unique(got).numel())
+    if rank != 0:
+        return None
+    # ---- roofline of the dominant kernel: hipEvent pair around every launch (same stream) -----
+    rounds = []
+    with torch.no_grad():
+        for i in range(3 + min(args.steps, 5)):
+            _, ms = wl["timed"]()
+            if i >= 3:
+                rounds.append(ms)
+    launches = wl["launches"]()
+    roof = roofline_from_launches(launches, rounds, batch, wl["gemm"])
+    roof["whole_forward"]["ms_per_step"] = round(ms_per_step, 4)
+    roof["whole_forward"]["hbm_frac_of_timed_step"] = round(roof["whole_forward"]["alg_bytes"] / (ms_per_step * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)
+    attach_traffic(roof, *wl["traffic"])
+    if args.dump_layers:
+        med = np.median(np.asarray(rounds), axis=0)
+        with open(args.dump_layers, "w") as f:
+            json.dump([dict(L, ms=float(t)) for L, t in zip(launches, med)], f, indent=1)
+    # ---- CPU baseline + parity on the same inputs (rank 0, N = 1 protocol) ---------------------
+    cpu = parity = parity32 = None
+    if args.cpu_images > 0 and world == 1:      # the CPU baseline is an N = 1 measurement (rank 0 only)
+        n = min(args.cpu_images if name == "migan" else max(1, args.cpu_images // 4), batch)
+        cores = os.cpu_count() or 1
+        threads = min(args.cpu_threads or cores, cores)
+        ref, ref32, sec = wl["cpu_ref"](n, threads)
+        cpu = {"value": round(n / sec, 4), "unit": "images/sec", "cores": int(threads), "kind": "port",
+               "sample": f"{n} image(s) of the same {name}-{res} batch, fp32, {wl['cpu_desc']}, timed after 1 warm-up, "
+                         f"{threads} threads (the fastest setting measured on this class of host), host has {cores} logical cores"}
+        if name == "migan" and args.model == "migan-512" and args.dtype == "f32" and not args.resolution:
+            if cores > threads:
+                _, _, sec_all = wl["cpu_ref"](1, cores, timed_runs=1)      # the all-cores figure, for the record (1 image, 1 run)
+                cpu["value_all_cores"] = round(1 / sec_all, 4)
+                cpu["all_cores"] = cores
+        parity = float((y[:n].cpu() - ref).abs().max())
+        parity32 = float((y[:n].cpu() - ref32).abs().max())
+    tag = BASELINE_CONFIG.get((name, res, args.dtype), "")
+    out = {
+        "metric": f"images/sec {name}-{res} generator fwd",
+        "value": round(value, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": args.dtype if name == "migan" else "f32", "data": wl["data"],
+        "config": dict({"workload": f"{name}-{res} generator forward, batch={batch} per GPU, {res}x{res}, "
+                                    f"{'fp32' if args.dtype == 'f32' or name != 'migan' else args.dtype + ' activation storage, fp32 arithmetic'}"
+                                    + (f" ({tag})" if tag else ""),
+                        "global_batch": world * batch, "resolution": res, "gemm": wl["gemm_text"],
+                        "parallelism": f"batch-shard x{world}" + (" + RCCL all-gather of every step's outputs, overlapped with the next step" if gather else "")},
+                       **wl["extra_cfg"]),
+        "max_abs_vs_ref": parity,
+        "roofline": roof,
+        "cpu_baseline": cpu,
+        "rccl_ranks": ranks_seen,
+        "device": torch.cuda.get_device_name(local_rank),
+    }
+    if parity32 is not None and args.dtype != "f32" and name == "migan":
+        out["max_abs_vs_ref"] = parity
+        out["max_abs_vs_fp32_ref"] = parity32
+        out["parity_note"] = "max_abs_vs_ref: against the oracle in the same storage mode; max_abs_vs_fp32_ref: against the fp32 reference"
+    if gather:
+        out["compute_only_ms_per_step"] = round(compute_only, 4)
+        out["gather_mb_per_rank_per_step"] = round(float(np.prod(wl["out_shape"])) * 4 / 1e6, 1)
+    return out
 
-        out = {
-            "metric": "images/sec migan-512 generator fwd" if R == 512 else f"images/sec migan-{R} generator fwd",
-            "value": round(value, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic (seeded export-like weights, demo.py-style mask+image batches)",
-            "config": {"workload": f"migan-{R} generator forward, batch={B} per GPU, {R}x{R}, fp32 (BASELINE configs[2])",
-                       "global_batch": world * B, "resolution": R,
-                       "gemm": GEMM_TEXT.get(gemm, gemm),
-                       "parallelism": f"batch-shard x{world}" + (" + RCCL all-gather of every step's outputs, overlapped with the next step" if gather else "")},
-            "max_abs_vs_ref": parity,
-            "roofline": roof,
-            "cpu_baseline": cpu,
-            "device": torch.cuda.get_device_name(local_rank),
-        }
+
+def secondary_line(base_args, **over):
+    """run another workload with the same protocol in this process and return its (trimmed) line"""
+    a = argparse.Namespace(**vars(base_args))
+    a.dump_layers = ""
+    for k, v in over.items():
+        setattr(a, k, v)
+    try:
+        out = run_workload(a, 0, 0, 1, None, torch.device("cuda", 0))
+    except Exception as e:   # a secondary workload must not take the primary line down with it
+        return {"model": a.model, "error": f"{type(e).__name__}: {e}"}
+    out["roofline"].pop("per_kernel", None)
+    return out
+
+
+def dry_run(args, rank, world, dist):
+    """--dry: the launch / rendezvous / gather / JSON plumbing on any backend, without the HIP library"""
+    pkg = importlib.import_module("mi-gan_amd")
+    name, res, batch = split_model(args)
+    dev = torch.device("cpu")
+    shape = (batch, 3, 8, 8)
+    y = torch.full(shape, float(rank))
+    gather = world > 1 and not args.no_gather
+    pipe = pkg.distributed.OutputGather(shape, torch.float32, dev) if gather else None
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        if gather:
+            slot = pipe.submit(y)
+    if gather:
+        pipe.drain()
+        full = pipe.result(slot)
+        assert full.shape[0] == world * batch and float(full[-1, 0, 0, 0]) == world - 1
+    if world > 1:
+        dist.barrier()
+    el = time.perf_counter() - t0
+    ranks_seen = world
+    if world > 1:
+        got = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
+        dist.all_gather(got, torch.tensor([rank], dtype=torch.int64))
+        ranks_seen = len({int(g) for g in got})
+    if rank != 0:
+        return None
+    return {"metric": f"images/sec {name}-{res} generator fwd", "value": 0.0, "unit": "images/sec", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(el / max(1, args.steps) * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": args.dtype, "data": "none (--dry: launch plumbing only, no forward was run)",
+            "config": {"workload": "dry run", "global_batch": world * batch, "parallelism": f"batch-shard x{world}"},
+            "dry": True, "rccl_ranks": ranks_seen, "backend": args.backend}
+
+
+def worker(rank, local_rank, world, args):
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if args.dry:
+        if world > 1:
+            dist.init_process_group(backend=args.backend, rank=rank, world_size=world)
+        out = dry_run(args, rank, world, dist)
+    else:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False (no CPU fallback)")
+        if args.backend != "nccl":
+            raise SystemExit("--backend gloo is for --dry only; GPU runs use nccl (= RCCL on ROCm)")
+        if world > 1 and torch.cuda.device_count() < world and "LOCAL_RANK" not in os.environ:
+            raise SystemExit(f"--gpus {world} but only {torch.cuda.device_count()} GPU(s) are visible")
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
+        if world > 1:
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
+        out = run_workload(args, rank, local_rank, world, dist, dev)
+        name, res, batch = split_model(args)
+        if out is not None and world == 1 and not args.no_secondary and args.model == "migan-512" and not args.resolution \
+                and not args.batch and args.dtype == "f32" and args.gemm == "f16x2":
+            # the default driver run: also time the exact-fp32-MFMA variant of the same workload and the other two
+            # single-GPU BASELINE configs, same protocol
+            ex = secondary_line(args, gemm="f32", cpu_images=0, steps=max(5, args.steps // 2), warmup=3)
+            out["value_exact_f32"] = ex.get("value")
+            out["exact_f32"] = {k: ex.get(k) for k in ("value", "ms_per_step", "error") if k in ex}
+            if "roofline" in ex:
+                out["exact_f32"]["whole_forward"] = ex["roofline"]["whole_forward"]
+                out["exact_f32"]["note"] = ("same workload with the 1x1 convs on v_mfma_f32_32x32x2_f32 (exact fp32 products): the number "
+                                            "comparable to SURVEY's 5 940 images/s fp32-MFMA ceiling")
+            out["secondary"] = [
+                secondary_line(args, model="migan-256", dtype="bf16", steps=max(10, args.steps), cpu_images=2),
+                secondary_line(args, model="comodgan-512", steps=max(5, args.steps // 2), warmup=3, cpu_images=4),
+            ]
+    ok = True
+    if out is not None:
+        if out.get("rccl_ranks") != args.gpus or out.get("n_gpus") != args.gpus:
+            out["error"] = f"--gpus {args.gpus} but {out.get('rccl_ranks')} rank(s) took part (n_gpus {out.get('n_gpus')})"
+            ok = False
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
-    return out
+    return ok
+
+
+def _spawned(local_rank, world, port, argv):
+    os.environ.update(RANK=str(local_rank), LOCAL_RANK=str(local_rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    ok = worker(local_rank, local_rank, world, parse(argv))
+    if not ok:
+        raise SystemExit(3)
+
+
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    args = parse(argv)
+    if "WORLD_SIZE" in os.environ:                        # launched as one of N ranks (torch.distributed.run)
+        world = int(os.environ["WORLD_SIZE"])
+        ok = worker(int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), world, args)
+        if not ok:
+            raise SystemExit(3)
+        return
+    if args.gpus <= 1:
+        if not worker(0, 0, 1, args):
+            raise SystemExit(3)
+        return
+    # --gpus N without a launcher: create the N ranks here, one process per GPU (the reference's own launcher does the same
+    # for training: main.py:27 mp.spawn, lib/utils.py:41-46 init_process_group on tcp://127.0.0.1)
+    import torch.multiprocessing as mp
+    mp.spawn(_spawned, args=(args.gpus, free_port(), argv), nprocs=args.gpus, join=True)
 
 
 if __name__ == "__main__":

@@ -192,6 +192,11 @@ int migan_pack_input(const void* img_hwc_u8, const void* mask_u8, void* x_nchw, 
 int migan_compose_output(const void* y_nchw, const void* img_hwc_u8, const void* mask_u8, void* out_hwc_u8,
                          int batch, int resolution, void* stream);
 
+/* Process-wide tuning knobs, the run-time form of the MIGAN_* environment variables (experiments and tests):
+ * "kc16" (bit mask: 16-channel K chunks for the 64-channel 512x512 layers), "kc16_minw", "wide", "nt256", "persist_min",
+ * "persist_grid", "streams", "stagger", "single_b".  Applies to handles created or re-planned afterwards. */
+int migan_set_tuning(const char* key, int value);
+
 const char* migan_last_error(void);
 /* "hip:gfx950" for the product library. */
 const char* migan_backend(void);

@@ -676,7 +676,7 @@ int comodgan_assume_static_weights(comodgan_handle* h, int on) {
   MIGAN_API_BEGIN
   MIGAN_CHECK(h, MIGAN_EINVAL, "null handle");
   h->static_weights = on != 0;
-  if (!on) h->prepared_ws = nullptr;
+  h->prepared_ws = nullptr;       // every call drops the planes prepared so far: (re-)asserting after an in-place write is the way to invalidate
   MIGAN_API_END
 }
 

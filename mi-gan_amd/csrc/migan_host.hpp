@@ -394,7 +394,7 @@ inline void launch_sepconv(Geo g, const SepArgs& a, rt::stream_t stream) {
   const bool fused_rgb = a.trgb_w != nullptr;
   g.persist = use_persistent(g, a.B, fused_rgb);
   g.torgb = fused_rgb;
-  MIGAN_CHECK(!fused_rgb || (g.mode == MODE_NORMAL && !g.fromrgb && g.nchunks == 1 && g.MINW == 2), MIGAN_EINVAL,
+  MIGAN_CHECK(!fused_rgb || (g.mode == MODE_NORMAL && !g.fromrgb && g.nchunks == 1), MIGAN_EINVAL,
               "ToRGB can only be fused into a plain layer whose output channels fit one column tile");
   if (g.wide) {
     MIGAN_CHECK(a.wsplit != nullptr, MIGAN_EINVAL, "internal: the wide kernel needs the fp16 weight planes");
@@ -1335,6 +1335,27 @@ int migan_prof_layer(int index, unsigned long long out[16]) {
   MIGAN_API_END
 }
 #endif
+
+// Process-wide tuning knobs (the MIGAN_* environment variables, settable at run time for experiments and tests).
+// Affects handles created / re-planned afterwards.
+int migan_set_tuning(const char* key, int value) {
+  MIGAN_API_BEGIN
+  using namespace migan;
+  MIGAN_CHECK(key != nullptr, MIGAN_EINVAL, "null key");
+  Tuning& t = tuning();
+  const std::string k = key;
+  if (k == "kc16") t.kc16 = value;
+  else if (k == "kc16_minw") t.kc16_minw = std::min(4, std::max(2, value));
+  else if (k == "wide") t.wide = value != 0;
+  else if (k == "nt256") t.nt256 = value != 0;
+  else if (k == "persist_min") t.persist_min = std::max(1, value);
+  else if (k == "persist_grid") t.persist_grid = std::max(8, value / 8 * 8);
+  else if (k == "streams") t.streams = value >= 2 ? 2 : 1;
+  else if (k == "stagger") t.stagger = value;
+  else if (k == "single_b") t.force_single_b = value != 0;
+  else throw Error(MIGAN_EINVAL, "unknown tuning key: " + k);
+  MIGAN_API_END
+}
 
 const char* migan_last_error(void) { return migan::last_error_ref().c_str(); }
 const char* migan_backend(void) { return rt::backend_name(); }

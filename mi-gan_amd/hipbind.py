@@ -62,7 +62,7 @@ EXPORTS = (
     "migan_num_launches", "migan_launch_info",
     "migan_forward_timed", "migan_set_debug", "migan_debug_tensor", "migan_sepconv_forward",
     "migan_pack_input", "migan_compose_output",
-    "migan_last_error", "migan_backend", "migan_gemm_variant", "migan_version",
+    "migan_set_tuning", "migan_last_error", "migan_backend", "migan_gemm_variant", "migan_version",
     # include/comodgan_hip.h
     "comodgan_create", "comodgan_destroy", "comodgan_num_weights", "comodgan_weight_info", "comodgan_set_weight",
     "comodgan_commit", "comodgan_workspace_bytes", "comodgan_assume_static_weights", "comodgan_noise_floats", "comodgan_forward",
@@ -120,6 +120,7 @@ class MiganLib:
         L.migan_set_debug.argtypes = [vp, ci]
         L.migan_debug_tensor.argtypes = [vp, ci, C.c_char_p, C.POINTER(C.c_size_t), C.POINTER(C.c_int64)]
         L.migan_sepconv_forward.argtypes = [C.POINTER(SepConvDesc), vp]
+        L.migan_set_tuning.argtypes = [C.c_char_p, ci]
         L.migan_pack_input.argtypes = [vp, vp, vp, ci, ci, vp]
         L.migan_compose_output.argtypes = [vp, vp, vp, vp, ci, ci, vp]
         fp = C.POINTER(C.c_float)
@@ -164,6 +165,9 @@ class MiganLib:
 
     def gemm_variant(self) -> str:
         return self.lib.migan_gemm_variant().decode()
+
+    def set_tuning(self, key: str, value: int) -> None:
+        self.check(self.lib.migan_set_tuning(key.encode(), int(value)))
 
     def pack_input(self, img_ptr: int, mask_ptr: int, x_ptr: int, batch: int, resolution: int, stream: int = 0) -> None:
         self.check(self.lib.migan_pack_input(C.c_void_p(img_ptr), C.c_void_p(mask_ptr), C.c_void_p(x_ptr), int(batch),

@@ -23,7 +23,7 @@ import torch
 import torch.nn as nn
 
 from . import schema
-from .hipbind import MiganError, MiganHandle, MiganLib, load_library
+from .hipbind import DTYPE_NAMES, MiganError, MiganHandle, MiganLib, dtype_code, load_library
 
 # reference class of each node of the module tree, for repr() only
 _NODE_KIND = {
@@ -79,7 +79,10 @@ def _init_tensor(e: schema.Entry) -> torch.Tensor:
 class Generator(nn.Module):
     """MI-GAN inference generator (reference migan_inference.py:355-369) on MI355X."""
 
-    def __init__(self, resolution: int = 256):
+    def __init__(self, resolution: int = 256, activation_dtype="f32"):
+        """resolution: as the reference (:356).  activation_dtype (extension): storage format of the feature maps between
+        layers on the GPU -- "f32" (the reference's precision, <= 1e-3 parity), "bf16" (BASELINE configs[1]) or "f16";
+        parameters, input, output and all arithmetic stay float32 (include/migan_hip.h, MIGAN_DTYPE_*)."""
         super().__init__()
         schema.check_resolution(resolution)                    # ValueError like reference :215-216
         if resolution > schema.MAX_RESOLUTION:
@@ -87,6 +90,10 @@ class Generator(nn.Module):
                 f"resolution {resolution}: feature width {schema.channels(resolution)} is below the 64-channel "
                 "MFMA column tile; supported resolutions are 8..512")
         self.resolution = resolution
+        self._act_dtype = dtype_code(activation_dtype)
+        self._gemm: Optional[str] = None                       # None: the library default (f16x2-split MFMA)
+        self._streams: Optional[int] = None
+        self._frozen = False
         self._names: List[str] = []
         for e in schema.entries(resolution):
             node: nn.Module = self
@@ -115,6 +122,48 @@ class Generator(nn.Module):
     def _invalidate(self) -> None:
         self._dirty = True
 
+    # ------------------------------------------------------------------ options of the MI355X engine (not in the reference)
+    @property
+    def activation_dtype(self) -> str:
+        return DTYPE_NAMES[self._act_dtype]
+
+    def set_activation_dtype(self, dtype) -> "Generator":
+        """'f32' | 'bf16' | 'f16' (or torch.float32 / torch.bfloat16 / torch.float16): see __init__."""
+        code = dtype_code(dtype)
+        if code != self._act_dtype:
+            self._act_dtype = code
+            if self._handle is not None:
+                self._handle.close()
+            self._handle = None
+            self._ws = None
+        return self
+
+    def set_gemm(self, variant: Optional[str]) -> "Generator":
+        """How the 1x1 convolutions are multiplied: 'f16x2' (default: 3 fp16 MFMA products per fp32 product on scaled 2-way
+        split operands), 'bf16x3' (6 bf16 products) or 'f32' (exact fp32 MFMA); all accumulate in fp32 (include/migan_hip.h)."""
+        self._gemm = variant
+        if self._handle is not None:
+            self._handle.set_gemm(variant or "f16x2")
+        return self
+
+    def set_streams(self, n: int) -> "Generator":
+        """2 (default): batches of >= 16 images run as two staggered sub-batches on two HIP streams; 1: one stream."""
+        self._streams = int(n)
+        if self._handle is not None:
+            self._handle.set_streams(self._streams)
+        return self
+
+    def freeze_weights(self, frozen: bool = True) -> "Generator":
+        """Opt-in for repeated inference: promise that no parameter is modified in place from now on, so the per-forward
+        preparation of the 1x1 weights (16-bit operand planes of the split GEMM, 0.13 ms of a 10 ms batch-32 forward) runs
+        once.  load_state_dict / .to() / re-assignment of a parameter are picked up automatically; after an in-place write
+        (``p.data.mul_()``, an optimizer step, a raw-pointer write) call ``freeze_weights()`` again, or
+        ``freeze_weights(False)`` to go back to preparing them every forward (the default: in-place updates always seen)."""
+        self._frozen = bool(frozen)
+        if self._handle is not None:
+            self._handle.assume_static_weights(self._frozen)
+        return self
+
     def _apply(self, fn, *args, **kwargs):
         out = super()._apply(fn, *args, **kwargs)
         self._invalidate()
@@ -142,7 +191,12 @@ class Generator(nn.Module):
         if self._handle is None or self._handle_device != dev:
             if self._handle is not None:
                 self._handle.close()
-            self._handle = MiganHandle(self._lib, self.resolution, dev)
+            self._handle = MiganHandle(self._lib, self.resolution, dev, dtype=self._act_dtype)
+            if self._gemm is not None:
+                self._handle.set_gemm(self._gemm)
+            if self._streams is not None:
+                self._handle.set_streams(self._streams)
+            self._handle.assume_static_weights(self._frozen)
             self._handle_device = dev
             self._bound = None
         tensors = self._tensors()
@@ -160,16 +214,16 @@ class Generator(nn.Module):
             self._dirty = False
         return self._handle
 
-    def _workspace(self, h: MiganHandle, batch: int, device: torch.device) -> torch.Tensor:
-        need = h.workspace_bytes(batch)
+    def _workspace(self, h: MiganHandle, batch: int, device: torch.device, hw: Optional[Tuple[int, int]] = None) -> torch.Tensor:
+        need = h.workspace_bytes(batch) if hw is None else h.workspace_bytes_hw(batch, hw[0], hw[1])
         if self._ws is None or self._ws.device != device or self._ws.numel() < need:
             self._ws = None
             self._ws = torch.empty(need, dtype=torch.uint8, device=device)
         return self._ws
 
-    def _check_input(self, x: torch.Tensor) -> torch.Tensor:
+    def _check_input(self, x: torch.Tensor, any_size: bool = False) -> torch.Tensor:
         r = self.resolution
-        if x.dim() != 4 or x.shape[1] != 4 or x.shape[2] != r or x.shape[3] != r:
+        if x.dim() != 4 or x.shape[1] != 4 or (not any_size and (x.shape[2] != r or x.shape[3] != r)):
             raise RuntimeError(f"expected input of shape [N, 4, {r}, {r}] (mask-0.5, img*mask), got {list(x.shape)}")
         if x.dtype != torch.float32:
             raise RuntimeError(f"Input type ({x.dtype}) and weight type (torch.float32) should be the same")
@@ -188,6 +242,40 @@ class Generator(nn.Module):
         h.forward(x.data_ptr(), y.data_ptr(), n, ws.data_ptr(), ws.numel(), self._stream(x))
         return y
 
+    def forward_any_size(self, x: torch.Tensor) -> torch.Tensor:
+        """Fully convolutional forward (reference README.md:87 asks for ``filter_const`` / ``noise_const`` to be made dynamic):
+        x [N,4,H,W] with H, W multiples of resolution / 4 -> [N,3,H,W].  Each ``noise_const`` is tiled periodically and
+        cropped to its layer's size; H = W = resolution is ``forward``."""
+        x = self._check_input(x, any_size=True)
+        h = self._engine(x)
+        n, hh, ww = x.shape[0], int(x.shape[2]), int(x.shape[3])
+        ws = self._workspace(h, n, x.device, (hh, ww))
+        y = torch.empty((n, 3, hh, ww), dtype=torch.float32, device=x.device)
+        h.forward_hw(x.data_ptr(), y.data_ptr(), n, hh, ww, ws.data_ptr(), ws.numel(), self._stream(x))
+        return y
+
+    def forward_uint8(self, img_u8: torch.Tensor, mask_u8: torch.Tensor) -> torch.Tensor:
+        """scripts/demo.py:56-66 + forward + :135-140 in one call, at network resolution: uint8 image [N,R,R,3] (HWC) and
+        uint8 mask [N,R,R] (255 = known pixel) -> composited uint8 image [N,R,R,3].  preprocess() runs inside the first
+        kernel's tile builder and the post-processing + composition inside the last ToRGB epilogue: no fp32 network input or
+        output tensor exists.  Bit-identical to pipeline.preprocess -> forward -> pipeline.compose."""
+        r = self.resolution
+        if not (img_u8.is_cuda and mask_u8.is_cuda):
+            raise RuntimeError("mi-gan_amd Generator.forward_uint8 needs tensors on an MI355X (HIP) device; there is no CPU path")
+        if img_u8.dtype != torch.uint8 or mask_u8.dtype != torch.uint8:
+            raise RuntimeError("image and mask must be uint8 (np.array of the PIL images, reference demo.py:59-60)")
+        if img_u8.dim() != 4 or tuple(img_u8.shape[1:]) != (r, r, 3) or tuple(mask_u8.shape) != tuple(img_u8.shape[:3]):
+            raise RuntimeError(f"expected image [N,{r},{r},3] and mask [N,{r},{r}], got {list(img_u8.shape)} and {list(mask_u8.shape)}")
+        if img_u8.shape[0] == 0:
+            raise RuntimeError("empty batch")
+        img_u8, mask_u8 = img_u8.contiguous(), mask_u8.contiguous()
+        h = self._engine(img_u8)
+        n = img_u8.shape[0]
+        ws = self._workspace(h, n, img_u8.device)
+        out = torch.empty((n, r, r, 3), dtype=torch.uint8, device=img_u8.device)
+        h.forward_u8(img_u8.data_ptr(), mask_u8.data_ptr(), out.data_ptr(), n, ws.data_ptr(), ws.numel(), self._stream(img_u8))
+        return out
+
     def forward_timed(self, x: torch.Tensor):
         """forward() with a hipEvent pair around every kernel launch: (y, [ms per launch])."""
         x = self._check_input(x)
@@ -202,5 +290,5 @@ class Generator(nn.Module):
         """Per-launch layer / kernel names and algorithmic flops and bytes per image."""
         if self._lib is None:
             self._lib = load_library()
-        h = self._handle or MiganHandle(self._lib, self.resolution, 0)
+        h = self._handle or MiganHandle(self._lib, self.resolution, 0, dtype=self._act_dtype)
         return h.launches()        # kernel names reflect the variants used by the last forward on this handle

@@ -25,6 +25,35 @@ import numpy as np
 SQRT2_F32 = np.float32(np.sqrt(2))        # reference :15, applied as an fp32 multiply :25
 
 
+# --------------------------------------------------------------------------- 16-bit activation storage (BASELINE configs[1])
+def round_storage(x: np.ndarray, storage: Optional[str]) -> np.ndarray:
+    """What a tensor reads back as after being stored in `storage` ('f32' / None: unchanged; 'bf16', 'f16': round to
+    nearest even).  The 16-bit modes of the HIP library (MIGAN_DTYPE_BF16 / _F16, include/migan_hip.h) keep parameters,
+    network input/output, the running RGB image and all arithmetic of the reference (:154-170) in fp32 and round once
+    per stored feature map: every SeparableConv2d output, after the skip add where the block has one (:272, :305)."""
+    if storage in (None, "f32"):
+        return x
+    x32 = np.ascontiguousarray(x, dtype=np.float32)
+    if storage == "bf16":
+        u = x32.view(np.uint32)
+        r = ((u + np.uint32(0x7FFF) + ((u >> np.uint32(16)) & np.uint32(1))) >> np.uint32(16)) << np.uint32(16)
+        out = r.view(np.float32)
+    elif storage == "f16":
+        out = x32.astype(np.float16).astype(np.float32)
+    else:
+        raise ValueError(storage)
+    return out.astype(x.dtype)
+
+
+def noise_plane(noise_const: np.ndarray, h: int, w: int) -> np.ndarray:
+    """noise_const [r,r] at an h x w layer (arbitrary-size forward, reference README.md:87): tiled periodically and
+    cropped; the identity at h = w = r."""
+    r0, r1 = noise_const.shape
+    if (h, w) == (r0, r1):
+        return noise_const
+    return np.tile(noise_const, ((h + r0 - 1) // r0, (w + r1 - 1) // r1))[:h, :w]
+
+
 # --------------------------------------------------------------------------- a1
 def lrelu_agc(x: np.ndarray, alpha: float = 0.2, clamp: float = 256.0) -> np.ndarray:
     """leaky_relu(x, 0.2) * sqrt(2), clamped to +-256  (reference :20-28)."""
@@ -126,14 +155,14 @@ def separable_conv(x: np.ndarray, sd: Dict[str, np.ndarray], prefix: str) -> np.
         x = upsample2d(x, sd[f"{prefix}.upsample.filter.weight"])        # :162-163
     if f"{prefix}.noise_const" in sd:
         # fp32 product first, then the add (reference :166-167)
-        noise = sd[f"{prefix}.noise_const"].astype(dt) * sd[f"{prefix}.noise_strength"].astype(dt)
+        noise = noise_plane(sd[f"{prefix}.noise_const"], x.shape[2], x.shape[3]).astype(dt) * sd[f"{prefix}.noise_strength"].astype(dt)
         x = x + noise
     return lrelu_agc(x)                                                  # :168-169
 
 
 # --------------------------------------------------------------------------- a6/a7
 def encoder(img: np.ndarray, sd: Dict[str, np.ndarray], resolution: int,
-            taps: Optional[dict] = None):
+            taps: Optional[dict] = None, storage: Optional[str] = None):
     """Encoder.forward (reference :235-246) with EncoderBlock.forward (:192-200)."""
     feats = {}
     x = None
@@ -143,8 +172,8 @@ def encoder(img: np.ndarray, sd: Dict[str, np.ndarray], resolution: int,
         if f"{b}.fromrgb.weight" in sd:
             y = lrelu_agc(pointwise(img, sd[f"{b}.fromrgb.weight"], sd[f"{b}.fromrgb.bias"]))  # :194-195
             x = y if x is None else x + y                                 # :196
-        feat = separable_conv(x, sd, f"{b}.conv1")                        # :198
-        x = separable_conv(feat, sd, f"{b}.conv2")                        # :199
+        feat = round_storage(separable_conv(x, sd, f"{b}.conv1"), storage)   # :198
+        x = round_storage(separable_conv(feat, sd, f"{b}.conv2"), storage)   # :199
         feats[res] = feat
         if taps is not None:
             taps[f"{b}.conv1"] = feat
@@ -155,7 +184,7 @@ def encoder(img: np.ndarray, sd: Dict[str, np.ndarray], resolution: int,
 
 # --------------------------------------------------------------------------- a8/a9/a10
 def synthesis(x: np.ndarray, feats: Dict[int, np.ndarray], sd: Dict[str, np.ndarray],
-              resolution: int, taps: Optional[dict] = None) -> np.ndarray:
+              resolution: int, taps: Optional[dict] = None, storage: Optional[str] = None) -> np.ndarray:
     """Synthesis.forward (reference :347-352), SynthesisBlockFirst (:270-279),
     SynthesisBlock (:303-315)."""
     img = None
@@ -165,10 +194,10 @@ def synthesis(x: np.ndarray, feats: Dict[int, np.ndarray], sd: Dict[str, np.ndar
         x = separable_conv(x, sd, f"{b}.conv1")                           # :271 / :304
         if taps is not None:
             taps[f"{b}.conv1"] = x                                        # SeparableConv2d output (pre skip)
-        x = x + feats[res]                                                # :272 / :305
+        x = round_storage(x + feats[res], storage)                        # :272 / :305
         if taps is not None:
             taps[f"{b}.conv1.skip"] = x
-        x = separable_conv(x, sd, f"{b}.conv2")                           # :273 / :306
+        x = round_storage(separable_conv(x, sd, f"{b}.conv2"), storage)   # :273 / :306
         if taps is not None:
             taps[f"{b}.conv2"] = x
         y = pointwise(x, sd[f"{b}.torgb.weight"], sd[f"{b}.torgb.bias"])  # :277 / :312
@@ -184,9 +213,11 @@ def synthesis(x: np.ndarray, feats: Dict[int, np.ndarray], sd: Dict[str, np.ndar
 
 
 def generator(x: np.ndarray, sd: Dict[str, np.ndarray], resolution: int,
-              dtype=np.float32, taps: Optional[dict] = None) -> np.ndarray:
-    """Generator.forward (reference :362-369): x [N,4,R,R] -> img [N,3,R,R]."""
+              dtype=np.float32, taps: Optional[dict] = None, storage: Optional[str] = None) -> np.ndarray:
+    """Generator.forward (reference :362-369): x [N,4,R,R] -> img [N,3,R,R].
+    x may be [N,4,H,W] with H, W multiples of R/4 (arbitrary-size forward, noise_plane above).
+    storage: None / 'f32' = the reference; 'bf16' / 'f16' = the library's 16-bit activation storage modes."""
     x = np.asarray(x, dtype=dtype)
     sd = {k: np.asarray(v) for k, v in sd.items()}
-    h, feats = encoder(x, sd, resolution, taps)
-    return synthesis(h, feats, sd, resolution, taps)
+    h, feats = encoder(x, sd, resolution, taps, storage)
+    return synthesis(h, feats, sd, resolution, taps, storage)

@@ -32,6 +32,33 @@ def _act(x: torch.Tensor) -> torch.Tensor:
     return x.clamp(-256.0, 256.0)
 
 
+def _store(x: torch.Tensor, storage: Optional[str]) -> torch.Tensor:
+    """16-bit activation storage modes of the HIP library (oracle/migan_oracle.py::round_storage): round to nearest even once
+    per stored feature map, everything else fp32."""
+    if storage in (None, "f32"):
+        return x
+    return x.to({"bf16": torch.bfloat16, "f16": torch.float16}[storage]).float()
+
+
+def _zero_insertion_mask(sd, key: str, x: torch.Tensor) -> torch.Tensor:
+    """filter_const (reference :85): 1 at even/even, 0 elsewhere; rebuilt at x's size for the arbitrary-size forward
+    (reference README.md:87)."""
+    fc = sd[key]
+    if fc.shape[-2:] == x.shape[-2:]:
+        return fc
+    m = torch.zeros((1, 1) + tuple(x.shape[-2:]), dtype=x.dtype)
+    m[:, :, 0::2, 0::2] = 1
+    return m
+
+
+def _noise(sd, p: str, x: torch.Tensor) -> torch.Tensor:
+    nc = sd[f"{p}.noise_const"]
+    h, w = x.shape[-2:]
+    if tuple(nc.shape) != (h, w):          # arbitrary-size forward: tiled periodically and cropped
+        nc = nc.repeat((h + nc.shape[0] - 1) // nc.shape[0], (w + nc.shape[1] - 1) // nc.shape[1])[:h, :w]
+    return nc * sd[f"{p}.noise_strength"]
+
+
 def _sepconv(x: torch.Tensor, sd: Dict[str, torch.Tensor], p: str) -> torch.Tensor:
     # reference :154-170
     c = x.shape[1]
@@ -44,18 +71,19 @@ def _sepconv(x: torch.Tensor, sd: Dict[str, torch.Tensor], p: str) -> torch.Tens
     k = f"{p}.upsample.filter.weight"
     if k in sd:                                                  # :98-103
         x = F.interpolate(x, scale_factor=2, mode="nearest")
-        x = x * sd[f"{p}.upsample.filter_const"]
+        x = x * _zero_insertion_mask(sd, f"{p}.upsample.filter_const", x)
         x = F.pad(x, (2, 1, 2, 1))
         x = F.conv2d(x, sd[k], None, groups=x.shape[1])
     k = f"{p}.noise_const"
     if k in sd:                                                  # :165-167
-        x = x.add_(sd[k] * sd[f"{p}.noise_strength"])
+        x = x.add_(_noise(sd, p, x))
     return _act(x)
 
 
 @torch.no_grad()
-def generator(x, sd, resolution: int, taps: Optional[dict] = None) -> torch.Tensor:
-    """x [N,4,R,R] float32 (tensor or ndarray), sd: name -> tensor/ndarray."""
+def generator(x, sd, resolution: int, taps: Optional[dict] = None, storage: Optional[str] = None) -> torch.Tensor:
+    """x [N,4,R,R] float32 (tensor or ndarray; [N,4,H,W] with H, W multiples of R/4 for the arbitrary-size forward),
+    sd: name -> tensor/ndarray.  storage: None / 'f32' = the reference; 'bf16' / 'f16' = 16-bit activation storage."""
     x = torch.as_tensor(np.asarray(x) if not torch.is_tensor(x) else x).float().cpu()
     sd = {k: (v if torch.is_tensor(v) else torch.from_numpy(np.ascontiguousarray(v))).float().cpu()
           for k, v in sd.items()}
@@ -68,8 +96,8 @@ def generator(x, sd, resolution: int, taps: Optional[dict] = None) -> torch.Tens
         if f"{b}.fromrgb.weight" in sd:                          # :193-196
             y = _act(F.conv2d(img_in, sd[f"{b}.fromrgb.weight"], sd[f"{b}.fromrgb.bias"]))
             h = y if h is None else h + y
-        feat = _sepconv(h, sd, f"{b}.conv1")
-        h = _sepconv(feat, sd, f"{b}.conv2")
+        feat = _store(_sepconv(h, sd, f"{b}.conv1"), storage)
+        h = _store(_sepconv(feat, sd, f"{b}.conv2"), storage)
         feats[res] = feat
         if taps is not None:
             taps[f"{b}.conv1"] = feat
@@ -82,16 +110,16 @@ def generator(x, sd, resolution: int, taps: Optional[dict] = None) -> torch.Tens
         h = _sepconv(h, sd, f"{b}.conv1")
         if taps is not None:
             taps[f"{b}.conv1"] = h                               # SeparableConv2d output (pre skip)
-        h = h + feats[res]                                       # :272 / :305
+        h = _store(h + feats[res], storage)                      # :272 / :305
         if taps is not None:
             taps[f"{b}.conv1.skip"] = h
-        h = _sepconv(h, sd, f"{b}.conv2")
+        h = _store(_sepconv(h, sd, f"{b}.conv2"), storage)
         if taps is not None:
             taps[f"{b}.conv2"] = h
         y = F.conv2d(h, sd[f"{b}.torgb.weight"], sd[f"{b}.torgb.bias"])
         if img is not None:                                      # :308-313
             u = F.interpolate(img, scale_factor=2, mode="nearest")
-            u = u * sd[f"{b}.upsample.filter_const"]
+            u = u * _zero_insertion_mask(sd, f"{b}.upsample.filter_const", u)
             u = F.pad(u, (2, 1, 2, 1))
             img = F.conv2d(u, sd[f"{b}.upsample.filter.weight"], None, groups=3).add_(y)
         else:

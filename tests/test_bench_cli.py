@@ -1,0 +1,42 @@
+"""bench.py's launch plumbing on a CPU box: `--gpus 2` creates its two ranks itself, they rendezvous (gloo here, nccl = RCCL on
+the GPU box), gather through the same OutputGather as the real run, and rank 0 prints one JSON line that says how many ranks
+took part; a mismatch between --gpus and the ranks is an error."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(*argv, env=None):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *argv], cwd=ROOT, capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, **(env or {})))
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    return r, (json.loads(lines[-1]) if lines else None)
+
+
+def test_gpus_2_spawns_two_ranks_and_reports_them():
+    r, out = _run("--gpus", "2", "--backend", "gloo", "--dry", "--steps", "3")
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert out["n_gpus"] == 2 and out["rccl_ranks"] == 2 and out["dry"] is True
+    assert out["config"]["global_batch"] == 64 and out["scaling"] == "weak"
+
+
+def test_n1_line_schema_and_rank_mismatch_is_an_error():
+    r, out = _run("--dry", "--steps", "2")
+    assert r.returncode == 0 and out["n_gpus"] == 1 and out["rccl_ranks"] == 1
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+                "data", "config"):
+        assert key in out
+    # launched as ONE rank of a 1-rank group but told --gpus 2: the line carries the error and the exit code is non-zero
+    r, out = _run("--gpus", "2", "--dry", "--steps", "1", env={"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode != 0 and "error" in out and out["rccl_ranks"] == 1
+
+
+def test_gpu_run_is_refused_without_a_gpu():
+    import torch
+    if torch.cuda.is_available():
+        return
+    r, out = _run("--steps", "1")
+    assert r.returncode != 0 and out is None and "MI355X" in (r.stderr + r.stdout)

@@ -14,6 +14,30 @@ def lib():
     return emu_lib()
 
 
+# Every test of this file runs under each of these (in-process: the GEMM variant is a field of the operator descriptor, the
+# persistent-workgroup thresholds are run-time tuning knobs): the default plan, and the three GEMM variants with persistent
+# workgroups forced on the small emulator cases (workgroups walk several tiles and prefetch the next tile's first K chunk
+# during the epilogue).
+_GEMM = {"code": -1}
+
+
+@pytest.fixture(autouse=True, params=["default", "f16x2+persist8", "bf16x3+persist16", "f32+persist8"])
+def variant(request, lib):
+    name = request.param
+    if name == "default":
+        _GEMM["code"] = -1
+        yield name
+        return
+    gemm, persist = name.split("+persist")
+    _GEMM["code"] = {"f32": 0, "bf16x3": 1, "f16x2": 2}[gemm]
+    lib.set_tuning("persist_min", 2)
+    lib.set_tuning("persist_grid", int(persist))
+    yield name
+    lib.set_tuning("persist_min", 8192)
+    lib.set_tuning("persist_grid", 512)
+    _GEMM["code"] = -1
+
+
 def _weights(pkg, cin, cout, seed, res_out, noise):
     s = pkg.synth
     sd = {
@@ -54,7 +78,7 @@ def _run(lib, pkg, *, cin, cout, res_in, batch, down=1, up=1, noise=False, skip=
                         conv2_weight=ptr(w2), noise_const=ptr(nc), noise_strength=ptr(ns),
                         batch=batch, cin=cin, cout=cout, res_in=res_in, down=down, up=up,
                         scratch=ptr(scratch), scratch_bytes=0 if scratch is None else scratch.nbytes,
-                        wsplit=ptr(wsp), wsplit_bytes=wsp.nbytes)
+                        wsplit=ptr(wsp), wsplit_bytes=wsp.nbytes, gemm=_GEMM["code"])
     got = nchw(y)
     assert np.isfinite(got).all(), "kernel left NaNs (unwritten output or read of unwritten LDS)"
     tol = 2e-5 * max(1.0, float(np.abs(want).max()))
@@ -113,7 +137,7 @@ def test_fromrgb_fused(lib, pkg, res, batch):
     wsp = aligned(np.full((3 * cin * cout + 1) // 2 + 8, np.nan, dtype=np.float32))
     lib.sepconv_forward(x=ptr(x), y=ptr(y), conv1_weight=ptr(arrs[0]), conv1_bias=ptr(arrs[1]), conv2_weight=ptr(arrs[2]),
                         fromrgb_weight=ptr(arrs[3]), fromrgb_bias=ptr(arrs[4]), wsplit=ptr(wsp), wsplit_bytes=wsp.nbytes,
-                        batch=batch, cin=cin, cout=cout, res_in=res)
+                        batch=batch, cin=cin, cout=cout, res_in=res, gemm=_GEMM["code"])
     np.testing.assert_allclose(nchw(y), want, rtol=0, atol=2e-5 * max(1.0, float(np.abs(want).max())))
 
 

@@ -108,3 +108,21 @@ def test_numpy_fp64_oracle_bounds_fp32_error(pkg, golden_dir):
     x = pkg.synth.make_input(n, r, seed=seed)
     y64 = orc.generator(x, sd, r, dtype=np.float64)
     assert np.abs(y64 - g["y"]).max() < 2e-4
+
+
+def test_oracles_vs_reference_arbitrary_size_goldens(pkg, golden_dir):
+    """the reference module run on H x W inputs with its two fixed-size buffers made dynamic
+    (tests/golden/make_golden_hw.py); both oracles implement the same rule (noise tiled + cropped, zero-insertion mask at size)."""
+    import glob
+    from oracle import migan_torch_cpu as torc
+    files = sorted(glob.glob(os.path.join(golden_dir, "generator_hw_*.npz")))
+    assert len(files) >= 5
+    for f in files:
+        g = np.load(f)
+        r, n, seed, hh, ww = int(g["resolution"]), int(g["batch"]), int(g["seed"]), int(g["height"]), int(g["width"])
+        sd = pkg.synth.make_state_dict(r, seed=seed, regime="export")
+        x = (pkg.synth.normal((n, 4, hh, ww), seed, "xhw") * 0.7).astype(np.float32)
+        tol = 3e-5 * max(1.0, float(g["y_absmax"]))
+        np.testing.assert_allclose(torc.generator(x, sd, r).numpy(), g["y"], rtol=0, atol=tol, err_msg=os.path.basename(f))
+        if hh * ww <= 48 * 80:
+            np.testing.assert_allclose(orc.generator(x, sd, r), g["y"], rtol=0, atol=tol, err_msg=os.path.basename(f))
