@@ -68,3 +68,63 @@ def test_loads_into_the_generator_and_rejects_incomplete_checkpoints(pkg, case):
     broken = {k: v for k, v in train.items() if not k.startswith("encoder.b16.conv1.conv1.")}
     with pytest.raises(KeyError):
         conv.convert_training_state_dict(broken, res)
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# Second, independent oracle: the reference's TRAINING generator (lib/model_zoo/migan.py, depthwise +
+# re-parameterised, 9 tensors per conv, noise_mode='const') on seeded weights, and the reference's own copy_weights() of that
+# very module tree (tests/golden/make_golden_training.py).  Here: regenerate the training tensors from the recipe, convert
+# them with mi-gan_amd/convert.py, run OUR forward.
+def training_case(pkg, golden_dir, tag):
+    g = np.load(os.path.join(golden_dir, f"training_{tag}.npz"))
+    seed, res = int(g["seed"]), int(g["resolution"])
+    train = {}
+    for key, shp in zip([str(k) for k in g["keys"]], [str(s) for s in g["shapes"]]):
+        shape = tuple(int(v) for v in shp.split(",")) if shp else ()
+        leaf = key.rsplit(".", 1)[1]
+        scale = 0.5 if leaf == "bias" else (0.3 if leaf == "noise_strength" else 1.0)
+        t = torch.from_numpy((pkg.synth.normal(shape or (1,), seed, "train/" + key) * scale).astype(np.float32)).reshape(shape)
+        train[key] = t
+    return g, res, seed, train
+
+
+@pytest.mark.parametrize("tag", ["r16", "r64", "r256"])
+def test_training_snapshot_to_inference_forward(pkg, golden_dir, tag):
+    from oracle import migan_torch_cpu as torc
+    conv = importlib.import_module("mi-gan_amd.convert")
+    g, res, seed, train = training_case(pkg, golden_dir, tag)
+    sd = conv.convert_training_state_dict(train, res)
+    # (a) the converted tensors are the ones the reference's copy_weights() wrote into the reference inference module
+    for k, v in sd.items():
+        s1, s2 = g["inf/" + k]
+        f = v.reshape(-1).double()
+        assert abs(float(f.sum()) - s1) <= 1e-5 * max(1.0, abs(s1), float(f.abs().sum())), k
+        assert abs(float((f * f).sum()) - s2) <= 1e-5 * max(1.0, s2), k
+    # (b) the inference forward on them reproduces the TRAINING generator's output (reference self-check: isclose(rtol=1e-3),
+    # export_inference_model.py:149-151; measured 5e-6 .. 2.5e-5 between the two reference models)
+    x = pkg.synth.make_input(int(g["batch"]), res, seed=seed)
+    y = torc.generator(x, {k: v.numpy() for k, v in sd.items()}, res).numpy()
+    assert float(np.abs(y - g["y_train"]).max()) <= 1e-4 * max(1.0, float(g["y_absmax"]))
+    assert float(np.abs(y - g["y_inference"]).max()) <= 3e-5 * max(1.0, float(g["y_absmax"]))
+    assert float(g["y_absmax"]) > 5.0
+
+
+def test_training_snapshot_through_the_product_kernels(pkg, golden_dir):
+    """the same chain with the forward executed by the product kernel source (CPU fiber emulator, C ABI)"""
+    from tests.emu_util import aligned, emu_lib
+    conv = importlib.import_module("mi-gan_amd.convert")
+    g, res, seed, train = training_case(pkg, golden_dir, "r16")
+    sd = conv.convert_training_state_dict(train, res)
+    lib = emu_lib()
+    h = pkg.hipbind.MiganHandle(lib, res)
+    keep = {k: aligned(v.numpy().reshape(1) if v.ndim == 0 else v.numpy()) for k, v in sd.items()}
+    for name, shape, _ in h.weights():
+        h.set_weight(name, keep[name].ctypes.data, shape)
+    h.commit()
+    n = int(g["batch"])
+    x = aligned(pkg.synth.make_input(n, res, seed=seed))
+    y = aligned(np.full((n, 3, res, res), np.nan, np.float32))
+    need = h.workspace_bytes(n)
+    ws = np.zeros(need // 4 + 64, np.float32)
+    h.forward(x.ctypes.data, y.ctypes.data, n, ws.ctypes.data, need)
+    assert float(np.abs(y - g["y_train"]).max()) <= 1e-4 * max(1.0, float(g["y_absmax"]))

@@ -283,3 +283,24 @@ def test_finite_inputs_give_finite_outputs_and_nan_policy(pkg, dev):
         xn[0, 1, 10, 10] = float("nan")
         yn = m(xn)
         assert bool(torch.isfinite(yn).all()) and torch.equal(yn, m(xn))
+
+
+# ------------------------------------------------------------------------------------------------ second oracle (N3)
+@pytest.mark.parametrize("tag", ["r64", "r256"])
+def test_training_snapshot_to_hip_forward(pkg, dev, golden_dir, tag):
+    """SURVEY 8c second oracle + 8f N3 on the GPU: seeded weights of the reference's TRAINING generator (migan.py, depthwise,
+    re-parameterised x9, noise_mode='const'; output recorded by tests/golden/make_golden_training.py) -> mi-gan_amd/convert.py
+    -> load_state_dict -> HIP forward, within the north star's 1e-3 (the reference's own two models differ by 2.5e-5)."""
+    import importlib
+    from tests.test_convert import training_case
+    conv = importlib.import_module("mi-gan_amd.convert")
+    g, res, seed, train = training_case(pkg, golden_dir, tag)
+    m = pkg.Generator(resolution=res)
+    m.load_state_dict(conv.convert_training_state_dict(train, res), strict=True)
+    m = m.to(dev).eval()
+    x = torch.from_numpy(pkg.synth.make_input(int(g["batch"]), res, seed=seed)).to(dev)
+    with torch.no_grad():
+        y = m(x).cpu().numpy()
+    err = float(np.abs(y - g["y_train"]).max())
+    assert err <= 1e-4 * max(1.0, float(g["y_absmax"])), err
+    assert err <= 1e-3
