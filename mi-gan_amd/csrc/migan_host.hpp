@@ -87,6 +87,7 @@ struct Tuning {
   int kc16_minw = 3;           // MIGAN_KC16_MINW=2|3|4: workgroups per CU those kernels are built for
   int streams = 2;             // MIGAN_STREAMS=1|2: default of migan_set_streams
   int stagger = -1;            // MIGAN_STAGGER: launch index of the first half after which the second half starts (-1: plan default)
+  int debug_split = 0;         // diagnostics: keep the two-sub-batch execution in keep-intermediates mode
 };
 inline Tuning& tuning() {
   static Tuning t = [] {
@@ -184,7 +185,7 @@ inline Geo choose_geo(int mode, int cin, int cout, int h_in, int w_in, bool from
   const int npl = g.gemmv == 2 ? 2 : 3;
   const int asz = g.gemmv ? npl * g.MT * (g.KC * 2) / 4 : g.MT * AS;
   const int bsz = g.gemmv ? npl * g.NT * (g.KC * 2) / 4 : g.NT * AS;
-  const int gs = g.MT * GS;   // accumulator tile; the fused ToRGB partial sums reuse its slots
+  const int gs = g.MT * (GS + 4);   // accumulator tile (row pitch NT+4, NT+8 with the fused ToRGB tail); the ToRGB partial sums reuse its slots
   const size_t limit = (size_t)(160 * 1024 / g.MINW);
   if (mode == MODE_PW) {
     // A and B operands double buffered: one barrier per K chunk
@@ -551,7 +552,7 @@ struct migan_handle {
   migan::Plan& plan_for(int H, int W);
   void split(int batch, int& n0, int& n1) const {
     n0 = batch; n1 = 0;
-    if (streams >= 2 && !debug && batch >= 16) {
+    if (streams >= 2 && (!debug || migan::tuning().debug_split) && batch >= 16) {
       n0 = (batch / 2 + 7) / 8 * 8;      // whole 8-image groups (the 4x4 tiles hold 8 images)
       n1 = batch - n0;
     }
@@ -1353,6 +1354,7 @@ int migan_set_tuning(const char* key, int value) {
   else if (k == "streams") t.streams = value >= 2 ? 2 : 1;
   else if (k == "stagger") t.stagger = value;
   else if (k == "single_b") t.force_single_b = value != 0;
+  else if (k == "debug_split") t.debug_split = value != 0;
   else throw Error(MIGAN_EINVAL, "unknown tuning key: " + k);
   MIGAN_API_END
 }

@@ -231,6 +231,21 @@ template <> struct Io<2> {
   }
 };
 
+// One lane's share of the three ToRGB dot products (4 of the CO channels of a pixel; reference :312).
+// Written as three scalar FMA chains the compiler cannot re-associate into packed-fp32 instructions: with 16-bit activation
+// storage the SLP-vectorised form of this expression (v_pk_fma_f32 / v_pk_add_f32 with op_sel on operands unpacked from the
+// rounded activations) returned wrong lower-half results in lanes 32-63, a few dozen pixels per launch and different ones
+// every launch, on MI355X (hipcc 7.2; fp32 storage, whose operands come straight from v_med3_f32, never showed it; the
+// un-fused torgb_kernel showed it only while a second stream's kernels shared the GPU).
+// Measurements and the variants tried: profiles/r02_torgb_packed_f32_hazard.md.
+MIGAN_DEVICE MIGAN_INLINE void torgb_partial(f4 v, f4 tw0, f4 tw1, f4 tw2, float& r0, float& r1, float& r2) {
+  r0 = v.x * tw0.x; r1 = v.x * tw1.x; r2 = v.x * tw2.x;
+  MIGAN_OPAQUE_F(r0); MIGAN_OPAQUE_F(r1); MIGAN_OPAQUE_F(r2);
+  r0 = r0 + v.y * tw0.y; MIGAN_OPAQUE_F(r0); r1 = r1 + v.y * tw1.y; MIGAN_OPAQUE_F(r1); r2 = r2 + v.y * tw2.y; MIGAN_OPAQUE_F(r2);
+  r0 = r0 + v.z * tw0.z; MIGAN_OPAQUE_F(r0); r1 = r1 + v.z * tw1.z; MIGAN_OPAQUE_F(r1); r2 = r2 + v.z * tw2.z; MIGAN_OPAQUE_F(r2);
+  r0 = r0 + v.w * tw0.w; MIGAN_OPAQUE_F(r0); r1 = r1 + v.w * tw1.w; MIGAN_OPAQUE_F(r1); r2 = r2 + v.w * tw2.w; MIGAN_OPAQUE_F(r2);
+}
+
 // XCD-aware workgroup order (MI355X: block b runs on XCD b%8, each XCD has a private 4 MiB L2):
 // give every XCD one contiguous range of logical tiles so halo rows shared by neighbouring tiles
 // and the Cout chunks of one tile hit the same L2.  Bijective for any grid size.
@@ -936,9 +951,8 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, MINW) sepconv_kernel(const SepArgs p)
           // goes into the g_s slot the item just consumed; the per-pixel sums are formed in the tail pass below.
           // (16-bit storage: ToRGB sees the stored, i.e. rounded, activations, like torgb_kernel reading the tensor back)
           v = IoOut::rounded(outv);
-          const float r0 = v.x * tw0.x + v.y * tw0.y + v.z * tw0.z + v.w * tw0.w;
-          const float r1 = v.x * tw1.x + v.y * tw1.y + v.z * tw1.z + v.w * tw1.w;
-          const float r2 = v.x * tw2.x + v.y * tw2.y + v.z * tw2.z + v.w * tw2.w;
+          float r0, r1, r2;
+          torgb_partial(v, tw0, tw1, tw2, r0, r1, r2);
           st4(g_s + (m0 + (it0 + u) * STEP) * GS + c4 * 4, f4{r0, r1, r2, 0.0f});
         }
       }
@@ -1390,9 +1404,8 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(kWideThreads, 2) sepconv_wide_kernel(const
         IoT::st(yb + (size_t)upix[u] * p.CO * OE, off_t, outv);
         if constexpr (TORGB) {
           v = IoT::rounded(outv);
-          const float r0 = v.x * tw0.x + v.y * tw0.y + v.z * tw0.z + v.w * tw0.w;
-          const float r1 = v.x * tw1.x + v.y * tw1.y + v.z * tw1.z + v.w * tw1.w;
-          const float r2 = v.x * tw2.x + v.y * tw2.y + v.z * tw2.z + v.w * tw2.w;
+          float r0, r1, r2;
+          torgb_partial(v, tw0, tw1, tw2, r0, r1, r2);
           st4(g_s + (m0 + (it0 + u) * STEP) * GS + c4 * 4, f4{r0, r1, r2, 0.0f});
         }
       }
@@ -1689,9 +1702,9 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, 2) torgb_kernel(const RgbArgs p) {
     for (int q = sub; q < (p.C >> 2); q += 16) {
       const f4 v = IoIn::cvt(IoIn::ld(xp, (unsigned)(q * 4) * IoIn::ESZ));
       const f4 w0 = ld4(p.w + q * 4), w1 = ld4(p.w + p.C + q * 4), w2 = ld4(p.w + 2 * p.C + q * 4);
-      r0 += v.x * w0.x + v.y * w0.y + v.z * w0.z + v.w * w0.w;
-      r1 += v.x * w1.x + v.y * w1.y + v.z * w1.z + v.w * w1.w;
-      r2 += v.x * w2.x + v.y * w2.y + v.z * w2.z + v.w * w2.w;
+      float d0, d1, d2;
+      torgb_partial(v, w0, w1, w2, d0, d1, d2);          // scalar FMA chains, see torgb_partial
+      r0 += d0; r1 += d1; r2 += d2;
     }
   }
 #pragma unroll

@@ -50,6 +50,8 @@ __device__ __forceinline__ float migan_swizzle_xor(float v) {
 #define MIGAN_STORE_NT(ptr, v) __builtin_nontemporal_store((v), (ptr))
 #define MIGAN_LOAD_NT(ptr) __builtin_nontemporal_load(ptr)
 #define MIGAN_OPAQUE(x) asm volatile("" : "+v"(x))
+// the same for a float: an optimisation barrier on one value (keeps scalar FMA chains scalar)
+#define MIGAN_OPAQUE_F(x) asm volatile("" : "+v"(x))
 #define MIGAN_CLOCK() __builtin_readcyclecounter()
 #define MIGAN_ATOMIC_ADD_U64(p, v) atomicAdd((p), (v))
 

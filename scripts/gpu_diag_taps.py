@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Per-layer error of the HIP forward against the torch-CPU oracle port (debug taps), then the
-plain (ping-pong workspace) forward.  Usage: gpu_diag_taps.py RES BATCH [SEED]"""
+plain (ping-pong workspace) forward.  Usage: gpu_diag_taps.py RES BATCH [SEED] [f32|bf16|f16]"""
 import importlib
 import os
 import sys
@@ -15,16 +15,19 @@ from oracle import migan_torch_cpu as torc  # noqa: E402
 pkg = importlib.import_module("mi-gan_amd")
 res, batch = int(sys.argv[1]), int(sys.argv[2])
 seed = int(sys.argv[3]) if len(sys.argv) > 3 else 31
+dtype = sys.argv[4] if len(sys.argv) > 4 else "f32"
+storage = None if dtype == "f32" else dtype
+THR = 1e-3 if storage is None else (0.25 if dtype == "bf16" else 0.03)
 dev = torch.device("cuda:0")
 lib = pkg.load_library()
 sd = pkg.synth.make_state_dict(res, seed=seed)
 x = pkg.synth.make_input(batch, res, seed=seed)
 taps = {}
-want = torc.generator(x, sd, res, taps=taps)
+want = torc.generator(x, sd, res, taps=taps, storage=storage)
 dsd = {k: torch.from_numpy(v.reshape(1) if v.ndim == 0 else v).to(dev) for k, v in sd.items()}
 stream = int(torch.cuda.current_stream().cuda_stream)
 for debug in (True, False):
-    h = pkg.hipbind.MiganHandle(lib, res, 0)
+    h = pkg.hipbind.MiganHandle(lib, res, 0, dtype=dtype)
     h.set_debug(debug)
     for name, shape, _ in h.weights():
         h.set_weight(name, dsd[name].data_ptr(), shape)
@@ -46,15 +49,18 @@ for debug in (True, False):
             continue
         off, shape = h.debug_tensor(batch, key)
         n = int(np.prod(shape))
-        t = ws[off:off + 4 * n].view(torch.float32).reshape(shape).cpu()
+        if key.endswith(".img") or storage is None:
+            t = ws[off:off + 4 * n].view(torch.float32).reshape(shape).cpu()
+        else:
+            t = ws[off:off + 2 * n].view(torch.bfloat16 if dtype == "bf16" else torch.float16).reshape(shape).float().cpu()
         got = t if key.endswith(".img") else t.permute(0, 3, 1, 2)
         d = (got - ref).abs()
-        bad = (d > 1e-3).nonzero()
+        bad = (d > THR).nonzero()
         print(f"  {name:28s} err {float(d.max()):.3e} absmax {float(ref.abs().max()):.2f} nbad {len(bad)}"
               + (f" first {bad[0].tolist()} last {bad[-1].tolist()}" if len(bad) else ""), flush=True)
     d = (y.cpu() - want).abs()
     print("per (b,ch) max", d.amax(dim=(2, 3)).tolist())
-    bad = d.amax(dim=(0, 1)) > 1e-3
+    bad = d.amax(dim=(0, 1)) > THR
     print("bad pixels", int(bad.sum()), "of", bad.numel())
     ys, xs = bad.nonzero(as_tuple=True)
     if len(ys):

@@ -131,6 +131,7 @@ inline float __shfl_xor(float v, int mask);
 #define MIGAN_STORE_NT(ptr, v) (*(ptr) = (v))
 #define MIGAN_LOAD_NT(ptr) (*(ptr))
 #define MIGAN_OPAQUE(x) asm volatile("" : "+r"(x))
+#define MIGAN_OPAQUE_F(x) asm volatile("" : "+x"(x))
 #define MIGAN_CLOCK() 0
 #define MIGAN_ATOMIC_ADD_U64(p, v) (*(p) += (v))
 

@@ -174,6 +174,24 @@ def test_batch32_distinct_images_two_streams(pkg, dev):
     assert float(total) == float(y1.double().sum())
 
 
+@pytest.mark.parametrize("res,storage", [(256, "bf16"), (512, "bf16"), (512, "f16"), (256, "f32")])
+def test_two_stream_forward_is_deterministic_in_every_storage_mode(pkg, dev, res, storage):
+    """32 distinct images, two staggered sub-batches on two streams, several runs: bit-identical run to run and identical to
+    the one-stream result.  (This is the test that caught the packed-fp32 hazard in the ToRGB dot products of the 16-bit
+    modes, profiles/r02_torgb_packed_f32_hazard.md: it only showed while kernels of the other stream shared the GPU.)"""
+    seed = 54
+    m, sd = _model(pkg, res, seed, dev, activation_dtype=storage)
+    xt = torch.from_numpy(pkg.synth.make_input(32, res, seed=seed, kind="demo")).to(dev)
+    with torch.no_grad():
+        m.set_streams(1)
+        y1 = m(xt).clone()
+        m.set_streams(2)
+        runs = [m(xt).clone() for _ in range(6)]
+    torch.cuda.synchronize()
+    for i, y in enumerate(runs):
+        assert torch.equal(y, y1), (i, int((y != y1).sum()))
+
+
 def test_ragged_sub_batches_256(pkg, dev):
     res, seed = 256, 53
     m, sd = _model(pkg, res, seed, dev)

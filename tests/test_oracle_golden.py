@@ -48,7 +48,7 @@ def test_separable_conv_matches_reference(units, tag):
 
 def _cases(golden_dir, max_res):
     out = []
-    for f in sorted(glob.glob(os.path.join(golden_dir, "generator_*.npz"))):
+    for f in sorted(glob.glob(os.path.join(golden_dir, "generator_r*.npz"))):
         g = np.load(f)
         if int(g["resolution"]) <= max_res:
             out.append(f)
