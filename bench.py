@@ -64,7 +64,7 @@ def parse(argv=None):
     ap.add_argument("--dtype", type=str, default="f32", choices=["f32", "bf16", "f16"],
                     help="activation storage between layers (f32 = the reference's precision; bf16 = BASELINE configs[1])")
     ap.add_argument("--gemm", type=str, default="f16x2", choices=["f16x2", "bf16x3", "f32"])
-    ap.add_argument("--streams", type=int, default=2, choices=[1, 2], help="sub-batches / HIP streams per forward (migan)")
+    ap.add_argument("--streams", type=int, default=2, choices=[1, 2, 3, 4], help="sub-batches / HIP streams per forward (migan)")
     ap.add_argument("--cpu-images", type=int, default=4, help="sample size of the CPU baseline (0 = skip)")
     ap.add_argument("--no-gather", action="store_true", help="N>1: skip the output all-gather")
     ap.add_argument("--no-secondary", action="store_true", help="N=1 default run: skip the secondary workloads")

@@ -69,10 +69,11 @@ int migan_get_gemm(const migan_handle* h, int* variant);
  * workspace pointer or stream differs from the one they were prepared on -- and reused.  In-place writes to a bound weight
  * tensor while the assertion is on are NOT seen: call migan_assume_static_weights(h, 1) again (or migan_commit) after them. */
 int migan_assume_static_weights(migan_handle* h, int on);
-/* streams = 2 (default): a forward of >= 16 images runs as two sub-batches on two HIP streams (the caller's and one the
- * handle owns, forked and joined with events, no host synchronisation), the second starting when the first is a few layers
- * in: the low-resolution layers of one half (a few dozen workgroups each) overlap full-size layers of the other.
- * streams = 1: every launch on the caller's stream.  Changes migan_workspace_bytes. */
+/* streams = n > 1 (default 2, at most 4): a forward of >= 8 n images runs as n sub-batches (whole groups of 8 images) on n HIP
+ * streams -- the caller's and n - 1 the handle owns, forked and joined with events, no host synchronisation -- each starting
+ * when the previous one is a few layers in: the low-resolution layers of one sub-batch (a few dozen workgroups each) and the
+ * tail of every launch overlap full-size layers of the others.  Results are bit-identical to streams = 1 (every launch on the
+ * caller's stream).  Changes migan_workspace_bytes. */
 int migan_set_streams(migan_handle* h, int streams);
 
 /* state_dict schema (same keys, shapes and parameter/buffer split as
@@ -194,7 +195,7 @@ int migan_compose_output(const void* y_nchw, const void* img_hwc_u8, const void*
 
 /* Process-wide tuning knobs, the run-time form of the MIGAN_* environment variables (experiments and tests):
  * "kc16" (bit mask: 16-channel K chunks for the 64-channel 512x512 layers), "kc16_minw", "wide", "nt256", "persist_min",
- * "persist_grid", "streams", "stagger", "single_b".  Applies to handles created or re-planned afterwards. */
+ * "persist_grid", "streams", "stagger", "stagger_pct", "single_b", "debug_split".  Applies to handles created or re-planned afterwards. */
 int migan_set_tuning(const char* key, int value);
 
 const char* migan_last_error(void);

@@ -88,6 +88,7 @@ struct Tuning {
   int streams = 2;             // MIGAN_STREAMS=1|2: default of migan_set_streams
   int stagger = -1;            // MIGAN_STAGGER: launch index of the first half after which the second half starts (-1: plan default)
   int debug_split = 0;         // diagnostics: keep the two-sub-batch execution in keep-intermediates mode
+  int stagger_pct = 22;        // MIGAN_STAGGER_PCT: the next sub-batch starts after this share of a forward's launches
 };
 inline Tuning& tuning() {
   static Tuning t = [] {
@@ -101,7 +102,7 @@ inline Tuning& tuning() {
     if (const char* e = std::getenv("MIGAN_PERSIST_GRID")) v.persist_grid = std::max(8, std::atoi(e) / 8 * 8);   // multiple of 8: one share per XCD
     if (const char* e = std::getenv("MIGAN_KC16")) v.kc16 = std::atoi(e);
     if (const char* e = std::getenv("MIGAN_KC16_MINW")) v.kc16_minw = std::min(4, std::max(2, std::atoi(e)));
-    if (const char* e = std::getenv("MIGAN_STREAMS")) v.streams = std::atoi(e) >= 2 ? 2 : 1;
+    if (const char* e = std::getenv("MIGAN_STREAMS")) v.streams = std::min(4, std::max(1, std::atoi(e)));
     if (const char* e = std::getenv("MIGAN_STAGGER")) v.stagger = std::atoi(e);
     return v;
   }();
@@ -496,7 +497,7 @@ struct migan_handle {
   int resolution = 0, device = 0;
   int stv = 0;                        // activation storage format (MIGAN_DTYPE_*)
   int gemm = 2;                       // MIGAN_GEMM_*
-  int streams = 2;                    // 2: batches of >= 16 images run as two staggered sub-batches on two streams
+  int streams = 2;                    // n > 1: batches of >= 8 n images run as n staggered sub-batches on n streams
   bool static_weights = false;        // caller asserts conv2 weights are unchanged between forwards on the same workspace
   bool committed = false, debug = false;
   std::vector<migan::Slot> slots;
@@ -504,8 +505,9 @@ struct migan_handle {
   std::vector<migan::Plan> hw_plans;  // migan_forward_hw sizes seen so far
   std::vector<rt::event_t> events;
   // two-stream execution
-  rt::stream_t aux_stream{};
-  rt::event_t ev_fork{}, ev_mid{}, ev_join{};
+  static constexpr int kMaxStreams = 4;
+  rt::stream_t aux_stream[kMaxStreams - 1]{};
+  rt::event_t ev_mid[kMaxStreams]{}, ev_join[kMaxStreams - 1]{};
   bool aux_ready = false;
   // static weights: where and when the operand planes were last written
   const void* prepared_ws = nullptr;
@@ -550,12 +552,19 @@ struct migan_handle {
     prepared_epoch = 0;
   }
   migan::Plan& plan_for(int H, int W);
-  void split(int batch, int& n0, int& n1) const {
-    n0 = batch; n1 = 0;
-    if (streams >= 2 && (!debug || migan::tuning().debug_split) && batch >= 16) {
-      n0 = (batch / 2 + 7) / 8 * 8;      // whole 8-image groups (the 4x4 tiles hold 8 images)
-      n1 = batch - n0;
+  // sub-batch sizes (whole 8-image groups: the 4x4 tiles hold 8 images; the last one takes the remainder)
+  int split(int batch, int n[kMaxStreams]) const {
+    int parts = 1;
+    if (streams >= 2 && (!debug || migan::tuning().debug_split)) parts = std::min(std::min(streams, (int)kMaxStreams), batch / 8);
+    if (parts < 2) { n[0] = batch; return 1; }
+    const int each = (batch / parts + 7) / 8 * 8;
+    int left = batch, k = 0;
+    while (left > 0 && k < parts) {
+      n[k] = (k == parts - 1) ? left : std::min(each, left);
+      left -= n[k];
+      ++k;
     }
+    return k;
   }
   static size_t sub_offset(const migan::Plan& P, int id, int n) {
     size_t off = 0;
@@ -564,13 +573,15 @@ struct migan_handle {
   }
   static size_t sub_bytes(const migan::Plan& P, int n) { return sub_offset(P, (int)P.bufs.size(), n); }
   size_t workspace_bytes(const migan::Plan& P, int batch) const {
-    int n0, n1;
-    split(batch, n0, n1);
-    return migan::align256(P.shared_bytes) + sub_bytes(P, n0) + (n1 ? sub_bytes(P, n1) : 0);
+    int n[kMaxStreams];
+    const int parts = split(batch, n);
+    size_t total = migan::align256(P.shared_bytes);
+    for (int k = 0; k < parts; ++k) total += sub_bytes(P, n[k]);
+    return total;
   }
   void ensure_aux();
   void run_range(const migan::Plan& P, const float* x, float* y, int n, char* sub_ws, char* shared, rt::stream_t stream,
-                 bool timed, int mid_after, const migan_io_u8* u8);
+                 bool timed, int mid_after, int part, const migan_io_u8* u8);
   void forward(migan::Plan& P, const float* x, float* y, int batch, void* ws, size_t ws_bytes, rt::stream_t stream, float* ms,
                int n_ms, const migan_io_u8* u8 = nullptr);
 };
@@ -776,18 +787,10 @@ inline void migan_handle::build_plan(migan::Plan& P, int H, int W) const {
   for (Launch& L : P.launches)
     if (L.noise_plane_off >= 0) L.noise_plane_off += (long long)wbytes;
   P.shared_bytes = wbytes + noise_bytes;
-  // second sub-batch starts once the first one is through its first three 512-class layers' worth of work: by default
-  // after ~30 % of the launches' algorithmic bytes, so the small-resolution middle of one half overlaps big layers of the other
-  {
-    double total = 0, acc = 0;
-    for (const Launch& L : P.launches) total += L.bytes;
-    P.stagger = 0;
-    for (size_t i = 0; i < P.launches.size(); ++i) {
-      acc += P.launches[i].bytes;
-      if (acc >= 0.30 * total) { P.stagger = (int)i; break; }
-    }
-    if (tuning().stagger >= 0) P.stagger = std::min((int)P.launches.size() - 1, tuning().stagger);
-  }
+  // the next sub-batch starts when the previous one is about a fifth of its launches in (measured on MI355X, migan-512 and
+  // migan-256, batch 32: +6 % at launch 8..12 of 46 / 40, nothing at 4 or 20; profiles/r02_streams_stagger_sweep.txt)
+  P.stagger = std::max(0, (int)P.launches.size() * tuning().stagger_pct / 100);
+  if (tuning().stagger >= 0) P.stagger = std::min((int)P.launches.size() - 1, tuning().stagger);
 }
 
 inline migan::Plan& migan_handle::plan_for(int H, int W) {
@@ -801,16 +804,17 @@ inline migan::Plan& migan_handle::plan_for(int H, int W) {
 
 inline void migan_handle::ensure_aux() {
   if (aux_ready) return;
-  migan::rt_check(rt::stream_create(&aux_stream), "hipStreamCreate");
-  migan::rt_check(rt::event_create_sync(&ev_fork), "hipEventCreate");
-  migan::rt_check(rt::event_create_sync(&ev_mid), "hipEventCreate");
-  migan::rt_check(rt::event_create_sync(&ev_join), "hipEventCreate");
+  for (int k = 0; k < kMaxStreams - 1; ++k) {
+    migan::rt_check(rt::stream_create(&aux_stream[k]), "hipStreamCreate");
+    migan::rt_check(rt::event_create_sync(&ev_join[k]), "hipEventCreate");
+  }
+  for (int k = 0; k < kMaxStreams; ++k) migan::rt_check(rt::event_create_sync(&ev_mid[k]), "hipEventCreate");
   aux_ready = true;
 }
 
 // launches of one sub-batch of n images on `stream`
 inline void migan_handle::run_range(const migan::Plan& P, const float* x, float* y, int n, char* sub_ws, char* shared,
-                                    rt::stream_t stream, bool timed, int mid_after, const migan_io_u8* u8) {
+                                    rt::stream_t stream, bool timed, int mid_after, int part, const migan_io_u8* u8) {
   using namespace migan;
   std::vector<size_t> offs(P.bufs.size());
   for (size_t i = 0; i < P.bufs.size(); ++i) offs[i] = sub_offset(P, (int)i, n);
@@ -860,7 +864,7 @@ inline void migan_handle::run_range(const migan::Plan& P, const float* x, float*
       L.kernel_last = kernel_name(gl);
     }
     if (timed) rt_check(rt::event_record(events[2 * li + 1], stream), "hipEventRecord");
-    if (!timed && (int)li == mid_after) rt_check(rt::event_record(ev_mid, stream), "hipEventRecord");
+    if (!timed && (int)li == mid_after) rt_check(rt::event_record(ev_mid[part], stream), "hipEventRecord");
 #ifdef MIGAN_PHASE_PROF
     if (timed) {
       prof_layers().resize(P.launches.size());
@@ -918,28 +922,35 @@ inline void migan_handle::forward(migan::Plan& P, const float* x, float* y, int 
     na.r = (int)slots[L.w_noise].shape[0]; na.h = L.hout; na.w = L.wout;
     rt_check(rt::launch(noise_plane_kernel, na, (unsigned)cdiv(L.hout * L.wout, kThreads), kThreads, 0, stream), "migan::noise_plane_kernel");
   }
-  int n0, n1;
-  split(batch, n0, n1);
-  if (timed) { n0 = batch; n1 = 0; }     // per-launch durations: one stream, whole-batch launches (the split workspace always fits them)
+  int nsub[kMaxStreams];
+  int parts = split(batch, nsub);
+  if (timed) { nsub[0] = batch; parts = 1; }     // per-launch durations: one stream, whole-batch launches (the split workspace always fits them)
   const size_t in_img = (size_t)4 * P.H * P.W, out_img = (size_t)3 * P.H * P.W;
-  if (n1 > 0) {
-    // two staggered sub-batches on two streams: the second half starts when the first is `stagger` launches in, so the
-    // small-resolution layers of one half (a few dozen workgroups each) run beside full-size layers of the other
+  if (parts > 1) {
+    // staggered sub-batches on separate streams: sub-batch k+1 starts when sub-batch k is `stagger` launches in, so the
+    // small-resolution layers of one (a few dozen workgroups each) and the tail of every launch run beside full-size layers
+    // of the others.  The caller's stream carries sub-batch 0 and is joined to all the others at the end (events only).
     ensure_aux();
-    migan_io_u8 u1{};
-    if (u8) {
-      u1.img = (const unsigned char*)u8->img + (size_t)n0 * P.H * P.W * 3;
-      u1.mask = (const unsigned char*)u8->mask + (size_t)n0 * P.H * P.W;
-      u1.out = (unsigned char*)u8->out + (size_t)n0 * P.H * P.W * 3;
+    int done = 0;
+    char* sub = sub0;
+    for (int k = 0; k < parts; ++k) {
+      rt::stream_t sk = k == 0 ? stream : aux_stream[k - 1];
+      if (k > 0) rt_check(rt::stream_wait_event(sk, ev_mid[k - 1]), "hipStreamWaitEvent");
+      migan_io_u8 uk{};
+      if (u8) {
+        uk.img = (const unsigned char*)u8->img + (size_t)done * P.H * P.W * 3;
+        uk.mask = (const unsigned char*)u8->mask + (size_t)done * P.H * P.W;
+        uk.out = (unsigned char*)u8->out + (size_t)done * P.H * P.W * 3;
+      }
+      run_range(P, x ? x + (size_t)done * in_img : nullptr, y ? y + (size_t)done * out_img : nullptr, nsub[k], sub, shared, sk, false,
+                k + 1 < parts ? P.stagger : -1, k, u8 ? &uk : nullptr);
+      if (k > 0) rt_check(rt::event_record(ev_join[k - 1], sk), "hipEventRecord");
+      sub += sub_bytes(P, nsub[k]);
+      done += nsub[k];
     }
-    run_range(P, x, y, n0, sub0, shared, stream, false, P.stagger, u8);
-    rt_check(rt::stream_wait_event(aux_stream, ev_mid), "hipStreamWaitEvent");
-    run_range(P, x ? x + (size_t)n0 * in_img : nullptr, y ? y + (size_t)n0 * out_img : nullptr, n1, sub0 + sub_bytes(P, n0), shared,
-              aux_stream, false, -1, u8 ? &u1 : nullptr);
-    rt_check(rt::event_record(ev_join, aux_stream), "hipEventRecord");
-    rt_check(rt::stream_wait_event(stream, ev_join), "hipStreamWaitEvent");
+    for (int k = 1; k < parts; ++k) rt_check(rt::stream_wait_event(stream, ev_join[k - 1]), "hipStreamWaitEvent");
   } else {
-    run_range(P, x, y, n0, sub0, shared, stream, timed, -1, u8);
+    run_range(P, x, y, nsub[0], sub0, shared, stream, timed, -1, 0, u8);
   }
   if (timed) {
     rt_check(rt::stream_sync(stream), "hipStreamSynchronize");
@@ -1001,10 +1012,11 @@ int migan_destroy(migan_handle* h) {
     migan::DeviceGuard guard(h->device);
     for (auto& e : h->events) rt::event_destroy(e);
     if (h->aux_ready) {
-      rt::event_destroy(h->ev_fork);
-      rt::event_destroy(h->ev_mid);
-      rt::event_destroy(h->ev_join);
-      rt::stream_destroy(h->aux_stream);
+      for (int k = 0; k < migan_handle::kMaxStreams - 1; ++k) {
+        rt::event_destroy(h->ev_join[k]);
+        rt::stream_destroy(h->aux_stream[k]);
+      }
+      for (int k = 0; k < migan_handle::kMaxStreams; ++k) rt::event_destroy(h->ev_mid[k]);
     }
     delete h;
   }
@@ -1040,7 +1052,7 @@ int migan_assume_static_weights(migan_handle* h, int on) {
 int migan_set_streams(migan_handle* h, int streams) {
   MIGAN_API_BEGIN
   MIGAN_CHECK(h, MIGAN_EINVAL, "null handle");
-  MIGAN_CHECK(streams == 1 || streams == 2, MIGAN_EINVAL, "streams must be 1 or 2");
+  MIGAN_CHECK(streams >= 1 && streams <= migan_handle::kMaxStreams, MIGAN_EINVAL, "streams must be 1 .. 4");
   h->streams = streams;
   MIGAN_API_END
 }
@@ -1351,10 +1363,11 @@ int migan_set_tuning(const char* key, int value) {
   else if (k == "nt256") t.nt256 = value != 0;
   else if (k == "persist_min") t.persist_min = std::max(1, value);
   else if (k == "persist_grid") t.persist_grid = std::max(8, value / 8 * 8);
-  else if (k == "streams") t.streams = value >= 2 ? 2 : 1;
+  else if (k == "streams") t.streams = std::min(4, std::max(1, value));
   else if (k == "stagger") t.stagger = value;
   else if (k == "single_b") t.force_single_b = value != 0;
   else if (k == "debug_split") t.debug_split = value != 0;
+  else if (k == "stagger_pct") t.stagger_pct = std::min(100, std::max(0, value));
   else throw Error(MIGAN_EINVAL, "unknown tuning key: " + k);
   MIGAN_API_END
 }

@@ -147,7 +147,7 @@ class Generator(nn.Module):
         return self
 
     def set_streams(self, n: int) -> "Generator":
-        """2 (default): batches of >= 16 images run as two staggered sub-batches on two HIP streams; 1: one stream."""
+        """n = 2 (default) .. 4: batches of >= 8 n images run as n staggered sub-batches on n HIP streams; 1: one stream."""
         self._streams = int(n)
         if self._handle is not None:
             self._handle.set_streams(self._streams)

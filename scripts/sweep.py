@@ -17,29 +17,21 @@ sys.path.insert(0, ROOT)
 import numpy as np
 import torch
 
-DEFAULTS = dict(kc16=0, kc16_minw=3, wide=1, nt256=1, persist_min=8192, persist_grid=512, stagger=-1)
+DEFAULTS = dict(kc16=0, kc16_minw=3, wide=1, nt256=1, persist_min=8192, persist_grid=512, stagger=-1, stagger_pct=22)
 
 VARIANTS = [
     # label, tuning overrides, streams, dtype
     ("base_s1", {}, 1, "f32"),
     ("base_s2", {}, 2, "f32"),
-    ("s2_stag4", {"stagger": 4}, 2, "f32"),
-    ("s2_stag8", {"stagger": 8}, 2, "f32"),
-    ("s2_stag14", {"stagger": 14}, 2, "f32"),
-    ("s2_stag20", {"stagger": 20}, 2, "f32"),
-    ("s2_stag26", {"stagger": 26}, 2, "f32"),
+] + [(f"s2_stag{k}", {"stagger": k}, 2, "f32") for k in (8, 10, 12, 14, 16, 18, 22)] + [
+    (f"s4_stag{k}", {"stagger": k}, 4, "f32") for k in (3, 5, 7, 9, 11, 14)] + [
     ("kc16_plain_w3_s1", {"kc16": 1, "kc16_minw": 3}, 1, "f32"),
-    ("kc16_rgb_w3_s1", {"kc16": 2, "kc16_minw": 3}, 1, "f32"),
-    ("kc16_up_w3_s1", {"kc16": 4, "kc16_minw": 3}, 1, "f32"),
-    ("kc16_all_w3_s1", {"kc16": 7, "kc16_minw": 3}, 1, "f32"),
-    ("kc16_all_w4_s1", {"kc16": 7, "kc16_minw": 4}, 1, "f32"),
-    ("kc16_all_w2_s1", {"kc16": 7, "kc16_minw": 2}, 1, "f32"),
-    ("kc16_all_w3_s2", {"kc16": 7, "kc16_minw": 3}, 2, "f32"),
-    ("kc16_all_w4_s2", {"kc16": 7, "kc16_minw": 4}, 2, "f32"),
+    ("kc16_plain_w3_s2", {"kc16": 1, "kc16_minw": 3, "stagger": 14}, 2, "f32"),
     ("nopersist_s1", {"persist_min": 1 << 30}, 1, "f32"),
     ("bf16_s1", {}, 1, "bf16"),
     ("bf16_s2", {}, 2, "bf16"),
-    ("bf16_kc16_w3_s2", {"kc16": 7, "kc16_minw": 3}, 2, "bf16"),
+    ("bf16_s2_stag14", {"stagger": 14}, 2, "bf16"),
+    ("bf16_s4_stag7", {"stagger": 7}, 4, "bf16"),
     ("f16_s2", {}, 2, "f16"),
 ]
 

@@ -180,6 +180,16 @@ def test_two_sub_batches_equal_one_batch(pkg, lib):
     assert h.workspace_bytes(21) >= need1
     y2, _ = _forward(h, x)
     np.testing.assert_array_equal(y1, y2)
+    x37 = pkg.synth.make_input(37, res, seed=seed + 1)
+    h.set_streams(1)
+    y37, _ = _forward(h, x37)
+    for n in (3, 4):                                                # 16 + 16 + 5 and 16 + 16 + 5 (whole groups of 8, remainder last)
+        h.set_streams(n)
+        yn, _ = _forward(h, x37)
+        np.testing.assert_array_equal(yn, y37)
+    with pytest.raises(ValueError):
+        h.set_streams(5)
+    h.set_streams(2)
     np.testing.assert_allclose(y2[17:19], orc.generator(x[17:19], sd, res), rtol=0, atol=2e-5)
     # the timed path (one stream, whole-batch launches) fits the same workspace
     xa, ya = aligned(x), aligned(np.full((21, 3, res, res), np.nan, np.float32))
