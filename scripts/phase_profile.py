@@ -17,7 +17,7 @@ import torch
 pkg = importlib.import_module("mi-gan_amd")
 R = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 32
-model = pkg.Generator(R)
+model = pkg.Generator(R); model.set_streams(1)
 model.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in pkg.synth.make_state_dict(R, seed=0).items()})
 model = model.to("cuda").eval()
 x = torch.from_numpy(pkg.synth.make_input(B, R, seed=1)).to("cuda")
