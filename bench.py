@@ -45,10 +45,11 @@ PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 / 1
 PEAK_BF16_MFMA_TFLOPS = 2500.0 # MI355X_MICROARCH.md: dense bf16 / fp16 MFMA peak
 # Split GEMM variants: every fp32 product costs six bf16 MFMA products ("bf16x3") or three fp16 MFMA
 # products ("f16x2"), so the matrix-core ceiling in ALGORITHMIC flops is 2500 / 6 resp. 2500 / 3
-MFMA_PRODUCTS = {"f32": None, "bf16x3": 6.0, "f16x2": 3.0}
+MFMA_PRODUCTS = {"f32": None, "bf16x3": 6.0, "f16x2": 3.0, "f16": 1.0}
 GEMM_TEXT = {"f32": "1x1 convs on exact fp32 MFMA",
              "bf16x3": "1x1 convs on bf16x3-split MFMA (6 bf16 products per fp32 product, fp32 accumulate)",
-             "f16x2": "1x1 convs on f16x2-split MFMA (3 fp16 products per fp32 product on scaled operands, fp32 accumulate)"}
+             "f16x2": "1x1 convs on f16x2-split MFMA (3 fp16 products per fp32 product on scaled operands, fp32 accumulate)",
+             "f16": "1x1 convs on fp16 MFMA (operands rounded to fp16 after power-of-two scaling, one product each, fp32 accumulate)"}
 BASELINE_CONFIG = {("migan", 512, "f32"): "BASELINE configs[2]", ("migan", 256, "bf16"): "BASELINE configs[1]",
                    ("comodgan", 512, "f32"): "BASELINE configs[4]"}
 
@@ -180,7 +181,7 @@ def build_migan(pkg, args, res, batch, dev, rank):
     # distinct images per rank (weak scaling), demo.py-style mask+image input
     x_np = pkg.synth.make_input(batch, res, seed=100 + rank, kind="demo")
     x = torch.from_numpy(x_np).to(dev)
-    gemm = args.gemm if args.dtype == "f32" else "f16x2"
+    gemm = args.gemm if args.dtype == "f32" else "f16"
 
     def cpu_ref(n, threads, timed_runs=2):
         from oracle import migan_torch_cpu as torc

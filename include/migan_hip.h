@@ -50,6 +50,7 @@ extern "C" {
 #define MIGAN_GEMM_F32 0
 #define MIGAN_GEMM_BF16X3 1
 #define MIGAN_GEMM_F16X2 2
+#define MIGAN_GEMM_F16 3          /* 16-bit activation storage only (its default) */
 
 typedef struct migan_handle migan_handle;
 
@@ -59,7 +60,10 @@ typedef struct migan_handle migan_handle;
 int migan_create(int resolution, int dtype, int device, migan_handle** out);
 int migan_destroy(migan_handle* h);
 
-/* Per-handle GEMM variant (initially the process default, environment MIGAN_GEMM; 16-bit storage handles are f16x2 only).
+/* Per-handle GEMM variant.  fp32 storage: f32 / bf16x3 / f16x2 (initially the process default, environment MIGAN_GEMM), all
+ * fp32-grade.  16-bit storage: "f16" (default: both operands of the 1x1 convolutions rounded to fp16 -- 11-bit significands,
+ * after the same exact power-of-two scaling as f16x2 -- one v_mfma_f32_32x32x16_f16 per product, fp32 accumulate: the
+ * "bf16 config" of BASELINE configs[1] / SURVEY 8d, whose rounding sits below the bf16 storage rounding) or f16x2 (operands exact).
  * Re-plans the launch sequence; the workspace size may change. */
 int migan_set_gemm(migan_handle* h, int variant);
 int migan_get_gemm(const migan_handle* h, int* variant);

@@ -25,8 +25,8 @@ SOURCES = [os.path.join(CSRC, f) for f in ("migan_hip.hip", "migan_k_slice.hip",
                                             "comodgan_kernels.hpp", "comodgan_host.hpp")] + [
     os.path.join(ROOT, "include", "migan_hip.h"), os.path.join(ROOT, "include", "comodgan_hip.h")]
 ARCH = "gfx950"
-# (GEMM variant, activation storage format) slices of the sepconv_kernel table; 16-bit storage is built for f16x2 only
-SLICES: Sequence[Tuple[int, int]] = ((0, 0), (1, 0), (2, 0), (2, 1), (2, 2))
+# (GEMM variant, activation storage format) slices of the sepconv_kernel table; 16-bit storage is built for the fp16 GEMM variants (f16x2 = 2, f16 = 3)
+SLICES: Sequence[Tuple[int, int]] = ((0, 0), (1, 0), (2, 0), (2, 1), (2, 2), (3, 1), (3, 2))
 # -fno-honor-nans is NOT used: the reference's Tensor.clamp propagates NaN and so does v_med3_f32
 # only when NaNs are honoured
 FLAGS = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC"] + os.environ.get("MIGAN_HIPCC_FLAGS", "").split()

@@ -115,7 +115,9 @@ inline Geo choose_geo(int mode, int cin, int cout, int h_in, int w_in, bool from
   Geo g;
   g.gemmv = gemmv < 0 ? tuning().gemm : gemmv;
   g.stv = stv;
-  MIGAN_CHECK(stv == 0 || g.gemmv == 2, MIGAN_EINVAL, "16-bit activation storage is built for the f16x2 GEMM variant only");
+  MIGAN_CHECK(g.gemmv >= 0 && g.gemmv <= 3, MIGAN_EINVAL, "unknown GEMM variant");
+  MIGAN_CHECK(stv == 0 ? g.gemmv <= 2 : g.gemmv >= 2, MIGAN_EINVAL,
+              "fp32 activation storage runs the f32 / bf16x3 / f16x2 GEMM variants, 16-bit storage the f16x2 / f16 variants");
   g.mode = mode;
   g.fromrgb = fromrgb;
   MIGAN_CHECK(cin % 32 == 0 && cout % 64 == 0, MIGAN_EINVAL,
@@ -127,7 +129,7 @@ inline Geo choose_geo(int mode, int cin, int cout, int h_in, int w_in, bool from
   int GH, GW, IMGS;
   if (mode == MODE_NORMAL) {
     g.MT = 128; g.KC = 32;
-    if (full && cout % 256 == 0 && !fromrgb && g.gemmv == 2 && tuning().wide) {
+    if (full && cout % 256 == 0 && !fromrgb && g.gemmv >= 2 && tuning().wide) {
       // wide layers: one 8-wave workgroup owns 256 output channels of 8x16 pixels; half of its waves run the
       // depthwise stage of the next K chunk while the other half keeps the matrix cores busy (sepconv_wide_kernel)
       g.wide = true; g.NT = 256; GH = 8; GW = 16; IMGS = 1;
@@ -183,7 +185,7 @@ inline Geo choose_geo(int mode, int cin, int cout, int h_in, int w_in, bool from
   MIGAN_CHECK(items <= g.NI, MIGAN_EINVAL, "internal: input tile too large");
   const int AS = g.KC + 4, GS = g.NT + 4;
   // operand tiles in floats: fp32 rows of pitch KC+4, or three unpadded (XOR-swizzled) bf16 planes
-  const int npl = g.gemmv == 2 ? 2 : 3;
+  const int npl = g.gemmv == 3 ? 1 : (g.gemmv == 2 ? 2 : 3);
   const int asz = g.gemmv ? npl * g.MT * (g.KC * 2) / 4 : g.MT * AS;
   const int bsz = g.gemmv ? npl * g.NT * (g.KC * 2) / 4 : g.NT * AS;
   const int gs = g.MT * (GS + 4);   // accumulator tile (row pitch NT+4, NT+8 with the fused ToRGB tail); the ToRGB partial sums reuse its slots
@@ -208,7 +210,7 @@ inline Geo choose_geo(int mode, int cin, int cout, int h_in, int w_in, bool from
   }
   if (g.wide) {
     // sepconv_wide_kernel carves its own LDS: 2 x (input tile + taps + A planes + B planes), aliased by the result tile
-    const int in_sz = 10 * 18 * g.KC, w_sz = g.KC * 10, a_sz = 2 * g.MT * (g.KC * 2) / 4, b_sz = 2 * g.NT * (g.KC * 2) / 4;
+    const int in_sz = 10 * 18 * g.KC, w_sz = g.KC * 10, a_sz = npl * g.MT * (g.KC * 2) / 4, b_sz = npl * g.NT * (g.KC * 2) / 4;
     g.NI = 3; g.b_stride = b_sz; g.a_stride = a_sz;
     g.lds_bytes = (size_t)std::max(2 * (in_sz + w_sz + a_sz + b_sz), g.MT * (g.NT + 4)) * sizeof(float);
   }
@@ -222,10 +224,12 @@ KernelSlice slice_g1s0();
 KernelSlice slice_g2s0();
 KernelSlice slice_g2s1();
 KernelSlice slice_g2s2();
+KernelSlice slice_g3s1();
+KernelSlice slice_g3s2();
 inline const std::vector<KernelEntry>& kernel_table() {
   static const std::vector<KernelEntry> t = [] {
     std::vector<KernelEntry> v;
-    for (const KernelSlice& sl : {slice_g0s0(), slice_g1s0(), slice_g2s0(), slice_g2s1(), slice_g2s2()})
+    for (const KernelSlice& sl : {slice_g0s0(), slice_g1s0(), slice_g2s0(), slice_g2s1(), slice_g2s2(), slice_g3s1(), slice_g3s2()})
       v.insert(v.end(), sl.entries, sl.entries + sl.n);
     return v;
   }();
@@ -233,14 +237,21 @@ inline const std::vector<KernelEntry>& kernel_table() {
 }
 
 inline const char* wide_name(const Geo& g) {
-  static const char* n[2][3] = {{"migan::sepconv_wide_kernel<false, 0>", "migan::sepconv_wide_kernel<false, 1>", "migan::sepconv_wide_kernel<false, 2>"},
-                                {"migan::sepconv_wide_kernel<true, 0>", "migan::sepconv_wide_kernel<true, 1>", "migan::sepconv_wide_kernel<true, 2>"}};
-  return n[g.torgb ? 1 : 0][g.stv];
+  static const char* n[2][2][3] = {
+      {{"migan::sepconv_wide_kernel<false, 0, false>", "migan::sepconv_wide_kernel<false, 1, false>", "migan::sepconv_wide_kernel<false, 2, false>"},
+       {"migan::sepconv_wide_kernel<true, 0, false>", "migan::sepconv_wide_kernel<true, 1, false>", "migan::sepconv_wide_kernel<true, 2, false>"}},
+      {{"", "migan::sepconv_wide_kernel<false, 1, true>", "migan::sepconv_wide_kernel<false, 2, true>"},
+       {"", "migan::sepconv_wide_kernel<true, 1, true>", "migan::sepconv_wide_kernel<true, 2, true>"}}};
+  return n[g.gemmv == 3 ? 1 : 0][g.torgb ? 1 : 0][g.stv];
 }
-inline SepKernelFn wide_fn(bool torgb, int stv) {
-  static const SepKernelFn f[2][3] = {{sepconv_wide_kernel<false, 0>, sepconv_wide_kernel<false, 1>, sepconv_wide_kernel<false, 2>},
-                                      {sepconv_wide_kernel<true, 0>, sepconv_wide_kernel<true, 1>, sepconv_wide_kernel<true, 2>}};
-  return f[torgb ? 1 : 0][stv];
+// x1: GEMM variant "f16" (one fp16 piece per operand; 16-bit storage only)
+inline SepKernelFn wide_fn(bool torgb, int stv, bool x1 = false) {
+  static const SepKernelFn f[2][2][3] = {
+      {{sepconv_wide_kernel<false, 0, false>, sepconv_wide_kernel<false, 1, false>, sepconv_wide_kernel<false, 2, false>},
+       {sepconv_wide_kernel<true, 0, false>, sepconv_wide_kernel<true, 1, false>, sepconv_wide_kernel<true, 2, false>}},
+      {{nullptr, sepconv_wide_kernel<false, 1, true>, sepconv_wide_kernel<false, 2, true>},
+       {nullptr, sepconv_wide_kernel<true, 1, true>, sepconv_wide_kernel<true, 2, true>}}};
+  return f[x1 ? 1 : 0][torgb ? 1 : 0][stv];
 }
 inline const char* kernel_name(const Geo& g);
 inline const KernelEntry& pick_kernel(const Geo& g) {
@@ -323,6 +334,7 @@ inline void prepare_kernels() {
   for (int t = 0; t < 2; ++t)
     for (int sv = 0; sv < 3; ++sv) {
       rt_check(rt::allow_dynamic_lds((const void*)wide_fn(t != 0, sv), 160 * 1024), "hipFuncSetAttribute");
+      if (sv) rt_check(rt::allow_dynamic_lds((const void*)wide_fn(t != 0, sv, true), 160 * 1024), "hipFuncSetAttribute");
       rt_check(rt::allow_dynamic_lds((const void*)dwfir_fn(t != 0, sv), 96 * 1024), "hipFuncSetAttribute");
     }
   if (dev >= (int)done.size()) done.resize(dev + 1, 0);
@@ -400,7 +412,7 @@ inline void launch_sepconv(Geo g, const SepArgs& a, rt::stream_t stream) {
               "ToRGB can only be fused into a plain layer whose output channels fit one column tile");
   if (g.wide) {
     MIGAN_CHECK(a.wsplit != nullptr, MIGAN_EINVAL, "internal: the wide kernel needs the fp16 weight planes");
-    rt_check(rt::launch(wide_fn(fused_rgb, g.stv), a, tiles_of(g, a.B), kWideThreads, g.lds_bytes, stream), wide_name(g));
+    rt_check(rt::launch(wide_fn(fused_rgb, g.stv, g.gemmv == 3), a, tiles_of(g, a.B), kWideThreads, g.lds_bytes, stream), wide_name(g));
     return;
   }
   const KernelEntry& k = pick_kernel(g);
@@ -900,7 +912,7 @@ inline void migan_handle::forward(migan::Plan& P, const float* x, float* y, int 
   if (gemm && !planes_valid) {
     SplitArgs sa{};
     sa.dst = reinterpret_cast<unsigned short*>(shared);
-    sa.f16 = gemm == 2;
+    sa.f16 = gemm == 3 ? 2 : (gemm == 2 ? 1 : 0);
     for (const Launch& L : P.launches) {
       if (L.is_rgb || L.is_dwfir) continue;
       MIGAN_CHECK(sa.n < 40, MIGAN_EINVAL, "internal: too many layers for the weight-split table");
@@ -993,7 +1005,7 @@ int migan_create(int resolution, int dtype, int device, migan_handle** out) {
   h->resolution = resolution;
   h->device = device;
   h->stv = dtype;
-  h->gemm = dtype == MIGAN_DTYPE_F32 ? tuning().gemm : MIGAN_GEMM_F16X2;
+  h->gemm = dtype == MIGAN_DTYPE_F32 ? tuning().gemm : MIGAN_GEMM_F16;
   h->streams = tuning().streams;
   h->build_schema();
   try {
@@ -1026,9 +1038,9 @@ int migan_destroy(migan_handle* h) {
 int migan_set_gemm(migan_handle* h, int variant) {
   MIGAN_API_BEGIN
   MIGAN_CHECK(h, MIGAN_EINVAL, "null handle");
-  MIGAN_CHECK(variant == MIGAN_GEMM_F32 || variant == MIGAN_GEMM_BF16X3 || variant == MIGAN_GEMM_F16X2, MIGAN_EINVAL, "unknown GEMM variant");
-  MIGAN_CHECK(h->stv == MIGAN_DTYPE_F32 || variant == MIGAN_GEMM_F16X2, MIGAN_EINVAL,
-              "16-bit activation storage runs on the f16x2 GEMM variant only");
+  MIGAN_CHECK(variant >= MIGAN_GEMM_F32 && variant <= MIGAN_GEMM_F16, MIGAN_EINVAL, "unknown GEMM variant");
+  MIGAN_CHECK(h->stv == MIGAN_DTYPE_F32 ? variant <= MIGAN_GEMM_F16X2 : variant >= MIGAN_GEMM_F16X2, MIGAN_EINVAL,
+              "fp32 activation storage runs the f32 / bf16x3 / f16x2 GEMM variants, 16-bit storage the f16x2 / f16 variants");
   h->gemm = variant;
   h->rebuild();
   MIGAN_API_END
@@ -1275,16 +1287,16 @@ int migan_sepconv_forward(const migan_sepconv_desc* d, void* stream) {
   }
   // split GEMM variants need room for the 16-bit weight planes; without it the exact fp32 MFMA path runs
   const size_t wsplit_need = wsplit_elems_of(d->cin, d->cout) * sizeof(unsigned short);
-  const int want = stv != 0 ? 2 : (d->gemm >= 0 ? d->gemm : tuning().gemm);
-  MIGAN_CHECK(want >= 0 && want <= 2, MIGAN_EINVAL, "unknown GEMM variant");
+  const int want = stv != 0 ? (d->gemm == MIGAN_GEMM_F16X2 ? MIGAN_GEMM_F16X2 : MIGAN_GEMM_F16) : (d->gemm >= 0 ? d->gemm : tuning().gemm);
+  MIGAN_CHECK(want >= 0 && want <= 3 && (stv != 0 || want <= 2), MIGAN_EINVAL, "unknown GEMM variant for this storage format");
   const bool have_planes = d->wsplit != nullptr && d->wsplit_bytes >= wsplit_need;
-  MIGAN_CHECK(stv == 0 || have_planes, MIGAN_EINVAL, "16-bit activation storage needs the wsplit buffer (f16x2 GEMM)");
+  MIGAN_CHECK(stv == 0 || have_planes, MIGAN_EINVAL, "16-bit activation storage needs the wsplit buffer (fp16 GEMM variants)");
   const int gemmv = have_planes ? want : 0;
   const Geo g = choose_geo(mode, d->cin, d->cout, gemm_h, gemm_w, d->fromrgb_weight != nullptr, d->torgb_weight != nullptr, gemmv, stv);
   if (gemmv) {
     SplitArgs sa{};
     sa.dst = (unsigned short*)d->wsplit;
-    sa.f16 = gemmv == 2;
+    sa.f16 = gemmv == 3 ? 2 : (gemmv == 2 ? 1 : 0);
     sa.src[0] = (const float*)d->conv2_weight; sa.dst_off[0] = kSplitHeader; sa.count[0] = (unsigned)(d->cin * d->cout); sa.ci[0] = (unsigned)d->cin; sa.n = 1;
     launch_split(sa, (rt::stream_t)stream);
   }

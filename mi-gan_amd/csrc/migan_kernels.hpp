@@ -375,8 +375,9 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, MINW) sepconv_kernel(const SepArgs p)
   constexpr int MTI = WROWS / 32, NTI = WCOLS / 32;
   static_assert(MTI >= 1 && NTI >= 1, "wave tile must be at least 32x32");
   constexpr bool BF = (GEMMV >= 1);                // operands are planes of 16-bit pieces
-  constexpr bool F16 = (GEMMV == 2);
-  constexpr int NPL = F16 ? 2 : 3;                 // planes per operand
+  constexpr bool F16 = (GEMMV >= 2);               // fp16 pieces of scaled operands
+  constexpr bool X1 = (GEMMV == 3);                // one fp16 piece per operand (operands rounded to 11-bit significands)
+  constexpr int NPL = X1 ? 1 : (F16 ? 2 : 3);      // planes per operand
   constexpr int PB = KC * 2;                       // BF: bytes per row of one 16-bit operand plane (XOR-swizzled 16-B slots, no padding)
   constexpr int NSLOT = PB / 16;
   constexpr int NB = BF ? NPL * NT * NSLOT / kThreads : NT * QC / kThreads;   // float4 items of the 1x1 weight tile per thread
@@ -453,7 +454,10 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, MINW) sepconv_kernel(const SepArgs p)
   // every 8 rows
   auto swz = [](int row) { return NSLOT == 4 ? ((row >> 2) & 3) : ((row >> 3) & 1); };
   auto emit_a = [&](float* abase, int m, int c4, f4 v) {
-    if constexpr (F16) {
+    if constexpr (X1) {
+      char* d = reinterpret_cast<char*>(abase) + m * PB + (((c4 >> 1) ^ swz(m)) << 4) + ((c4 & 1) << 3);
+      *reinterpret_cast<u2v*>(d) = u2v{MIGAN_PACK_F16(v.x, v.y), MIGAN_PACK_F16(v.z, v.w)};
+    } else if constexpr (F16) {
       // v already carries the 2^7 activation scale
       u2v h1, h2;
       split2_f16(v, h1, h2);
@@ -783,7 +787,9 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, MINW) sepconv_kernel(const SepArgs p)
         for (int i = 0; i < MTI; ++i)
 #pragma unroll
           for (int j = 0; j < NTI; ++j) {
-            if constexpr (F16) {
+            if constexpr (X1) {
+              acc[i][j] = MIGAN_MFMA_F16_32X32X16(av[i][0], bv[j][0], acc[i][j]);
+            } else if constexpr (F16) {
               acc[i][j] = MIGAN_MFMA_F16_32X32X16(av[i][1], bv[j][0], acc[i][j]);
               acc[i][j] = MIGAN_MFMA_F16_32X32X16(av[i][0], bv[j][1], acc[i][j]);
               acc[i][j] = MIGAN_MFMA_F16_32X32X16(av[i][0], bv[j][0], acc[i][j]);
@@ -1092,7 +1098,7 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, MINW) sepconv_kernel(const SepArgs p)
 // Everything the K loop touches is double buffered (input tile, taps, A planes, B planes: 145 KB), so one
 // barrier per chunk suffices.  MFMA wave grid 2 x 4, each wave 64 x 64 (same fragments as sepconv_kernel).
 constexpr int kWideThreads = 512;
-template <bool TORGB, int STV = 0>
+template <bool TORGB, int STV = 0, bool X1 = false>
 MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(kWideThreads, 2) sepconv_wide_kernel(const SepArgs p) {
   typedef Io<STV> IoT;
   constexpr unsigned OE = IoT::ESZ;
@@ -1102,7 +1108,7 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(kWideThreads, 2) sepconv_wide_kernel(const
   constexpr int GH = 8, GW = 16, lgGW = 4;
   constexpr int IGH = GH + 2, IGW = GW + 2, NPIX = IGH * IGW, NITEMS = NPIX * QC;
   constexpr int NI = (NITEMS + kWideThreads - 1) / kWideThreads;            // 3 float4 input items per thread and chunk
-  constexpr int PB = KC * 2, NSLOT = PB / 16, NPL = 2;
+  constexpr int PB = KC * 2, NSLOT = PB / 16, NPL = X1 ? 1 : 2;      // X1: one fp16 piece per operand (GEMM variant "f16")
   constexpr int NB = NPL * NT * NSLOT / kWideThreads;                       // 4 float4 weight-plane items per thread and chunk
   static_assert(NB * kWideThreads == NPL * NT * NSLOT, "weight tile must split evenly over the threads");
   constexpr int NW4 = KC * 10 / 4;
@@ -1247,11 +1253,16 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(kWideThreads, 2) sepconv_wide_kernel(const
 #pragma unroll
         for (int kx = 0; kx < 3; ++kx) sacc += w[ky * 3 + kx] * win[(o + ky) % 3][kx];
       const int m = ((r0 + o) << lgGW) + gx;
-      u2v h1, h2;
-      split2_f16(act4_scaled<7>(sacc), h1, h2);
       char* d = a_b + m * PB + (((c4 >> 1) ^ ((m >> 2) & (NSLOT - 1))) << 4) + ((c4 & 1) << 3);
-      *reinterpret_cast<u2v*>(d) = h1;
-      *reinterpret_cast<u2v*>(d + MT * PB) = h2;
+      if constexpr (X1) {
+        const f4 av_ = act4_scaled<7>(sacc);
+        *reinterpret_cast<u2v*>(d) = u2v{MIGAN_PACK_F16(av_.x, av_.y), MIGAN_PACK_F16(av_.z, av_.w)};
+      } else {
+        u2v h1, h2;
+        split2_f16(act4_scaled<7>(sacc), h1, h2);
+        *reinterpret_cast<u2v*>(d) = h1;
+        *reinterpret_cast<u2v*>(d + MT * PB) = h2;
+      }
     }
   };
   f16v acc[MTI][NTI];
@@ -1285,8 +1296,10 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(kWideThreads, 2) sepconv_wide_kernel(const
       for (int i = 0; i < MTI; ++i)
 #pragma unroll
         for (int j = 0; j < NTI; ++j) {
-          acc[i][j] = MIGAN_MFMA_F16_32X32X16(av[i][1], bv[j][0], acc[i][j]);
-          acc[i][j] = MIGAN_MFMA_F16_32X32X16(av[i][0], bv[j][1], acc[i][j]);
+          if constexpr (!X1) {
+            acc[i][j] = MIGAN_MFMA_F16_32X32X16(av[i][1], bv[j][0], acc[i][j]);
+            acc[i][j] = MIGAN_MFMA_F16_32X32X16(av[i][0], bv[j][1], acc[i][j]);
+          }
           acc[i][j] = MIGAN_MFMA_F16_32X32X16(av[i][0], bv[j][0], acc[i][j]);
         }
     }
@@ -1613,7 +1626,7 @@ struct SplitArgs {
   unsigned ci[40];                  // CI (the planes are written chunk-major: [plane][CI/32][CO][32])
   unsigned short* dst;
   int n;
-  int f16;                          // 0: three bf16 planes; 1: two fp16 planes of the scaled weights
+  int f16;                          // 0: three bf16 planes; 1: two fp16 planes of the scaled weights; 2: one fp16 plane (GEMM variant "f16")
 };
 constexpr int kSplitHeader = 8;     // 16-bit elements of header in front of the planes: float[0] = accumulator scale, float[2] = weight scale
 constexpr int kSplitBlocksPerTensor = 32;
@@ -1660,7 +1673,7 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, 2) split_weights_kernel(const SplitAr
       u2v h1, h2;
       split2_f16(ld4(src + i) * sw, h1, h2);
       *reinterpret_cast<u2v*>(dst + o) = h1;
-      *reinterpret_cast<u2v*>(dst + cnt + o) = h2;
+      if (p.f16 == 1) *reinterpret_cast<u2v*>(dst + cnt + o) = h2;
     } else {
       u2v h1, h2, h3;
       split3_bf16(ld4(src + i), h1, h2, h3);

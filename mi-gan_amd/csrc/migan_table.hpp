@@ -50,14 +50,14 @@ struct KernelEntry {
   MIGAN_K(3, 128, 128, 32, false, 4, 2, true, true, G, false, S),                                                                \
   MIGAN_K(3, 128, 64, 32, false, 4, 2, true, false, G, false, S), MIGAN_K(3, 128, 64, 32, false, 4, 2, false, false, G, false, S)
 
-// 16-channel K chunks (f16x2 GEMM only): half the K-loop LDS and prefetch registers of the 32-channel tiles, built for
+// 16-channel K chunks (fp16 GEMM variants only): half the K-loop LDS and prefetch registers of the 32-channel tiles, built for
 // 3 or 4 workgroups per CU -- the 64-output-channel layers at 512x512 (encoder first layer, last FIR-up layer, last plain
 // layer + ToRGB), which are latency- / issue-bound rather than matrix-bound.
-#define MIGAN_GEOMETRIES_KC16(S, W)                                                                                              \
-  MIGAN_K(0, 128, 64, 16, false, 3, W, true, false, 2, true, S), MIGAN_K(0, 128, 64, 16, false, 3, W, true, false, 2, false, S),   \
-  MIGAN_K(0, 128, 64, 16, false, 3, W, true, true, 2, false, S),                                                                 \
-  MIGAN_K(0, 128, 64, 16, true, 3, W, true, false, 2, false, S), MIGAN_K(0, 128, 64, 16, true, 3, W, true, true, 2, false, S),     \
-  MIGAN_K(2, 128, 64, 16, false, 3, W, true, false, 2, false, S), MIGAN_K(2, 128, 64, 16, false, 3, W, true, true, 2, false, S)
+#define MIGAN_GEOMETRIES_KC16(G, S, W)                                                                                             \
+  MIGAN_K(0, 128, 64, 16, false, 3, W, true, false, G, true, S), MIGAN_K(0, 128, 64, 16, false, 3, W, true, false, G, false, S),   \
+  MIGAN_K(0, 128, 64, 16, false, 3, W, true, true, G, false, S),                                                                 \
+  MIGAN_K(0, 128, 64, 16, true, 3, W, true, false, G, false, S), MIGAN_K(0, 128, 64, 16, true, 3, W, true, true, G, false, S),     \
+  MIGAN_K(2, 128, 64, 16, false, 3, W, true, false, G, false, S), MIGAN_K(2, 128, 64, 16, false, 3, W, true, true, G, false, S)
 
 struct KernelSlice {
   const KernelEntry* entries;

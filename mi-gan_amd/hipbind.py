@@ -19,8 +19,8 @@ MIGAN_OK, MIGAN_EINVAL, MIGAN_ESTATE, MIGAN_ERUNTIME, MIGAN_EUNSUPPORTED = 0, 1,
 # activation storage formats (MIGAN_DTYPE_*) and GEMM variants (MIGAN_GEMM_*) of include/migan_hip.h
 DTYPES = {"f32": 0, "fp32": 0, "float32": 0, "bf16": 1, "bfloat16": 1, "f16": 2, "fp16": 2, "float16": 2}
 DTYPE_NAMES = {0: "f32", 1: "bf16", 2: "f16"}
-GEMMS = {"default": -1, "f32": 0, "bf16x3": 1, "f16x2": 2}
-GEMM_NAMES = {0: "f32", 1: "bf16x3", 2: "f16x2"}
+GEMMS = {"default": -1, "f32": 0, "bf16x3": 1, "f16x2": 2, "f16": 3}
+GEMM_NAMES = {0: "f32", 1: "bf16x3", 2: "f16x2", 3: "f16"}
 
 
 def dtype_code(dtype) -> int:

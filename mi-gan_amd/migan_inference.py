@@ -139,11 +139,12 @@ class Generator(nn.Module):
         return self
 
     def set_gemm(self, variant: Optional[str]) -> "Generator":
-        """How the 1x1 convolutions are multiplied: 'f16x2' (default: 3 fp16 MFMA products per fp32 product on scaled 2-way
-        split operands), 'bf16x3' (6 bf16 products) or 'f32' (exact fp32 MFMA); all accumulate in fp32 (include/migan_hip.h)."""
+        """How the 1x1 convolutions are multiplied.  fp32 storage: 'f16x2' (default: 3 fp16 MFMA products per fp32 product on
+        scaled 2-way split operands), 'bf16x3' (6 bf16 products) or 'f32' (exact fp32 MFMA) -- all fp32-grade.  16-bit storage:
+        'f16' (default: operands rounded to fp16, one MFMA per product) or 'f16x2'.  All accumulate in fp32 (include/migan_hip.h)."""
         self._gemm = variant
         if self._handle is not None:
-            self._handle.set_gemm(variant or "f16x2")
+            self._handle.set_gemm(variant or ("f16x2" if self._act_dtype == 0 else "f16"))
         return self
 
     def set_streams(self, n: int) -> "Generator":

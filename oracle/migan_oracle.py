@@ -45,6 +45,24 @@ def round_storage(x: np.ndarray, storage: Optional[str]) -> np.ndarray:
     return out.astype(x.dtype)
 
 
+def round_gemm_operands(x: np.ndarray, w: np.ndarray):
+    """GEMM variant "f16" of the 16-bit storage modes (MIGAN_GEMM_F16): both operands of the 1x1 convolution are rounded to fp16
+    (11-bit significands, round to nearest even) after exact power-of-two scaling -- activations by 2^7 (they are bounded by the
+    +-256 clamp), each weight tensor so that its largest magnitude lands in [2^13, 2^14) -- products and sums are fp32."""
+    x32 = np.asarray(x, dtype=np.float32)
+    xr = ((x32 * np.float32(128.0)).astype(np.float16).astype(np.float32) / np.float32(128.0)).astype(x.dtype)
+    w32 = np.asarray(w, dtype=np.float32)
+    m = float(np.abs(w32).max())
+    if m > 0 and np.isfinite(m):
+        e = int(np.floor(np.log2(m)))
+        e = min(max(e, -100), 100)
+        s = np.float32(2.0 ** (13 - e))
+        wr = ((w32 * s).astype(np.float16).astype(np.float32) / s)
+    else:
+        wr = w32
+    return xr, wr.astype(w.dtype)
+
+
 def noise_plane(noise_const: np.ndarray, h: int, w: int) -> np.ndarray:
     """noise_const [r,r] at an h x w layer (arbitrary-size forward, reference README.md:87): tiled periodically and
     cropped; the identity at h = w = r."""
@@ -141,7 +159,7 @@ def pointwise(x: np.ndarray, w: np.ndarray, bias: Optional[np.ndarray] = None) -
 
 
 # --------------------------------------------------------------------------- a5
-def separable_conv(x: np.ndarray, sd: Dict[str, np.ndarray], prefix: str) -> np.ndarray:
+def separable_conv(x: np.ndarray, sd: Dict[str, np.ndarray], prefix: str, gemm16: bool = False) -> np.ndarray:
     """SeparableConv2d.forward (reference :154-170): dw3x3(+bias) -> act ->
     [FIR down] -> 1x1 -> [FIR up] -> [+ noise_const*noise_strength] -> act."""
     dt = x.dtype
@@ -150,7 +168,10 @@ def separable_conv(x: np.ndarray, sd: Dict[str, np.ndarray], prefix: str) -> np.
     x = lrelu_agc(x)                                                     # :156-157
     if f"{prefix}.downsample.filter.weight" in sd:
         x = downsample2d(x, sd[f"{prefix}.downsample.filter.weight"])    # :159-160
-    x = pointwise(x, sd[f"{prefix}.conv2.weight"])                       # :161
+    w2 = sd[f"{prefix}.conv2.weight"]
+    if gemm16:
+        x, w2 = round_gemm_operands(x, w2)
+    x = pointwise(x, w2)                                                 # :161
     if f"{prefix}.upsample.filter.weight" in sd:
         x = upsample2d(x, sd[f"{prefix}.upsample.filter.weight"])        # :162-163
     if f"{prefix}.noise_const" in sd:
@@ -162,7 +183,7 @@ def separable_conv(x: np.ndarray, sd: Dict[str, np.ndarray], prefix: str) -> np.
 
 # --------------------------------------------------------------------------- a6/a7
 def encoder(img: np.ndarray, sd: Dict[str, np.ndarray], resolution: int,
-            taps: Optional[dict] = None, storage: Optional[str] = None):
+            taps: Optional[dict] = None, storage: Optional[str] = None, gemm16: bool = False):
     """Encoder.forward (reference :235-246) with EncoderBlock.forward (:192-200)."""
     feats = {}
     x = None
@@ -172,8 +193,8 @@ def encoder(img: np.ndarray, sd: Dict[str, np.ndarray], resolution: int,
         if f"{b}.fromrgb.weight" in sd:
             y = lrelu_agc(pointwise(img, sd[f"{b}.fromrgb.weight"], sd[f"{b}.fromrgb.bias"]))  # :194-195
             x = y if x is None else x + y                                 # :196
-        feat = round_storage(separable_conv(x, sd, f"{b}.conv1"), storage)   # :198
-        x = round_storage(separable_conv(feat, sd, f"{b}.conv2"), storage)   # :199
+        feat = round_storage(separable_conv(x, sd, f"{b}.conv1", gemm16), storage)   # :198
+        x = round_storage(separable_conv(feat, sd, f"{b}.conv2", gemm16), storage)   # :199
         feats[res] = feat
         if taps is not None:
             taps[f"{b}.conv1"] = feat
@@ -184,20 +205,20 @@ def encoder(img: np.ndarray, sd: Dict[str, np.ndarray], resolution: int,
 
 # --------------------------------------------------------------------------- a8/a9/a10
 def synthesis(x: np.ndarray, feats: Dict[int, np.ndarray], sd: Dict[str, np.ndarray],
-              resolution: int, taps: Optional[dict] = None, storage: Optional[str] = None) -> np.ndarray:
+              resolution: int, taps: Optional[dict] = None, storage: Optional[str] = None, gemm16: bool = False) -> np.ndarray:
     """Synthesis.forward (reference :347-352), SynthesisBlockFirst (:270-279),
     SynthesisBlock (:303-315)."""
     img = None
     res = 4
     while res <= resolution:
         b = f"synthesis.b{res}"
-        x = separable_conv(x, sd, f"{b}.conv1")                           # :271 / :304
+        x = separable_conv(x, sd, f"{b}.conv1", gemm16)                   # :271 / :304
         if taps is not None:
             taps[f"{b}.conv1"] = x                                        # SeparableConv2d output (pre skip)
         x = round_storage(x + feats[res], storage)                        # :272 / :305
         if taps is not None:
             taps[f"{b}.conv1.skip"] = x
-        x = round_storage(separable_conv(x, sd, f"{b}.conv2"), storage)   # :273 / :306
+        x = round_storage(separable_conv(x, sd, f"{b}.conv2", gemm16), storage)   # :273 / :306
         if taps is not None:
             taps[f"{b}.conv2"] = x
         y = pointwise(x, sd[f"{b}.torgb.weight"], sd[f"{b}.torgb.bias"])  # :277 / :312
@@ -213,11 +234,15 @@ def synthesis(x: np.ndarray, feats: Dict[int, np.ndarray], sd: Dict[str, np.ndar
 
 
 def generator(x: np.ndarray, sd: Dict[str, np.ndarray], resolution: int,
-              dtype=np.float32, taps: Optional[dict] = None, storage: Optional[str] = None) -> np.ndarray:
+              dtype=np.float32, taps: Optional[dict] = None, storage: Optional[str] = None, gemm16: Optional[bool] = None) -> np.ndarray:
     """Generator.forward (reference :362-369): x [N,4,R,R] -> img [N,3,R,R].
     x may be [N,4,H,W] with H, W multiples of R/4 (arbitrary-size forward, noise_plane above).
-    storage: None / 'f32' = the reference; 'bf16' / 'f16' = the library's 16-bit activation storage modes."""
+    storage: None / 'f32' = the reference; 'bf16' / 'f16' = the library's 16-bit activation storage modes.
+    gemm16: the 1x1 convolutions on fp16-rounded operands (GEMM variant "f16", the default of the 16-bit storage modes;
+    None = that default: on with 16-bit storage, off with fp32)."""
     x = np.asarray(x, dtype=dtype)
     sd = {k: np.asarray(v) for k, v in sd.items()}
-    h, feats = encoder(x, sd, resolution, taps, storage)
-    return synthesis(h, feats, sd, resolution, taps, storage)
+    if gemm16 is None:
+        gemm16 = storage in ("bf16", "f16")
+    h, feats = encoder(x, sd, resolution, taps, storage, gemm16)
+    return synthesis(h, feats, sd, resolution, taps, storage, gemm16)

@@ -59,7 +59,19 @@ def _noise(sd, p: str, x: torch.Tensor) -> torch.Tensor:
     return nc * sd[f"{p}.noise_strength"]
 
 
-def _sepconv(x: torch.Tensor, sd: Dict[str, torch.Tensor], p: str) -> torch.Tensor:
+def _gemm16(x: torch.Tensor, w: torch.Tensor):
+    """GEMM variant "f16" (oracle/migan_oracle.py::round_gemm_operands): operands of the 1x1 rounded to fp16 after exact
+    power-of-two scaling, fp32 products and sums."""
+    xr = (x * 128.0).half().float() / 128.0
+    m = float(w.abs().max())
+    if m > 0 and np.isfinite(m):
+        e = min(max(int(np.floor(np.log2(m))), -100), 100)
+        s = float(2.0 ** (13 - e))
+        w = (w * s).half().float() / s
+    return xr, w
+
+
+def _sepconv(x: torch.Tensor, sd: Dict[str, torch.Tensor], p: str, gemm16: bool = False) -> torch.Tensor:
     # reference :154-170
     c = x.shape[1]
     x = F.conv2d(x, sd[f"{p}.conv1.weight"], sd[f"{p}.conv1.bias"], padding=1, groups=c)
@@ -67,7 +79,10 @@ def _sepconv(x: torch.Tensor, sd: Dict[str, torch.Tensor], p: str) -> torch.Tens
     k = f"{p}.downsample.filter.weight"
     if k in sd:                                                  # :58-76
         x = F.conv2d(x, sd[k], None, stride=2, padding=1, groups=c)
-    x = F.conv2d(x, sd[f"{p}.conv2.weight"])
+    w2 = sd[f"{p}.conv2.weight"]
+    if gemm16:
+        x, w2 = _gemm16(x, w2)
+    x = F.conv2d(x, w2)
     k = f"{p}.upsample.filter.weight"
     if k in sd:                                                  # :98-103
         x = F.interpolate(x, scale_factor=2, mode="nearest")
@@ -81,9 +96,12 @@ def _sepconv(x: torch.Tensor, sd: Dict[str, torch.Tensor], p: str) -> torch.Tens
 
 
 @torch.no_grad()
-def generator(x, sd, resolution: int, taps: Optional[dict] = None, storage: Optional[str] = None) -> torch.Tensor:
+def generator(x, sd, resolution: int, taps: Optional[dict] = None, storage: Optional[str] = None,
+              gemm16: Optional[bool] = None) -> torch.Tensor:
     """x [N,4,R,R] float32 (tensor or ndarray; [N,4,H,W] with H, W multiples of R/4 for the arbitrary-size forward),
     sd: name -> tensor/ndarray.  storage: None / 'f32' = the reference; 'bf16' / 'f16' = 16-bit activation storage."""
+    if gemm16 is None:          # GEMM variant "f16" is the default of the 16-bit storage modes
+        gemm16 = storage in ("bf16", "f16")
     x = torch.as_tensor(np.asarray(x) if not torch.is_tensor(x) else x).float().cpu()
     sd = {k: (v if torch.is_tensor(v) else torch.from_numpy(np.ascontiguousarray(v))).float().cpu()
           for k, v in sd.items()}
@@ -96,8 +114,8 @@ def generator(x, sd, resolution: int, taps: Optional[dict] = None, storage: Opti
         if f"{b}.fromrgb.weight" in sd:                          # :193-196
             y = _act(F.conv2d(img_in, sd[f"{b}.fromrgb.weight"], sd[f"{b}.fromrgb.bias"]))
             h = y if h is None else h + y
-        feat = _store(_sepconv(h, sd, f"{b}.conv1"), storage)
-        h = _store(_sepconv(feat, sd, f"{b}.conv2"), storage)
+        feat = _store(_sepconv(h, sd, f"{b}.conv1", gemm16), storage)
+        h = _store(_sepconv(feat, sd, f"{b}.conv2", gemm16), storage)
         feats[res] = feat
         if taps is not None:
             taps[f"{b}.conv1"] = feat
@@ -107,13 +125,13 @@ def generator(x, sd, resolution: int, taps: Optional[dict] = None, storage: Opti
     res = 4
     while res <= resolution:                                     # :347-352
         b = f"synthesis.b{res}"
-        h = _sepconv(h, sd, f"{b}.conv1")
+        h = _sepconv(h, sd, f"{b}.conv1", gemm16)
         if taps is not None:
             taps[f"{b}.conv1"] = h                               # SeparableConv2d output (pre skip)
         h = _store(h + feats[res], storage)                      # :272 / :305
         if taps is not None:
             taps[f"{b}.conv1.skip"] = h
-        h = _store(_sepconv(h, sd, f"{b}.conv2"), storage)
+        h = _store(_sepconv(h, sd, f"{b}.conv2", gemm16), storage)
         if taps is not None:
             taps[f"{b}.conv2"] = h
         y = F.conv2d(h, sd[f"{b}.torgb.weight"], sd[f"{b}.torgb.bias"])

@@ -86,7 +86,7 @@ def main():
             print(f"{label:22s} ERROR {e}", flush=True)
             continue
         if dtype not in ref:
-            ref[dtype] = torc.generator(x_np[:2], sd, res, storage=None if dtype == "f32" else dtype)
+            ref[dtype] = torc.generator(x_np[:2], sd, res, storage=None if dtype == "f32" else dtype)     # (16-bit: GEMM variant "f16")
         err = float((y[:2].cpu() - ref[dtype]).abs().max())
         row = dict(label=label, tuning=tune, streams=streams, dtype=dtype, ms_per_step=el / args.steps * 1e3,
                    images_per_s=args.batch * args.steps / el, sum_kernel_ms=float(np.sum(ms)), max_abs_err=err)

@@ -21,6 +21,12 @@
 #undef MIGAN_SLICE_S
 #define MIGAN_SLICE_S 2
 #include "../../mi-gan_amd/csrc/migan_k_slice.inc"
+#undef MIGAN_SLICE_G
+#define MIGAN_SLICE_G 3
+#include "../../mi-gan_amd/csrc/migan_k_slice.inc"
+#undef MIGAN_SLICE_S
+#define MIGAN_SLICE_S 1
+#include "../../mi-gan_amd/csrc/migan_k_slice.inc"
 #undef MIGAN_SLICE_S
 #undef MIGAN_SLICE_G
 #include "../../mi-gan_amd/csrc/migan_host.hpp"

@@ -55,6 +55,19 @@ def test_sepconv_16bit_storage(lib, pkg, storage, case):
     _sepconv(lib, pkg, storage=storage, **case)
 
 
+@pytest.mark.parametrize("storage", ["bf16", "f16"])
+@pytest.mark.parametrize("case", [
+    dict(cin=64, cout=64, h=16, batch=2, noise=True, skip=True),
+    dict(cin=64, cout=256, h=16, batch=1, noise=True, skip=True),                     # wide kernel
+    dict(cin=32, cout=64, h=32, batch=1, down=2),
+    dict(cin=64, cout=64, h=16, batch=1, up=2, noise=True, skip=True),
+    dict(cin=128, cout=128, h=16, batch=2, noise=True, torgb=True, with_prev=True),
+])
+def test_sepconv_16bit_storage_exact_gemm(lib, pkg, storage, case):
+    """16-bit storage with the f16x2 GEMM variant (operands exact) instead of its default "f16" variant."""
+    _sepconv(lib, pkg, storage=storage, gemm=2, **case)
+
+
 def _bind(pkg, lib, res, seed, dtype="f32", debug=False, regime="export"):
     h = pkg.hipbind.MiganHandle(lib, res, dtype=dtype)
     if debug:
@@ -105,7 +118,9 @@ def test_generator_16bit_storage_every_layer(pkg, lib, storage):
             # the first layers agree except for isolated last-place ties; deeper in, an element that rounded the other way
             # moves everything it feeds, so the two computations decorrelate inside the quantisation noise: every stored
             # tensor stays within one storage step of its largest magnitude (+ one step of the element itself)
-            storage_close(np.transpose(t, (0, 3, 1, 2)), ref, storage, ulps=1, frac=0.6 if checked >= 2 else 0.02, what=name, top_ulps=1.0)
+            # (f16 storage: the fp16 operand rounding of the default GEMM variant is as large as the storage step itself)
+            storage_close(np.transpose(t, (0, 3, 1, 2)), ref, storage, ulps=1, frac=0.7 if checked >= 2 else 0.05, what=name,
+                          top_ulps=1.0 if storage == "bf16" else 3.0)
         checked += 1
     assert checked == 2 * 6 + 2
     ref32 = orc.generator(x, sd, res)
@@ -162,8 +177,13 @@ def test_generator_per_handle_gemm_variant(pkg, lib, tuned, gemm):
     with pytest.raises(ValueError):
         h.set_gemm(7)
     hb = pkg.hipbind.MiganHandle(lib, 8, dtype="bf16")
+    assert hb.gemm() == "f16"                                      # default of the 16-bit storage modes
     with pytest.raises(ValueError, match="f16x2"):
         hb.set_gemm("f32")
+    hb.set_gemm("f16x2")
+    assert hb.gemm() == "f16x2"
+    with pytest.raises(ValueError):
+        h.set_gemm("f16")                                          # fp32 storage keeps fp32-grade products
 
 
 # ------------------------------------------------------------------------------------------------ two sub-batches

@@ -91,8 +91,16 @@ def test_sepconv_16bit_storage(pkg, dev, storage, case):
     run_sepconv_case(pkg.load_library(), pkg, CudaMem(dev), storage=storage, **case)
 
 
-@pytest.mark.parametrize("res,storage", [(256, "bf16"), (512, "bf16"), (256, "f16"), (64, "bf16")])
-def test_generator_16bit_storage_full_size(pkg, dev, res, storage):
+@pytest.mark.parametrize("storage", ["bf16", "f16"])
+@pytest.mark.parametrize("case", OPERATOR_CASES[::2])
+def test_sepconv_16bit_storage_exact_gemm(pkg, dev, storage, case):
+    """16-bit storage with the f16x2 GEMM variant (operands exact) instead of its default "f16" variant."""
+    run_sepconv_case(pkg.load_library(), pkg, CudaMem(dev), storage=storage, gemm=2, **case)
+
+
+@pytest.mark.parametrize("res,storage,gemm", [(256, "bf16", "f16"), (512, "bf16", "f16"), (256, "f16", "f16"), (64, "bf16", "f16"),
+                                              (256, "bf16", "f16x2")])
+def test_generator_16bit_storage_full_size(pkg, dev, res, storage, gemm):
     """BASELINE configs[1] (migan-256, bf16 storage) and the same mode at 512: the tolerance of a storage mode is its own
     quantisation noise, measured oracle(mode) vs oracle(fp32) on the same inputs; the kernels must sit inside that
     envelope both against the mode's oracle and against the fp32 reference (tests/test_emu_round2.py checks every stored
@@ -100,17 +108,18 @@ def test_generator_16bit_storage_full_size(pkg, dev, res, storage):
     seed, batch = 33, 2
     m, sd = _model(pkg, res, seed, dev, activation_dtype=storage)
     assert m.activation_dtype == storage
+    m.set_gemm(gemm)
     x = pkg.synth.make_input(batch, res, seed=seed)
     with torch.no_grad():
         y = m(torch.from_numpy(x).to(dev)).cpu()
         y2 = m(torch.from_numpy(x).to(dev)).cpu()
-    assert torch.equal(y, y2)
-    want_mode = torc.generator(x, sd, res, storage=storage)
+    assert torch.equal(y, y2) and m._handle.gemm() == gemm
+    want_mode = torc.generator(x, sd, res, storage=storage, gemm16=(gemm == "f16"))
     want_f32 = torc.generator(x, sd, res)
     err_mode = float((want_mode - want_f32).abs().max())
     err = float((y - want_mode).abs().max())
     err32 = float((y - want_f32).abs().max())
-    print(f"migan-{res} {storage}: |y|max {float(want_f32.abs().max()):.2f}  mode vs fp32 oracle {err_mode:.3e}  "
+    print(f"migan-{res} {storage} gemm {gemm}: |y|max {float(want_f32.abs().max()):.2f}  mode vs fp32 oracle {err_mode:.3e}  "
           f"kernels vs mode oracle {err:.3e}  kernels vs fp32 oracle {err32:.3e}")
     assert err <= 2.0 * err_mode and err32 <= 2.0 * err_mode
     assert err_mode <= (3e-2 if storage == "bf16" else 4e-3) * float(want_f32.abs().max())
