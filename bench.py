@@ -199,7 +199,9 @@ def build_migan(pkg, args, res, batch, dev, rank):
     return dict(model=model, x=x, step=lambda: model(x), timed=lambda: model.forward_timed(x), launches=model.launch_info,
                 gemm=gemm, cpu_ref=cpu_ref, out_shape=(batch, 3, res, res),
                 cpu_desc=f"oracle/migan_torch_cpu.py (torch-CPU/oneDNN op-for-op port of the reference module)",
-                traffic=("profiles/pmc_traffic_latest.json", res == 512 and batch == 32 and args.dtype == "f32" and gemm == "f16x2"),
+                traffic=(("profiles/pmc_traffic_latest.json", res == 512 and batch == 32 and args.dtype == "f32" and gemm == "f16x2")
+                         if args.dtype == "f32" else
+                         ("profiles/pmc_traffic_migan256_bf16_latest.json", res == 256 and batch == 32 and args.dtype == "bf16" and gemm == "f16")),
                 data="synthetic (seeded export-like weights, demo.py-style mask+image batches)",
                 gemm_text=GEMM_TEXT.get(gemm, gemm),
                 extra_cfg={"activation_storage": args.dtype, "streams": args.streams,

