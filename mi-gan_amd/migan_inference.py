@@ -109,6 +109,21 @@ class Generator(nn.Module):
             else:
                 node.register_buffer(parts[-1], t)
             self._names.append(e.name)
+        # attributes the reference's own tools read on the module tree (scripts/export_inference_model.py::copy_weights :33-83):
+        # `fromrgb` is None on the encoder blocks that have none, the 1x1 convolutions carry `bias = None` (bias=False,
+        # reference :130-136), every SeparableConv2d says whether it has noise
+        for name, node in list(self.named_modules()):
+            parts = name.split(".")
+            if len(parts) == 2 and parts[0] == "encoder" and not hasattr(node, "fromrgb"):
+                node.fromrgb = None
+            if len(parts) == 3 and parts[2] in ("conv1", "conv2"):                 # a SeparableConv2d
+                node.use_noise = hasattr(node, "noise_const")
+                if not hasattr(node, "downsample"):
+                    node.downsample = None
+                if not hasattr(node, "upsample"):
+                    node.upsample = None
+                if hasattr(node, "conv2") and not hasattr(node.conv2, "bias"):
+                    node.conv2.register_parameter("bias", None)
         # engine state (never part of state_dict)
         self._lib: Optional[MiganLib] = None
         self._handle: Optional[MiganHandle] = None

@@ -128,3 +128,52 @@ def test_training_snapshot_through_the_product_kernels(pkg, golden_dir):
     ws = np.zeros(need // 4 + 64, np.float32)
     h.forward(x.ctypes.data, y.ctypes.data, n, ws.ctypes.data, need)
     assert float(np.abs(y - g["y_train"]).max()) <= 1e-4 * max(1.0, float(g["y_absmax"]))
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/scripts"), reason="the reference repository is only present in the build container")
+def test_reference_copy_weights_accepts_our_generator_as_destination(pkg):
+    """scripts/export_inference_model.py::copy_weights (:17-85), the reference's own function, run with the reference's TRAINING
+    generator as source and THIS package's Generator as destination: every attribute it reads exists on our module tree
+    (fromrgb None, conv2.bias None, use_noise), and the state_dict it leaves equals mi-gan_amd/convert.py's."""
+    import sys
+    import types
+    import importlib.util
+    conv = importlib.import_module("mi-gan_amd.convert")
+    ref = "/root/reference"
+    saved_path, saved = list(sys.path), {k: sys.modules.get(k) for k in ("cv2", "torchvision", "torchvision.transforms")}
+    sys.path.insert(0, ref)
+    try:
+        for name in ("cv2", "torchvision", "torchvision.transforms"):
+            if name not in sys.modules:
+                sys.modules[name] = types.ModuleType(name)
+        if not hasattr(sys.modules["torchvision"], "transforms"):
+            sys.modules["torchvision"].transforms = sys.modules["torchvision.transforms"]
+        import lib.model_zoo.migan as train_mod
+        spec = importlib.util.spec_from_file_location("ref_export_t", os.path.join(ref, "scripts", "export_inference_model.py"))
+        ref_export = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(ref_export)
+        res = 16
+        kw = dict(resolution=res, ch_base=32768, ch_max=512, depthwise=True, reparametrize=True, num_reparam_tensors=9)
+        G = train_mod.Generator(train_mod.Encoder(ic_n=4, **kw), train_mod.Synthesis(rgb_n=3, **kw)).eval()
+        new = {}
+        for k, v in G.state_dict().items():
+            if "filter" in k.rsplit(".", 1)[1]:
+                new[k] = v
+            else:
+                new[k] = torch.from_numpy((pkg.synth.normal(tuple(v.shape) or (1,), 5, "t/" + k) * 0.7).astype(np.float32)).reshape(v.shape)
+        G.load_state_dict(new, strict=True)
+        dest = pkg.Generator(resolution=res)
+        with torch.no_grad():
+            ref_export.copy_weights(G, dest, resolution=res)
+        want = conv.convert_training_state_dict({k: v for k, v in new.items()}, res)
+        got = dest.state_dict()
+        assert list(got.keys()) == list(want.keys())
+        for k in want:
+            assert torch.allclose(got[k], want[k], rtol=1e-6, atol=1e-7), k
+    finally:
+        sys.path[:] = saved_path
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+        for k in [k for k in sys.modules if k == "lib" or k.startswith("lib.") or k.startswith("torch_utils") or k.startswith("dnnlib")]:
+            sys.modules.pop(k, None)
