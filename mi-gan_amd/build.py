@@ -27,8 +27,9 @@ SOURCES = [os.path.join(CSRC, f) for f in ("migan_hip.hip", "migan_k_slice.hip",
 ARCH = "gfx950"
 # (GEMM variant, activation storage format) slices of the sepconv_kernel table; 16-bit storage is built for the fp16 GEMM variants (f16x2 = 2, f16 = 3)
 SLICES: Sequence[Tuple[int, int]] = ((0, 0), (1, 0), (2, 0), (2, 1), (2, 2), (3, 1), (3, 2))
-# -fno-honor-nans is NOT used: the reference's Tensor.clamp propagates NaN and so does v_med3_f32
-# only when NaNs are honoured
+# -fno-honor-nans is NOT used: what happens to a non-finite value is then what the instructions do (v_max_f32 / v_med3_f32:
+# a NaN activation leaves the clamp as -256, like the reference's CUDA plugin bias_act.cu:139) rather than whatever the
+# optimiser derives from "NaNs cannot occur"; pinned by tests/test_gpu_round2.py::test_finite_inputs_give_finite_outputs_and_nan_policy
 FLAGS = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC"] + os.environ.get("MIGAN_HIPCC_FLAGS", "").split()
 
 

@@ -40,7 +40,7 @@ struct CmDebugTensor {
 
 typedef void (*CmConvFn)(const CmConvArgs);
 struct CmConvEntry { int NT, KC, nine, MTI; CmConvFn fn; const char* name; int up4 = 0; };
-#define CM_CONV_ENTRY(NT, KC, NIA, NINE, MTI) {NT, KC, NINE, MTI, cm_conv_kernel<NT, KC, NIA, NINE, MTI>, "migan::cm_conv_kernel<" #NT ", " #KC ", " #NIA ", " #NINE ", " #MTI ">"}
+#define CM_CONV_ENTRY(NT, KC, NIA, NINE, MTI) {NT, KC, NINE, MTI, cm_conv_kernel<NT, KC, NIA, NINE, MTI>, "migan::cm_conv_kernel<" #NT ", " #KC ", " #NIA ", " #NINE ", " #MTI ", false>"}
 inline const std::vector<CmConvEntry>& cm_conv_table() {
   static const std::vector<CmConvEntry> t = {
       // 8 x 16 pixel tiles (MTI 2), 64 / 128 output channels: nine-tap unrolled K loop (plain: 10x18-pixel tile, 6 items per thread;

@@ -89,9 +89,9 @@ def test_generator_matches_reference_golden(tag):
     y, _, info = run_emu(cfg, sd, x, z, psi=float(g["psi"]))
     assert np.abs(y - g["y"]).max() <= 1e-3, np.abs(y - g["y"]).max()
     kernels = {i["kernel"] for i in info}
-    assert ("migan::cm_conv_kernel<128, 32, 6, true, 2>" if "c128" in tag else "migan::cm_conv_kernel<64, 32, 6, true, 2>") in kernels
+    assert ("migan::cm_conv_kernel<128, 32, 6, true, 2, false>" if "c128" in tag else "migan::cm_conv_kernel<64, 32, 6, true, 2, false>") in kernels
     # synthesis conv0: all four transposed-convolution phases in one launch with 128-column tiles, one launch per phase with 64
-    assert ("migan::cm_conv_kernel<128, 32, 6, true, 2, true>" if "c128" in tag else "migan::cm_conv_kernel<64, 32, 6, false, 2>") in kernels
+    assert ("migan::cm_conv_kernel<128, 32, 6, true, 2, true>" if "c128" in tag else "migan::cm_conv_kernel<64, 32, 6, false, 2, false>") in kernels
 
 
 @pytest.mark.parametrize("mode", ["none", "random"])
@@ -159,8 +159,8 @@ def test_256_column_tiles(monkeypatch):
     x, z = pkg.synth.make_input(1, 16, 21), pkg.synth.make_latent(1, 512, 21)
     y, _, info = run_emu(cfg, sd, x, z)
     kernels = {i["kernel"] for i in info}
-    assert {"migan::cm_conv_kernel<256, 32, 11, true, 4>", "migan::cm_conv_kernel<256, 16, 18, true, 4>",
-            "migan::cm_conv_kernel<256, 32, 11, false, 4>"} <= kernels, kernels
+    assert {"migan::cm_conv_kernel<256, 32, 11, true, 4, false>", "migan::cm_conv_kernel<256, 16, 18, true, 4, false>",
+            "migan::cm_conv_kernel<256, 32, 11, false, 4, false>"} <= kernels, kernels
     want = orc.generator(x, z, sd, 16, cfg.num_ws)
     assert np.abs(y - want).max() <= 1e-3, np.abs(y - want).max()
 
