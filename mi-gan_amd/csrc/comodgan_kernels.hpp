@@ -825,9 +825,12 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, 2) cm_torgb_kernel(const CmRgbArgs p)
     for (int q = sub; q < (p.C >> 2); q += 16) {
       const f4 v = ld4(xp + q * 4);
       const f4 w0 = ld4(w + q * 4), w1 = ld4(w + p.C + q * 4), w2 = ld4(w + 2 * p.C + q * 4);
-      r0 += v.x * w0.x + v.y * w0.y + v.z * w0.z + v.w * w0.w;
-      r1 += v.x * w1.x + v.y * w1.y + v.z * w1.z + v.w * w1.w;
-      r2 += v.x * w2.x + v.y * w2.y + v.z * w2.z + v.w * w2.w;
+      // scalar FMA chains, not SLP-vectorised packed-fp32 dot products (profiles/r02_torgb_packed_f32_hazard.md)
+      float a0, a1, a2;
+      torgb_partial(v, w0, w1, w2, a0, a1, a2);
+      r0 += a0;
+      r1 += a1;
+      r2 += a2;
     }
   }
 #pragma unroll

@@ -651,6 +651,10 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, MINW) sepconv_kernel(const SepArgs p)
       if (c == 0 && tid < npix_in) st4(rgb_s + tid * 4, rraw);
       __syncthreads();                              // w_s (fromrgb weights of this chunk) and rgb_s visible
       // x = act(fromrgb(img)) (reference :194-195), 4 -> CI pointwise with bias, per halo pixel
+      // (Do not "tidy" this loop: with the weight reads hoisted out of it, or the FMA chain started from the bias, hipcc 7.2
+      // emits v_pk_fma_f32 with low-lane op_sel swizzles for the raw.y products -- the instruction form that gives
+      // intermittently wrong results on MI355X (profiles/r02_torgb_packed_f32_hazard.md; measured: 1-2 % of the first
+      // layer's outputs wrong, different ones every launch).  tests/test_isa_lint.py scans the built code for that form.)
 #pragma unroll
       for (int j = 0; j < NI; ++j) {
         if (emask & (1u << j)) {
