@@ -66,6 +66,9 @@ def parse(argv=None):
                     help="activation storage between layers (f32 = the reference's precision; bf16 = BASELINE configs[1])")
     ap.add_argument("--gemm", type=str, default="f16x2", choices=["f16x2", "bf16x3", "f32"])
     ap.add_argument("--streams", type=int, default=2, choices=[1, 2, 3, 4], help="sub-batches / HIP streams per forward (migan)")
+    ap.add_argument("--io", type=str, default="f32", choices=["f32", "u8"],
+                    help="migan: u8 = uint8 image + mask in, composed uint8 image out (demo.py's pre/post-processing inside the first / "
+                         "last kernels, migan_forward_u8); the all-gather then moves uint8 shards (4x fewer bytes)")
     ap.add_argument("--cpu-images", type=int, default=4, help="sample size of the CPU baseline (0 = skip)")
     ap.add_argument("--no-gather", action="store_true", help="N>1: skip the output all-gather")
     ap.add_argument("--no-secondary", action="store_true", help="N=1 default run: skip the secondary workloads")
@@ -196,16 +199,29 @@ def build_migan(pkg, args, res, batch, dev, rank):
         ref32 = ref if storage is None else torc.generator(x_np[:n], sd, res)
         return ref, ref32, float(np.median(times))
 
-    return dict(model=model, x=x, step=lambda: model(x), timed=lambda: model.forward_timed(x), launches=model.launch_info,
-                gemm=gemm, cpu_ref=cpu_ref, out_shape=(batch, 3, res, res),
+    step, out_shape, out_dtype, post = (lambda: model(x)), (batch, 3, res, res), torch.float32, None
+    if args.io == "u8":
+        img_np, mask_np = pkg.synth.make_uint8_input(batch, res, seed=100 + rank)      # the uint8 source of x_np
+        img_u8, mask_u8 = torch.from_numpy(img_np).to(dev), torch.from_numpy(mask_np).to(dev)
+        step, out_shape, out_dtype = (lambda: model.forward_uint8(img_u8, mask_u8)), (batch, res, res, 3), torch.uint8
+
+        def post(ref_y, n):                                  # reference-side post-processing of the oracle's fp32 output
+            from oracle import migan_prepost as pp
+            return torch.from_numpy(pp.compose(ref_y.numpy() if hasattr(ref_y, "numpy") else ref_y, img_np[:n], mask_np[:n]).astype(np.int16))
+
+    return dict(model=model, x=x, step=step, timed=lambda: model.forward_timed(x), launches=model.launch_info,
+                gemm=gemm, cpu_ref=cpu_ref, out_shape=out_shape, out_dtype=out_dtype, post=post,
                 cpu_desc=f"oracle/migan_torch_cpu.py (torch-CPU/oneDNN op-for-op port of the reference module)",
                 traffic=(("profiles/pmc_traffic_latest.json", res == 512 and batch == 32 and args.dtype == "f32" and gemm == "f16x2")
                          if args.dtype == "f32" else
                          ("profiles/pmc_traffic_migan256_bf16_latest.json", res == 256 and batch == 32 and args.dtype == "bf16" and gemm == "f16")),
                 data="synthetic (seeded export-like weights, demo.py-style mask+image batches)",
                 gemm_text=GEMM_TEXT.get(gemm, gemm),
-                extra_cfg={"activation_storage": args.dtype, "streams": args.streams,
-                           "weights": "static (migan_assume_static_weights: 1x1 operand planes prepared once)"})
+                extra_cfg=dict({"activation_storage": args.dtype, "streams": args.streams,
+                                "weights": "static (migan_assume_static_weights: 1x1 operand planes prepared once)"},
+                               **({"io": "uint8 HWC image + mask in, composed uint8 image out (scripts/demo.py:56-66,135-140 inside the "
+                                         "first / last kernels); parity in uint8 steps against compose(oracle output)"}
+                                  if args.io == "u8" else {})))
 
 
 def build_comodgan(pkg, args, res, batch, dev, rank):
@@ -235,8 +251,13 @@ def build_comodgan(pkg, args, res, batch, dev, rank):
                 traffic=("profiles/pmc_traffic_comodgan_latest.json", res == 512 and batch == 16),
                 data="synthetic (seeded N(0,1) weights, demo.py-style mask+image batches, fixed z, noise_mode=const)",
                 gemm_text="3x3 convs as implicit GEMM on f16x2-split MFMA (3 fp16 products per fp32 product, fp32 accumulate)",
-                extra_cfg={"noise_mode": "const (the reference default 'random' adds a torch.randn of every layer's noise per forward)",
-                           "weights": "static (comodgan_assume_static_weights)"})
+                extra_cfg={"noise_mode": "const (the reference default 'random' adds a torch.randn of every layer's noise per forward: "
+                                         "measured as value_noise_random)",
+                           "weights": "static (comodgan_assume_static_weights)"},
+                alt={"key": "value_noise_random", "step": lambda: model(x),
+                     "note": "model(x) exactly as scripts/demo.py:133-134 calls it: z = torch.randn([N, 512]) (comodgan.py:438-439) and "
+                             "noise_mode='random' (torch.randn of every synthesis layer's noise plane per forward, stylegan.py:284-285), "
+                             "both drawn on the GPU inside the timed step"})
 
 
 def run_workload(args, rank, local_rank, world, dist, dev):
@@ -247,7 +268,7 @@ def run_workload(args, rank, local_rank, world, dist, dev):
     gather = world > 1 and not args.no_gather
     # N > 1: every step's output shards are all-gathered (RCCL) into one of two buffers; the gather of step i runs on
     # RCCL's stream while step i+1 computes, and every gather completes inside the timed region (fence()).
-    pipe = pkg.distributed.OutputGather(wl["out_shape"], torch.float32, dev) if gather else None
+    pipe = pkg.distributed.OutputGather(wl["out_shape"], wl.get("out_dtype", torch.float32), dev) if gather else None
 
     def step():
         y = wl["step"]()
@@ -286,6 +307,13 @@ def run_workload(args, rank, local_rank, world, dist, dev):
                 wl["step"]()
             el2, _ = timed_loop(wl["step"], args.steps)
             compute_only = el2 / args.steps * 1e3
+        alt = None
+        if wl.get("alt") and world == 1:                     # the same workload the way the reference's demo.py calls it
+            for _ in range(2):
+                wl["alt"]["step"]()
+            el3, _ = timed_loop(wl["alt"]["step"], max(3, args.steps // 2))
+            alt = {"value": round(batch * max(3, args.steps // 2) / el3, 2), "ms_per_step": round(el3 / max(3, args.steps // 2) * 1e3, 4),
+                   "note": wl["alt"]["note"]}
     ms_per_step = elapsed / args.steps * 1e3
     value = world * batch * args.steps / elapsed
     ranks_seen = world
@@ -327,13 +355,17 @@ def run_workload(args, rank, local_rank, world, dist, dev):
                 _, _, sec_all = wl["cpu_ref"](1, cores, timed_runs=1)      # the all-cores figure, for the record (1 image, 1 run)
                 cpu["value_all_cores"] = round(1 / sec_all, 4)
                 cpu["all_cores"] = cores
-        parity = float((y[:n].cpu() - ref).abs().max())
-        parity32 = float((y[:n].cpu() - ref32).abs().max())
+        if wl.get("post"):                                   # uint8 output: compare in uint8 steps with the composed oracle output
+            parity = float((y[:n].cpu().to(torch.int16) - wl["post"](ref, n)).abs().max())
+            parity32 = float((y[:n].cpu().to(torch.int16) - wl["post"](ref32, n)).abs().max())
+        else:
+            parity = float((y[:n].cpu() - ref).abs().max())
+            parity32 = float((y[:n].cpu() - ref32).abs().max())
         envelope = float((ref - ref32).abs().max())
         ymax = float(ref32.abs().max())
     tag = BASELINE_CONFIG.get((name, res, args.dtype), "")
     out = {
-        "metric": f"images/sec {name}-{res} generator fwd",
+        "metric": f"images/sec {name}-{res} generator fwd" + (" + fused uint8 pre/post-processing" if wl.get("post") else ""),
         "value": round(value, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": args.dtype if name == "migan" else "f32", "data": wl["data"],
@@ -357,9 +389,13 @@ def run_workload(args, rank, local_rank, world, dist, dev):
         out["parity_note"] = ("max_abs_vs_ref: against the oracle in the same storage mode; max_abs_vs_fp32_ref: against the fp32 reference; "
                               "storage_mode_envelope: oracle(mode) vs oracle(fp32) on the same inputs = the quantisation noise of the mode "
                               "(the tolerance is 2x that)")
+    if wl.get("post"):
+        out["parity_unit"] = "uint8 steps of the composed image (scripts/demo.py:135-140 applied to the oracle's fp32 output)"
+    if alt is not None:
+        out[wl["alt"]["key"]] = alt
     if gather:
         out["compute_only_ms_per_step"] = round(compute_only, 4)
-        out["gather_mb_per_rank_per_step"] = round(float(np.prod(wl["out_shape"])) * 4 / 1e6, 1)
+        out["gather_mb_per_rank_per_step"] = round(float(np.prod(wl["out_shape"])) * (1 if wl.get("out_dtype") == torch.uint8 else 4) / 1e6, 1)
     return out
 
 
@@ -382,10 +418,11 @@ def dry_run(args, rank, world, dist):
     pkg = importlib.import_module("mi-gan_amd")
     name, res, batch = split_model(args)
     dev = torch.device("cpu")
-    shape = (batch, 3, 8, 8)
-    y = torch.full(shape, float(rank))
+    u8 = args.io == "u8"
+    shape = (batch, 8, 8, 3) if u8 else (batch, 3, 8, 8)
+    y = torch.full(shape, rank, dtype=torch.uint8 if u8 else torch.float32)
     gather = world > 1 and not args.no_gather
-    pipe = pkg.distributed.OutputGather(shape, torch.float32, dev) if gather else None
+    pipe = pkg.distributed.OutputGather(shape, y.dtype, dev) if gather else None
     t0 = time.perf_counter()
     for _ in range(args.steps):
         if gather:
@@ -408,7 +445,7 @@ def dry_run(args, rank, world, dist):
             "warmup": args.warmup, "ms_per_step": round(el / max(1, args.steps) * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.dtype, "data": "none (--dry: launch plumbing only, no forward was run)",
             "config": {"workload": "dry run", "global_batch": world * batch, "parallelism": f"batch-shard x{world}"},
-            "dry": True, "rccl_ranks": ranks_seen, "backend": args.backend}
+            "dry": True, "rccl_ranks": ranks_seen, "backend": args.backend, "gather_dtype": str(y.dtype).replace("torch.", "")}
 
 
 def worker(rank, local_rank, world, args):
@@ -435,7 +472,7 @@ def worker(rank, local_rank, world, args):
         out = run_workload(args, rank, local_rank, world, dist, dev)
         name, res, batch = split_model(args)
         if out is not None and world == 1 and not args.no_secondary and args.model == "migan-512" and not args.resolution \
-                and not args.batch and args.dtype == "f32" and args.gemm == "f16x2":
+                and not args.batch and args.dtype == "f32" and args.gemm == "f16x2" and args.io == "f32":
             # the default driver run: also time the exact-fp32-MFMA variant of the same workload and the other two
             # single-GPU BASELINE configs, same protocol
             ex = secondary_line(args, gemm="f32", cpu_images=0, steps=max(5, args.steps // 2), warmup=3)
@@ -448,6 +485,8 @@ def worker(rank, local_rank, world, args):
             out["secondary"] = [
                 secondary_line(args, model="migan-256", dtype="bf16", steps=max(10, args.steps), cpu_images=2),
                 secondary_line(args, model="comodgan-512", steps=max(5, args.steps // 2), warmup=3, cpu_images=4),
+                # the primary workload with demo.py's pre/post-processing fused in (uint8 in, composed uint8 out)
+                secondary_line(args, io="u8", steps=max(10, args.steps // 2), warmup=3, cpu_images=2),
             ]
     ok = True
     if out is not None:

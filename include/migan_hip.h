@@ -198,7 +198,7 @@ int migan_compose_output(const void* y_nchw, const void* img_hwc_u8, const void*
                          int batch, int resolution, void* stream);
 
 /* Process-wide tuning knobs, the run-time form of the MIGAN_* environment variables (experiments and tests):
- * "kc16" (bit mask: 16-channel K chunks for the 64-channel 512x512 layers), "kc16_minw", "wide", "nt256", "persist_min",
+ * "kc16" (bit mask: 16-channel K chunks for the 64-channel 512x512 layers), "kc16_minw", "w3" (the same mask: those layers on 32-channel chunks at 3 workgroups per CU), "wide", "nt256", "persist_min",
  * "persist_grid", "streams", "stagger", "stagger_pct", "single_b", "debug_split".  Applies to handles created or re-planned afterwards. */
 int migan_set_tuning(const char* key, int value);
 

@@ -85,6 +85,10 @@ struct Tuning {
   int kc16 = 0;                // MIGAN_KC16 bit mask: 16-channel K chunks for the 64-output-channel main-geometry layers (f16x2 GEMM):
                                // 1 plain / ToRGB layers, 2 fused-FromRGB layer, 4 FIR-up layers
   int kc16_minw = 3;           // MIGAN_KC16_MINW=2|3|4: workgroups per CU those kernels are built for
+  int w3 = 2;                  // bit mask like kc16: the same layers on 32-channel chunks at 3 workgroups per CU (non-persistent tiles).
+                               // Default: the fused-FromRGB layer only -- measured on encoder.b512.conv1: 1.19 ms as persistent tiles at
+                               // 2 workgroups per CU, 0.98 ms as one tile per workgroup at 3 (164 VGPRs, no spills); the plain / ToRGB
+                               // and FIR-up tiles need 60 bytes of scratch at that budget and lose 10-19 %
   int streams = 2;             // MIGAN_STREAMS=1|2: default of migan_set_streams
   int stagger = -1;            // MIGAN_STAGGER: launch index of the first half after which the second half starts (-1: plan default)
   int debug_split = 0;         // diagnostics: keep the two-sub-batch execution in keep-intermediates mode
@@ -102,6 +106,7 @@ inline Tuning& tuning() {
     if (const char* e = std::getenv("MIGAN_PERSIST_GRID")) v.persist_grid = std::max(8, std::atoi(e) / 8 * 8);   // multiple of 8: one share per XCD
     if (const char* e = std::getenv("MIGAN_KC16")) v.kc16 = std::atoi(e);
     if (const char* e = std::getenv("MIGAN_KC16_MINW")) v.kc16_minw = std::min(4, std::max(2, std::atoi(e)));
+    if (const char* e = std::getenv("MIGAN_W3")) v.w3 = std::atoi(e);
     if (const char* e = std::getenv("MIGAN_STREAMS")) v.streams = std::min(4, std::max(1, std::atoi(e)));
     if (const char* e = std::getenv("MIGAN_STAGGER")) v.stagger = std::atoi(e);
     return v;
@@ -179,6 +184,10 @@ inline Geo choose_geo(int mode, int cin, int cout, int h_in, int w_in, bool from
   // compile-time tile geometry: plain / pointwise tiles must be whole (no bounds checks in that epilogue), FIR-up tiles
   // are ragged by construction
   g.maing = (IMGS == 1 && GW == 16 && GH == (g.MT == 64 ? 4 : 8)) && (full || mode == MODE_UP);
+  if (g.maing && g.gemmv >= 2 && g.NT == 64 && g.MT == 128 && g.KC == 32 && !g.wide && mode != MODE_PW) {
+    const int bit = fromrgb ? 2 : (mode == MODE_UP ? 4 : 1);
+    if (tuning().w3 & bit) g.MINW = 3;
+  }
   if (mode == MODE_PW || g.MT == 64) g.NI = 4;
   else if (g.KC == 16) g.NI = 3;
   else g.NI = g.maing ? 6 : 9;
@@ -266,7 +275,7 @@ inline const char* kernel_name(const Geo& g) { return g.wide ? wide_name(g) : pi
 
 // persistent variants exist where they fit the register budget without spilling
 inline bool has_persistent_variant(const Geo& g) {
-  return g.maing && ((g.NT == 64 && g.mode != MODE_PW) || (g.mode == MODE_PW && g.NT == 128 && g.MINW == 2));
+  return g.maing && ((g.NT == 64 && g.mode != MODE_PW && (g.KC == 16 || g.MINW == 2)) || (g.mode == MODE_PW && g.NT == 128 && g.MINW == 2));
 }
 
 // ---- depthwise + FIR-down kernel (first half of down=2 layers) ----
@@ -1371,6 +1380,7 @@ int migan_set_tuning(const char* key, int value) {
   const std::string k = key;
   if (k == "kc16") t.kc16 = value;
   else if (k == "kc16_minw") t.kc16_minw = std::min(4, std::max(2, value));
+  else if (k == "w3") t.w3 = value;
   else if (k == "wide") t.wide = value != 0;
   else if (k == "nt256") t.nt256 = value != 0;
   else if (k == "persist_min") t.persist_min = std::max(1, value);

@@ -59,6 +59,12 @@ struct KernelEntry {
   MIGAN_K(0, 128, 64, 16, true, 3, W, true, false, G, false, S), MIGAN_K(0, 128, 64, 16, true, 3, W, true, true, G, false, S),     \
   MIGAN_K(2, 128, 64, 16, false, 3, W, true, false, G, false, S), MIGAN_K(2, 128, 64, 16, false, 3, W, true, true, G, false, S)
 
+// The 64-output-channel main tiles with 32-channel chunks built for 3 workgroups per CU (<= 168 VGPRs, single-buffered 1x1 weight
+// tile so that three 49 KB workgroups fit the 160 KB LDS): one more workgroup's loads in flight per CU.  Non-persistent only.
+#define MIGAN_GEOMETRIES_W3(G, S)                                                                                                 \
+  MIGAN_K(0, 128, 64, 32, false, 6, 3, true, false, G, false, S), MIGAN_K(0, 128, 64, 32, false, 6, 3, true, false, G, true, S),   \
+  MIGAN_K(0, 128, 64, 32, true, 6, 3, true, false, G, false, S), MIGAN_K(2, 128, 64, 32, false, 6, 3, true, false, G, false, S)
+
 struct KernelSlice {
   const KernelEntry* entries;
   int n;

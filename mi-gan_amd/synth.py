@@ -130,6 +130,15 @@ def make_input(batch: int, resolution: int, seed: int = 0, kind: str = "demo") -
     return np.concatenate([mask - 0.5, img * mask], axis=1).astype(np.float32)
 
 
+def make_uint8_input(batch: int, resolution: int, seed: int = 0):
+    """The uint8 source of make_input(kind='demo'): image [N,R,R,3] uint8 (HWC, as np.array of a PIL image, demo.py:59) and
+    mask [N,R,R] uint8 (255 = known pixel, demo.py:60); preprocess(image, mask) == make_input(batch, resolution, seed)."""
+    r = resolution
+    img_u8 = np.floor(uniform((batch, 3, r, r), seed, f"img{r}") * 256.0).astype(np.uint8)
+    mask = make_masks(batch, r, seed)
+    return np.ascontiguousarray(np.transpose(img_u8, (0, 2, 3, 1))), (mask[:, 0] * 255.0).astype(np.uint8)
+
+
 # ---- Co-Mod-GAN (SURVEY section 8f row N1) -------------------------------------------------------
 
 def make_comodgan_state_dict(cfg, seed: int = 0) -> Dict[str, np.ndarray]:

@@ -40,3 +40,20 @@ def test_gpu_run_is_refused_without_a_gpu():
         return
     r, out = _run("--steps", "1")
     assert r.returncode != 0 and out is None and "MI355X" in (r.stderr + r.stdout)
+
+
+def test_uint8_io_gathers_uint8_shards():
+    """--io u8 (migan_forward_u8): the shards the ranks exchange are the composed uint8 images, a quarter of the fp32 bytes"""
+    r, out = _run("--gpus", "2", "--backend", "gloo", "--dry", "--steps", "2", "--io", "u8")
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert out["rccl_ranks"] == 2 and out["gather_dtype"] == "uint8"
+
+
+def test_uint8_source_of_the_synthetic_input_matches_it():
+    import importlib
+    import numpy as np
+    from oracle import migan_prepost as pp
+    synth = importlib.import_module("mi-gan_amd").synth
+    img, mask = synth.make_uint8_input(3, 32, seed=5)
+    assert img.dtype == np.uint8 and img.shape == (3, 32, 32, 3) and set(np.unique(mask)) <= {0, 255}
+    np.testing.assert_array_equal(pp.preprocess(img, mask), synth.make_input(3, 32, seed=5))

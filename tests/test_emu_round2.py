@@ -20,7 +20,7 @@ def lib():
 def tuned(lib):
     """set process-wide tuning knobs for one test, restore the defaults afterwards"""
     changed = {}
-    defaults = dict(kc16=0, kc16_minw=3, wide=1, nt256=1, persist_min=8192, persist_grid=512, streams=2, stagger=-1)
+    defaults = dict(kc16=0, kc16_minw=3, w3=2, wide=1, nt256=1, persist_min=8192, persist_grid=512, streams=2, stagger=-1)
 
     def set_(key, value):
         changed[key] = True
@@ -145,6 +145,19 @@ def test_generator_16bit_storage_every_layer(pkg, lib, storage):
 ])
 def test_sepconv_kc16_tiles(lib, pkg, tuned, storage, case):
     tuned("kc16", 7)
+    _sepconv(lib, pkg, storage=storage, gemm=2, **case)
+
+
+@pytest.mark.parametrize("storage", ["f32", "bf16"])
+@pytest.mark.parametrize("case", [
+    dict(cin=64, cout=64, h=16, w=32, batch=2, noise=True, torgb=True, with_prev=True),
+    dict(cin=96, cout=64, h=16, batch=1, noise=True, skip=True),
+    dict(cin=64, cout=64, h=16, batch=2, fromrgb=True),
+    dict(cin=128, cout=64, h=16, batch=1, up=2, noise=True, skip=True),
+])
+def test_sepconv_three_workgroup_tiles(lib, pkg, tuned, storage, case):
+    """the 64-output-channel main tiles built for 3 workgroups per CU (tuning key w3): single-buffered 1x1 weight tile"""
+    tuned("w3", 7)
     _sepconv(lib, pkg, storage=storage, gemm=2, **case)
 
 

@@ -25,7 +25,7 @@ def dev():
 def tuned(pkg):
     lib = pkg.load_library()
     changed = {}
-    defaults = dict(kc16=0, kc16_minw=3, wide=1, nt256=1, persist_min=8192, persist_grid=512, streams=2, stagger=-1)
+    defaults = dict(kc16=0, kc16_minw=3, w3=2, wide=1, nt256=1, persist_min=8192, persist_grid=512, streams=2, stagger=-1)
 
     def set_(key, value):
         changed[key] = True
@@ -140,6 +140,29 @@ def test_sepconv_kc16_tiles(pkg, dev, tuned, minw, storage, case):
     tuned("kc16", 7)
     tuned("kc16_minw", minw)
     run_sepconv_case(pkg.load_library(), pkg, CudaMem(dev), storage=storage, gemm=2, **case)
+
+
+@pytest.mark.parametrize("storage", ["f32", "bf16"])
+@pytest.mark.parametrize("case", [
+    dict(cin=64, cout=64, h=32, w=64, batch=2, noise=True, torgb=True, with_prev=True),
+    dict(cin=96, cout=64, h=32, batch=1, noise=True, skip=True),
+    dict(cin=64, cout=64, h=32, batch=2, fromrgb=True),
+    dict(cin=128, cout=64, h=32, batch=1, up=2, noise=True, skip=True),
+])
+def test_sepconv_three_workgroup_tiles(pkg, dev, tuned, storage, case):
+    tuned("w3", 7)
+    run_sepconv_case(pkg.load_library(), pkg, CudaMem(dev), storage=storage, gemm=2, **case)
+
+
+def test_generator_512_with_three_workgroup_tiles(pkg, dev, tuned):
+    tuned("w3", 7)
+    res, seed, batch = 512, 32, 2
+    m, sd = _model(pkg, res, seed, dev)
+    x = pkg.synth.make_input(batch, res, seed=seed)
+    with torch.no_grad():
+        y = m(torch.from_numpy(x).to(dev)).cpu()
+    assert ", 6, 3, true, false, 2, " in " ".join(l["kernel"] for l in m.launch_info())
+    assert float((y - torc.generator(x, sd, res)).abs().max()) <= TOL
 
 
 def test_generator_512_with_kc16_tiles(pkg, dev, tuned):
