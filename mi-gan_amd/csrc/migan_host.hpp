@@ -85,10 +85,11 @@ struct Tuning {
   int kc16 = 0;                // MIGAN_KC16 bit mask: 16-channel K chunks for the 64-output-channel main-geometry layers (f16x2 GEMM):
                                // 1 plain / ToRGB layers, 2 fused-FromRGB layer, 4 FIR-up layers
   int kc16_minw = 3;           // MIGAN_KC16_MINW=2|3|4: workgroups per CU those kernels are built for
-  int w3 = 2;                  // bit mask like kc16: the same layers on 32-channel chunks at 3 workgroups per CU (non-persistent tiles).
-                               // Default: the fused-FromRGB layer only -- measured on encoder.b512.conv1: 1.19 ms as persistent tiles at
-                               // 2 workgroups per CU, 0.98 ms as one tile per workgroup at 3 (164 VGPRs, no spills); the plain / ToRGB
-                               // and FIR-up tiles need 60 bytes of scratch at that budget and lose 10-19 %
+  int w3 = 3;                  // bit mask like kc16: the same layers on 32-channel chunks at 3 workgroups per CU (one tile per workgroup).
+                               // Default: the fused-FromRGB layer (encoder.b512.conv1: 1.19 ms as persistent tiles at 2 per CU, 0.98 ms at 3
+                               // per CU, 164 VGPRs) and the plain / ToRGB layers with Cin = 64, whose two K chunks unroll at compile time
+                               // (135 VGPRs instead of 184; synthesis.b512.conv2 1.34 -> 1.07 ms).  The FIR-up tile (4 chunks) needs 60 bytes
+                               // of scratch at that budget and loses 10 %: profiles/r02_w3_and_persistence_sweep.txt
   int streams = 2;             // MIGAN_STREAMS=1|2: default of migan_set_streams
   int stagger = -1;            // MIGAN_STAGGER: launch index of the first half after which the second half starts (-1: plan default)
   int debug_split = 0;         // diagnostics: keep the two-sub-batch execution in keep-intermediates mode
@@ -186,7 +187,8 @@ inline Geo choose_geo(int mode, int cin, int cout, int h_in, int w_in, bool from
   g.maing = (IMGS == 1 && GW == 16 && GH == (g.MT == 64 ? 4 : 8)) && (full || mode == MODE_UP);
   if (g.maing && g.gemmv >= 2 && g.NT == 64 && g.MT == 128 && g.KC == 32 && !g.wide && mode != MODE_PW) {
     const int bit = fromrgb ? 2 : (mode == MODE_UP ? 4 : 1);
-    if (tuning().w3 & bit) g.MINW = 3;
+    // (the plain 3-workgroup tiles are compiled for exactly two K chunks: Cin == 64, the layers they were measured on)
+    if ((tuning().w3 & bit) && (bit != 1 || cin == 64)) g.MINW = 3;
   }
   if (mode == MODE_PW || g.MT == 64) g.NI = 4;
   else if (g.KC == 16) g.NI = 3;
@@ -406,6 +408,9 @@ inline unsigned tiles_of(const Geo& g, int batch) {
 inline bool use_persistent(const Geo& g, int batch, bool fused_rgb) {
   const int total = (int)tiles_of(g, batch);
   // measured on MI355X (profiles/): +2..7 % on the 512x512 layers; with the ToRGB tail fused -7 % (first tail) / -3 % (LDS-reduction tail)
+  // 16-bit storage: the one-tile FIR-up kernel needs 164 VGPRs / 41 KB of LDS, i.e. three workgroups per CU, and beats its
+  // persistent form (226 VGPRs, two per CU): synthesis.b512.conv1 0.81 -> 0.64 ms (profiles/r02_w3_and_persistence_sweep.txt)
+  if (g.stv != 0 && g.mode == MODE_UP) return false;
   return has_persistent_variant(g) && !fused_rgb && total >= tuning().persist_min && total > tuning().persist_grid;
 }
 inline unsigned grid_of(const Geo& g, int batch, bool fused_rgb = false) {

@@ -357,6 +357,7 @@ MIGAN_DEVICE MIGAN_INLINE void compose_pixel(const unsigned char* img, const uns
 //
 // Waves are laid out 2x2 over the MT x NT tile; each wave owns (MT/2)x(NT/2) as 32x32 MFMA tiles.
 //   STV    : activation storage format (Io<STV>): 0 fp32, 1 bf16, 2 fp16
+#define BF_OF(G) ((G) >= 1)
 template <int MODE, int MT, int NT, int KC, bool FROMRGB, int NI, int MINW, bool MAING, bool PERSIST, int GEMMV, bool TORGB, int STV = 0>
 MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, MINW) sepconv_kernel(const SepArgs p) {
   static_assert(MODE != MODE_DOWN, "FIR-down layers run as dwfir_kernel + a MODE_PW pointwise GEMM");
@@ -389,6 +390,11 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, MINW) sepconv_kernel(const SepArgs p)
   constexpr int NW4 = KC * 10 / 4;                 // float4s of depthwise weights (9 taps) + bias per chunk
   constexpr int NF4 = FROMRGB ? KC * 5 / 4 : 0;    // float4s of fromrgb weights (4 per channel) + bias
   constexpr int SEGH = (MT >= 128) ? 4 : 2;        // output rows per depthwise strip (NORMAL / UP)
+  // The plain 3-workgroup tiles (MINW 3, host: Cin == 64) know their two K chunks at compile time: the loop unrolls, the prefetch
+  // registers are dead in the second chunk and the accumulators in the first (its first product reads C = 0), so the register
+  // peak drops from 184 to what three waves per SIMD allow (168) without spilling.
+  constexpr int NKC = (MINW == 3 && KC == 32 && NT == 64 && MODE == MODE_NORMAL && !FROMRGB && BF_OF(GEMMV)) ? 2 : 0;
+  constexpr bool ZEROC = NKC != 0;
 
   const char* __restrict__ gx_ = reinterpret_cast<const char*>(p.x);
   char* __restrict__ gy_ = reinterpret_cast<char*>(p.y);
@@ -591,7 +597,7 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, MINW) sepconv_kernel(const SepArgs p)
   };
 
   PROF_MARK(0);
-  const int nkc = p.CI / KC;
+  const int nkc = NKC ? NKC : p.CI / KC;
   issue_loads(b0, goff, boff, 0);
   if constexpr (FROMRGB) rraw = load_raw(b0, gy0, gx0);
 
@@ -600,16 +606,19 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, MINW) sepconv_kernel(const SepArgs p)
   const bool has_next = PERSIST && (tl + tstep < tcnt);   // PERSIST = false: exactly one tile per workgroup
   int n0n = 0, b0n = 0, gy0n = 0, gx0n = 0;
   unsigned goffn[NI], vmaskn = 0, boffn[NB];
+  if constexpr (!ZEROC) {
 #pragma unroll
-  for (int i = 0; i < MTI; ++i)
+    for (int i = 0; i < MTI; ++i)
 #pragma unroll
-    for (int j = 0; j < NTI; ++j)
+      for (int j = 0; j < NTI; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+  }
   // interior tiles (no padding anywhere in the wave's items) skip the zero-fill selects
   const bool wave_all_valid = __all(vmask == emask);
 
   // ======================================= K loop ==========================================
+#pragma unroll(NKC ? NKC : 1)
   for (int c = 0; c < nkc; ++c) {
     const int k0 = c * KC;
     float* bcur = b_s + (c & 1) * p.b_stride;
@@ -791,6 +800,7 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, MINW) sepconv_kernel(const SepArgs p)
         for (int i = 0; i < MTI; ++i)
 #pragma unroll
           for (int j = 0; j < NTI; ++j) {
+            if (ZEROC && c == 0 && ks == 0) acc[i][j] = f16v{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // (folds into the first product's C operand)
             if constexpr (X1) {
               acc[i][j] = MIGAN_MFMA_F16_32X32X16(av[i][0], bv[j][0], acc[i][j]);
             } else if constexpr (F16) {

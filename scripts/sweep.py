@@ -17,7 +17,7 @@ sys.path.insert(0, ROOT)
 import numpy as np
 import torch
 
-DEFAULTS = dict(kc16=0, kc16_minw=3, w3=2, wide=1, nt256=1, persist_min=8192, persist_grid=512, stagger=-1, stagger_pct=22)
+DEFAULTS = dict(kc16=0, kc16_minw=3, w3=3, wide=1, nt256=1, persist_min=8192, persist_grid=512, stagger=-1, stagger_pct=22)
 
 VARIANTS = [
     # label, tuning overrides, streams, dtype
@@ -28,6 +28,10 @@ VARIANTS = [
     ("kc16_plain_w3_s1", {"kc16": 1, "kc16_minw": 3}, 1, "f32"),
     ("kc16_plain_w3_s2", {"kc16": 1, "kc16_minw": 3, "stagger": 14}, 2, "f32"),
     ("nopersist_s1", {"persist_min": 1 << 30}, 1, "f32"),
+    ("w3_2_s1", {"w3": 2}, 1, "f32"),
+    ("w3_2_s2", {"w3": 2}, 2, "f32"),
+    ("bf16_w3_2_s1", {"w3": 2}, 1, "bf16"),
+    ("bf16_w3_2_s2", {"w3": 2}, 2, "bf16"),
     ("w3_none_s1", {"w3": 0}, 1, "f32"),
     ("w3_none_s2", {"w3": 0}, 2, "f32"),
     ("bf16_w3_none_s1", {"w3": 0}, 1, "bf16"),
@@ -38,6 +42,7 @@ VARIANTS = [
     ("w3_all_s1", {"w3": 7}, 1, "f32"),
     ("w3_plain_s2", {"w3": 1}, 2, "f32"),
     ("w3_all_s2", {"w3": 7}, 2, "f32"),
+    ("bf16_nopersist_s1", {"persist_min": 1 << 30}, 1, "bf16"),
     ("bf16_s1", {}, 1, "bf16"),
     ("bf16_s2", {}, 2, "bf16"),
     ("bf16_s2_stag14", {"stagger": 14}, 2, "bf16"),

@@ -20,7 +20,7 @@ def lib():
 def tuned(lib):
     """set process-wide tuning knobs for one test, restore the defaults afterwards"""
     changed = {}
-    defaults = dict(kc16=0, kc16_minw=3, w3=2, wide=1, nt256=1, persist_min=8192, persist_grid=512, streams=2, stagger=-1)
+    defaults = dict(kc16=0, kc16_minw=3, w3=3, wide=1, nt256=1, persist_min=8192, persist_grid=512, streams=2, stagger=-1)
 
     def set_(key, value):
         changed[key] = True
