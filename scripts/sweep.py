@@ -17,7 +17,7 @@ sys.path.insert(0, ROOT)
 import numpy as np
 import torch
 
-DEFAULTS = dict(kc16=0, kc16_minw=3, w3=3, wide=1, nt256=1, persist_min=8192, persist_grid=512, stagger=-1, stagger_pct=22)
+DEFAULTS = dict(kc16=0, kc16_minw=3, w3=3, wide=1, nt256=1, persist_min=8192, persist_grid=512, single_b=0, stagger=-1, stagger_pct=22)
 
 VARIANTS = [
     # label, tuning overrides, streams, dtype
@@ -32,6 +32,9 @@ VARIANTS = [
     ("w3_2_s2", {"w3": 2}, 2, "f32"),
     ("bf16_w3_2_s1", {"w3": 2}, 1, "bf16"),
     ("bf16_w3_2_s2", {"w3": 2}, 2, "bf16"),
+    ("singleb_nopersist_s1", {"single_b": 1, "persist_min": 1 << 30}, 1, "f32"),
+    ("singleb_s1", {"single_b": 1}, 1, "f32"),
+    ("bf16_singleb_nopersist_s1", {"single_b": 1, "persist_min": 1 << 30}, 1, "bf16"),
     ("w3_none_s1", {"w3": 0}, 1, "f32"),
     ("w3_none_s2", {"w3": 0}, 2, "f32"),
     ("bf16_w3_none_s1", {"w3": 0}, 1, "bf16"),
