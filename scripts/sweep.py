@@ -35,6 +35,8 @@ VARIANTS = [
     ("singleb_nopersist_s1", {"single_b": 1, "persist_min": 1 << 30}, 1, "f32"),
     ("singleb_s1", {"single_b": 1}, 1, "f32"),
     ("bf16_singleb_nopersist_s1", {"single_b": 1, "persist_min": 1 << 30}, 1, "bf16"),
+    ("w3_7_s1", {"w3": 7}, 1, "f32"),
+    ("w3_7_s2", {"w3": 7}, 2, "f32"),
     ("w3_none_s1", {"w3": 0}, 1, "f32"),
     ("w3_none_s2", {"w3": 0}, 2, "f32"),
     ("bf16_w3_none_s1", {"w3": 0}, 1, "bf16"),
