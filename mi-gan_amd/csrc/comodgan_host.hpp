@@ -95,6 +95,10 @@ struct comodgan_handle {
   const void* prepared_ws = nullptr;
   rt::stream_t prepared_stream{};   // the planes are only valid for work ordered after their preparation: same stream
   unsigned long long weights_epoch = 1, prepared_epoch = 0;
+  // the mapping network (8 small dense layers on z only) runs on a library-owned stream beside the encoder
+  rt::stream_t map_stream{};
+  rt::event_t ev_fork{}, ev_map{};
+  bool side_ready = false;
 
   int channels(int res) const { return std::min(cfg.ch_base / res, cfg.ch_max); }
   int slot_index(const std::string& n) const {
@@ -215,6 +219,7 @@ inline size_t comodgan_handle::walk(int batch, const float* x, const float* z, f
     debug_tensors.push_back(t);
   };
   bool skip_launch = false;      // set around the weight-preparation launches when their results in the workspace are still valid
+  rt::stream_t cur_stream = stream;   // the stream emit() launches on (the mapping network moves to map_stream)
   auto emit = [&](const std::string& layer, const char* kname, double flops, double mfma, double bytes, auto kernel, const auto& args,
                   unsigned grid, size_t lds) {
     if (dry) {
@@ -223,7 +228,7 @@ inline size_t comodgan_handle::walk(int batch, const float* x, const float* z, f
       infos.push_back(inf);
     } else {
       if (timed) rt_check(rt::event_record(events[2 * nlaunch], stream), "hipEventRecord");
-      if (!skip_launch) rt_check(rt::launch(kernel, args, grid, kThreads, lds, stream), kname);
+      if (!skip_launch) rt_check(rt::launch(kernel, args, grid, kThreads, lds, cur_stream), kname);
       if (timed) rt_check(rt::event_record(events[2 * nlaunch + 1], stream), "hipEventRecord");
 #ifdef MIGAN_PHASE_PROF
       if (timed) {
@@ -393,6 +398,21 @@ inline size_t comodgan_handle::walk(int batch, const float* x, const float* z, f
   float* m0 = alloc((size_t)B * cfg.w_dim * 4);
   float* m1 = alloc((size_t)B * cfg.w_dim * 4);
   float* wlat = alloc((size_t)B * cfg.w_dim * 4);
+  // The mapping network depends on z only and its eight launches are latency-bound (27 us each, 64 workgroups): they run on the
+  // handle's own stream while the caller's stream goes on with the encoder; the affine layers (first reader of w) wait for it.
+  // Ordering is by events only.  Timed / debug walks keep everything on the caller's stream.
+  const bool side = !dry && !timed && !debug;
+  if (side) {
+    if (!side_ready) {
+      rt_check(rt::stream_create(&map_stream), "hipStreamCreate");
+      rt_check(rt::event_create_sync(&ev_fork), "hipEventCreate");
+      rt_check(rt::event_create_sync(&ev_map), "hipEventCreate");
+      side_ready = true;
+    }
+    rt_check(rt::event_record(ev_fork, stream), "hipEventRecord");          // after everything already queued by the caller (z, earlier forwards)
+    rt_check(rt::stream_wait_event(map_stream, ev_fork), "hipStreamWaitEvent");
+    cur_stream = map_stream;
+  }
   {
     const float* cur = z;
     for (int i = 0; i < cfg.map_layers; ++i) {
@@ -405,6 +425,10 @@ inline size_t comodgan_handle::walk(int batch, const float* x, const float* z, f
     }
     reg_debug("mapping", wlat, {B, cfg.w_dim});
   }
+  if (side) {
+    rt_check(rt::event_record(ev_map, map_stream), "hipEventRecord");
+    cur_stream = stream;
+  }
 
   // ---------------------------------------------------------------- encoder (comodgan.py:192-204)
   float* w0 = alloc((size_t)B * cfg.w0_dim * 4);
@@ -416,7 +440,7 @@ inline size_t comodgan_handle::walk(int batch, const float* x, const float* z, f
       a.x = x; a.w = dry ? nullptr : W(bname("encoder", R) + ".fromrgb.weight"); a.b = dry ? nullptr : W(bname("encoder", R) + ".fromrgb.bias");
       a.y = cur; a.wgain = 0.5f; a.B = B; a.R = R; a.C = c0;
       emit(bname("encoder", R) + ".fromrgb", "migan::cm_fromrgb_kernel", 2.0 * 4 * c0 * R * R, 0, 4.0 * (4 + c0) * R * R, cm_fromrgb_kernel, a,
-           grid1d((size_t)B * R * R * (c0 / 4)), 0);
+           grid1d((size_t)B * R * R * (c0 / 4) / 8), 0);      // 8 pixels per thread: the weights are read once per thread
     }
     for (int res = R; res > 4; res /= 2) {
       const std::string b = bname("encoder", res);
@@ -476,6 +500,7 @@ inline size_t comodgan_handle::walk(int batch, const float* x, const float* z, f
     }
     a.blk0[a.njobs] = blk;
     a.x = wlat; a.x2 = w0; a.wgain = 1.0f / std::sqrt((float)wl); a.N = B; a.K = wl; a.K1 = cfg.w_dim;
+    if (side) rt_check(rt::stream_wait_event(stream, ev_map), "hipStreamWaitEvent");     // w from the mapping stream
     emit("synthesis.affine", "migan::cm_dense_multi_kernel", fl, 0, 2.0 * fl / B, cm_dense_multi_kernel, a, (unsigned)blk, 0);
   }
   auto styles_of = [&](const std::string& p) -> float* {
@@ -483,16 +508,55 @@ inline size_t comodgan_handle::walk(int batch, const float* x, const float* z, f
       if (af.name == p) return af.styles;
     throw Error(MIGAN_EINVAL, "internal: no affine " + p);
   };
+  // every style computation (input scales + demodulation coefficients of the modulated convs, modulated ToRGB weights) in one
+  // launch ahead of the synthesis blocks: inputs are the affine outputs above and the per-tensor weight statistics
   struct Mod { float* sa; float* coef; };
-  auto style_demod = [&](const std::string& p, const ConvW& cw) -> Mod {
-    float* styles = styles_of(p);
-    Mod m{alloc((size_t)B * cw.ci * 4), alloc((size_t)B * cw.co * 4)};
-    CmStyleArgs a{};
-    a.styles = styles; a.wsq = cw.wsq; a.wn2 = cw.wn2; a.sa = m.sa; a.coef = m.coef; a.B = B; a.CI = cw.ci; a.CO = cw.co; a.demod = 1;
-    emit(p + ".style", "migan::cm_style_kernel", 2.0 * cw.ci * cw.co, 0, 4.0 * ((double)cw.ci * cw.co + cw.ci + cw.co), cm_style_kernel, a,
-         (unsigned)(B * cdiv(cw.co, kCmStyleSlice)), (size_t)(cw.ci + 8) * 4);
-    return m;
+  struct ModEntry { std::string name; Mod m; float* wm; };
+  std::vector<ModEntry> mods;
+  {
+    CmStyleMultiArgs sm{};
+    int blk = 0;
+    size_t lds = 0;
+    double fl = 0, by = 0;
+    auto add_demod = [&](const std::string& p) {
+      const ConvW& cw = conv_of(p);
+      MIGAN_CHECK(sm.njobs < kCmMaxStyle, MIGAN_EINVAL, "internal: too many modulated layers");
+      Mod m{alloc((size_t)B * cw.ci * 4), alloc((size_t)B * cw.co * 4)};
+      CmStyleArgs& a = sm.job[sm.njobs];
+      a.styles = styles_of(p); a.wsq = cw.wsq; a.wn2 = cw.wn2; a.sa = m.sa; a.coef = m.coef; a.B = B; a.CI = cw.ci; a.CO = cw.co; a.demod = 1;
+      sm.blk0[sm.njobs++] = blk;
+      blk += B * cdiv(cw.co, kCmStyleSlice);
+      lds = std::max(lds, (size_t)(cw.ci + 8) * 4);
+      fl += 2.0 * cw.ci * cw.co; by += 4.0 * ((double)cw.ci * cw.co + cw.ci + cw.co);
+      mods.push_back({p, m, nullptr});
+    };
+    auto add_rgb = [&](const std::string& p, int c) {
+      MIGAN_CHECK(sm.njobs < kCmMaxStyle, MIGAN_EINVAL, "internal: too many modulated layers");
+      float* wm = alloc((size_t)B * 3 * c * 4);
+      CmStyleArgs& a = sm.job[sm.njobs];
+      a.styles = styles_of(p); a.w = dry ? nullptr : W(p + ".weight"); a.wm = wm; a.wgain = 1.0f / std::sqrt((float)c); a.B = B; a.CI = c; a.CO = 3; a.demod = 0;
+      sm.blk0[sm.njobs++] = blk;
+      blk += B;
+      lds = std::max(lds, (size_t)(c + 8) * 4);
+      fl += 6.0 * c; by += 4.0 * 7 * c;
+      mods.push_back({p, Mod{nullptr, nullptr}, wm});
+    };
+    add_demod("synthesis.b4.conv");
+    add_rgb("synthesis.b4.torgb", channels(4));
+    for (int res = 8; res <= R; res *= 2) {
+      add_demod(bname("synthesis", res) + ".conv0");
+      add_demod(bname("synthesis", res) + ".conv1");
+      add_rgb(bname("synthesis", res) + ".torgb", channels(res));
+    }
+    sm.blk0[sm.njobs] = blk;
+    emit("synthesis.styles", "migan::cm_style_multi_kernel", fl, 0, by, cm_style_multi_kernel, sm, (unsigned)blk, lds);
+  }
+  auto mod_of = [&](const std::string& p) -> const ModEntry& {
+    for (const auto& e : mods)
+      if (e.name == p) return e;
+    throw Error(MIGAN_EINVAL, "internal: no style job " + p);
   };
+  auto style_demod = [&](const std::string& p, const ConvW&) -> Mod { return mod_of(p).m; };
   auto noise_of = [&](const std::string& p, int res, const float*& nz, long long& bstride) {
     nz = nullptr; bstride = 0;
     if (noise_mode == COMODGAN_NOISE_CONST) nz = dry ? reinterpret_cast<const float*>(base) : W(p + ".noise_const");
@@ -500,15 +564,14 @@ inline size_t comodgan_handle::walk(int batch, const float* x, const float* z, f
     noise_off += (size_t)res * res;
   };
   auto torgb = [&](const std::string& p, const float* xin, int res, int c, const float* prev, float* out) {
-    float* styles = styles_of(p);
-    float* wm = alloc((size_t)B * 3 * c * 4);
-    CmStyleArgs s{};
-    s.styles = styles; s.w = dry ? nullptr : W(p + ".weight"); s.wm = wm; s.wgain = 1.0f / std::sqrt((float)c); s.B = B; s.CI = c; s.CO = 3; s.demod = 0;
-    emit(p + ".style", "migan::cm_style_kernel", 6.0 * c, 0, 4.0 * 7 * c, cm_style_kernel, s, (unsigned)B, (size_t)(c + 8) * 4);
+    float* wm = mod_of(p).wm;
     CmRgbArgs a{};
     a.x = xin; a.wm = wm; a.bias = dry ? nullptr : W(p + ".bias"); a.img_prev = prev; a.img_out = out; a.B = B; a.H = res; a.W = res; a.C = c;
-    emit(p, "migan::cm_torgb_kernel", 2.0 * 3 * c * res * res, 0, 4.0 * ((double)c * res * res + 3.75 * res * res), cm_torgb_kernel, a,
-         (unsigned)(((size_t)B * res * res * 16 + kThreads - 1) / kThreads), 0);
+    const double fl = 2.0 * 3 * c * res * res, by = 4.0 * ((double)c * res * res + 3.75 * res * res);
+    const auto grid_of = [&](int lpp) { return (unsigned)(((size_t)B * res * res * lpp + kThreads - 1) / kThreads); };
+    if (c <= 64) emit(p, "migan::cm_torgb_kernel<4>", fl, 0, by, cm_torgb_kernel<4>, a, grid_of(4), 0);
+    else if (c <= 128) emit(p, "migan::cm_torgb_kernel<8>", fl, 0, by, cm_torgb_kernel<8>, a, grid_of(8), 0);
+    else emit(p, "migan::cm_torgb_kernel<16>", fl, 0, by, cm_torgb_kernel<16>, a, grid_of(16), 0);
   };
   {
     const int c4 = channels(4);
@@ -609,6 +672,11 @@ int comodgan_destroy(comodgan_handle* h) {
   MIGAN_API_BEGIN
   if (h) {
     for (auto& e : h->events) rt::event_destroy(e);
+    if (h->side_ready) {
+      rt::event_destroy(h->ev_fork);
+      rt::event_destroy(h->ev_map);
+      rt::stream_destroy(h->map_stream);
+    }
     delete h;
   }
   MIGAN_API_END

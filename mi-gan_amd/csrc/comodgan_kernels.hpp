@@ -28,7 +28,7 @@
 //   cm_torgb_kernel     modulated 1x1 conv C -> 3 (no demodulation) + bias + 2x FIR upsample of the running image
 //   cm_dense_kernel     fully connected layers (mapping, affine, encoder fc, synthesis fc): weight streaming, fp32 FMA
 //   cm_wprep_kernel     per-tensor statistics: max |w| per output channel (fp16 range scale), demodulation sums of w^2
-//   cm_style_kernel     styles -> normalised input scales (with the per-sample power-of-two fp16 range scale) and
+//   cm_style_multi_kernel  styles -> normalised input scales (with the per-sample power-of-two fp16 range scale) and
 //                       demodulation coefficients, or (ToRGB) the per-sample modulated 1x1 weights
 //   cm_split_conv_kernel  3x3 weights -> two fp16 planes, [plane][tap][Cin/32][Cout][32]
 //
@@ -527,11 +527,11 @@ struct CmStyleArgs {
   int B, CI, CO, demod;
 };
 constexpr int kCmStyleSlice = 16;       // output channels per workgroup (demod); grid = B * ceil(CO / 16)
-MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, 2) cm_style_kernel(const CmStyleArgs p) {
+MIGAN_DEVICE MIGAN_INLINE void cm_style_block(const CmStyleArgs& p, int block) {
   MIGAN_DYN_SMEM(sm);            // [CI] s~^2 of this sample, then 8 floats of reduction scratch
   const int tid = threadIdx.x;
   if (!p.demod) {
-    const int b = (int)blockIdx.x;
+    const int b = block;
     const float* st = p.styles + (size_t)b * p.CI;
     for (int i = tid; i < 3 * p.CI; i += 256) {
       const int ci = i % p.CI;
@@ -540,7 +540,7 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, 2) cm_style_kernel(const CmStyleArgs 
     return;
   }
   const int nsl = (p.CO + kCmStyleSlice - 1) / kCmStyleSlice;
-  const int b = (int)blockIdx.x / nsl, sl = (int)blockIdx.x % nsl;
+  const int b = block / nsl, sl = block % nsl;
   const float* st = p.styles + (size_t)b * p.CI;
   float* red = sm + p.CI;
   float ss = 0.0f;
@@ -586,6 +586,21 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, 2) cm_style_kernel(const CmStyleArgs 
   }
 }
 
+// Every style computation of the synthesis network in one launch: they depend only on the affine outputs (one launch, above)
+// and on the weight statistics, not on activations, so the 23 small launches that used to sit between the convolutions
+// (0.4 ms of a 19 ms forward at comodgan-512) become one.
+constexpr int kCmMaxStyle = 32;
+struct CmStyleMultiArgs {
+  CmStyleArgs job[kCmMaxStyle];
+  int blk0[kCmMaxStyle + 1];     // first workgroup of each job
+  int njobs;
+};
+MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, 2) cm_style_multi_kernel(const CmStyleMultiArgs p) {
+  int j = 0;
+  while (j + 1 < p.njobs && (int)blockIdx.x >= p.blk0[j + 1]) ++j;
+  cm_style_block(p.job[j], (int)blockIdx.x - p.blk0[j]);
+}
+
 // ------------------------------------------------------------------------------------------------
 // dense (stylegan.py:64-99): y[n][o] = act((sum_k x[n][k] W[o][k]) * wgain + b[o] * bgain)
 // Optional: per-row input normalisation x * rsqrt(mean(x^2) + 1e-8) (normalize_2nd_moment, stylegan.py:351-352),
@@ -606,32 +621,58 @@ struct CmDenseArgs {
   int act, norm, in_c, out_c;
 };
 MIGAN_DEVICE MIGAN_INLINE void cm_dense_block(const CmDenseArgs& p, int block) {
+  constexpr int RP = 8;                      // batch rows per pass over the weights (16 spills)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int o0 = (block * 4 + wave) * 2;
   if (o0 >= p.O) return;
   const int no = (o0 + 1 < p.O) ? 2 : 1;
   const int K2 = p.K - p.K1;
-  for (int n0 = 0; n0 < p.N; n0 += 8) {
-    float acc[2][8], nrm[8];
+  const float* wr0 = p.w + (size_t)o0 * p.K;
+  const float* wr1 = p.w + (size_t)(o0 + (no > 1 ? 1 : 0)) * p.K;
+  for (int n0 = 0; n0 < p.N; n0 += RP) {
+    float acc[2][RP], nrm[RP];
 #pragma unroll
-    for (int r = 0; r < 8; ++r) { acc[0][r] = 0.0f; acc[1][r] = 0.0f; nrm[r] = 0.0f; }
-    for (int k = lane; k < p.K; k += 64) {
-      const float w0 = p.w[(size_t)o0 * p.K + k];
-      const float w1 = no > 1 ? p.w[(size_t)(o0 + 1) * p.K + k] : 0.0f;
-      int ks = k;
-      if (p.in_c) ks = (k & 15) * p.in_c + (k >> 4);        // NCHW flatten index c*16 + pos -> NHWC pos*C + c
+    for (int r = 0; r < RP; ++r) { acc[0][r] = 0.0f; acc[1][r] = 0.0f; nrm[r] = 0.0f; }
+    if (p.in_c) {
+      // The input is the NHWC 4x4 bottleneck [N][16][C] and feature k of the reference's NCHW flatten is c * 16 + pos: a lane
+      // owns channel c, reads its 16 weights per output row as four float4 (64 contiguous bytes per lane) and the 16 inputs
+      // x[n][pos][c] with consecutive lanes on consecutive channels -- every access coalesced (walking k in weight order
+      // would gather the inputs at a 2 KB stride)
+      for (int c = lane; c < p.in_c; c += 64) {
+#pragma unroll 1
+        for (int q = 0; q < 4; ++q) {          // (kept rolled: unrolling all 16 positions x 16 rows spills)
+          const f4 a = ld4(wr0 + (size_t)c * 16 + q * 4), bq = ld4(wr1 + (size_t)c * 16 + q * 4);
 #pragma unroll
-      for (int r = 0; r < 8; ++r) {
-        const int n = n0 + r;
-        float xv = 0.0f;
-        if (n < p.N) xv = (ks < p.K1) ? p.x[(size_t)n * p.K1 + ks] : p.x2[(size_t)n * K2 + (ks - p.K1)];
-        acc[0][r] += xv * w0;
-        acc[1][r] += xv * w1;
-        nrm[r] += xv * xv;
+          for (int e = 0; e < 4; ++e) {
+            const int pos = q * 4 + e;
+#pragma unroll
+            for (int r = 0; r < RP; ++r) {
+              const int n = n0 + r;
+              const float xv = n < p.N ? p.x[(size_t)n * p.K1 + (size_t)pos * p.in_c + c] : 0.0f;
+              acc[0][r] += xv * a[e];
+              acc[1][r] += xv * bq[e];
+              nrm[r] += xv * xv;
+            }
+          }
+        }
+      }
+    } else {
+      for (int k = lane; k < p.K; k += 64) {
+        const float w0 = wr0[k];
+        const float w1 = no > 1 ? wr1[k] : 0.0f;
+#pragma unroll
+        for (int r = 0; r < RP; ++r) {
+          const int n = n0 + r;
+          float xv = 0.0f;
+          if (n < p.N) xv = (k < p.K1) ? p.x[(size_t)n * p.K1 + k] : p.x2[(size_t)n * K2 + (k - p.K1)];
+          acc[0][r] += xv * w0;
+          acc[1][r] += xv * w1;
+          nrm[r] += xv * xv;
+        }
       }
     }
 #pragma unroll
-    for (int r = 0; r < 8; ++r) {
+    for (int r = 0; r < RP; ++r) {
 #pragma unroll
       for (int sft = 32; sft >= 1; sft >>= 1) {
         acc[0][r] += __shfl_xor(acc[0][r], sft);
@@ -639,14 +680,14 @@ MIGAN_DEVICE MIGAN_INLINE void cm_dense_block(const CmDenseArgs& p, int block) {
         if (p.norm) nrm[r] += __shfl_xor(nrm[r], sft);
       }
     }
-    if (lane < 16) {
-      const int r = lane & 7, j = lane >> 3;
+    if (lane < 2 * RP) {
+      const int r = lane & (RP - 1), j = lane / RP;
       const int n = n0 + r, o = o0 + j;
       if (n < p.N && j < no) {
         // select without dynamic register indexing
         float a = 0.0f, q = 0.0f;
 #pragma unroll
-        for (int rr = 0; rr < 8; ++rr)
+        for (int rr = 0; rr < RP; ++rr)
           if (rr == r) { a = j ? acc[1][rr] : acc[0][rr]; q = nrm[rr]; }
         if (p.norm) a = a * (1.0f / sqrtf(q / (float)p.K + 1e-8f));
         float v = a * p.wgain + p.b[o] * p.bgain;
@@ -700,21 +741,24 @@ struct CmFromRgbArgs {
   int B, R, C;
 };
 MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, 2) cm_fromrgb_kernel(const CmFromRgbArgs p) {
-  const int qn = p.C >> 2;
+  // a thread keeps one channel quad (its 4 x 4 weights and bias stay in registers) and walks pixels; 256 / (C/4) pixels per
+  // workgroup step, consecutive lanes = consecutive channel quads of a pixel (1 KiB contiguous store per wave)
+  const int qn = p.C >> 2;                      // 16 ... 256, divides 256
+  const int c4 = (int)threadIdx.x % qn;
+  const int ppb = 256 / qn;
   const size_t plane = (size_t)p.R * p.R;
-  const size_t total = (size_t)p.B * plane * qn;
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-    const int c4 = (int)(i % qn);
-    const size_t pix = i / qn;
+  const size_t npix = (size_t)p.B * plane;
+  f4 w[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) w[j] = ld4(p.w + (c4 * 4 + j) * 4) * p.wgain;
+  const f4 bias = ld4(p.b + c4 * 4);
+  for (size_t pix = (size_t)blockIdx.x * ppb + threadIdx.x / qn; pix < npix; pix += (size_t)gridDim.x * ppb) {
     const size_t bi = pix / plane, rem = pix % plane;
     const float* xp = p.x + bi * 4 * plane + rem;
     const float x0 = xp[0], x1 = xp[plane], x2 = xp[2 * plane], x3 = xp[3 * plane];
     f4 v;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const f4 w = ld4(p.w + (c4 * 4 + j) * 4) * p.wgain;
-      v[j] = (x0 * w.x + x1 * w.y + x2 * w.z + x3 * w.w) + p.b[c4 * 4 + j];
-    }
+    for (int j = 0; j < 4; ++j) v[j] = (x0 * w[j].x + x1 * w[j].y + x2 * w[j].z + x3 * w[j].w) + bias[j];
     st4(p.y + pix * p.C + c4 * 4, act4(v));
   }
 }
@@ -756,6 +800,23 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, 2) cm_fir_kernel(const CmFirArgs p) {
     const int b = (int)(blk / nby);
     const int x0 = bx * 4, y0 = by * 2;
     const float* xb = p.x + (size_t)b * p.H * p.W * p.C + c4 * 4;
+    // EPI 1: the skip tensor and the noise plane of the 2 x 4 output block are requested first, so that they travel with
+    // the 35 window loads instead of after the arithmetic that needs them last
+    f4 sk[2][4];
+    float nz[2][4];
+    if constexpr (EPI == 1) {
+#pragma unroll
+      for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const int oy = y0 + r, ox = x0 + c;
+          const bool ok = oy < p.HO && ox < p.WO;
+          sk[r][c] = f4{0.f, 0.f, 0.f, 0.f};
+          nz[r][c] = 0.0f;
+          if (ok && p.skip) sk[r][c] = ld4once(p.skip + (((size_t)b * p.HO + oy) * p.WO + ox) * p.C + c4 * 4);
+          if (ok && p.noise) nz[r][c] = p.noise[(size_t)b * p.noise_bstride + (size_t)oy * p.WO + ox];
+        }
+    }
     f4 acc[2][4];
 #pragma unroll
     for (int r = 0; r < 2; ++r)
@@ -790,9 +851,9 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, 2) cm_fir_kernel(const CmFirArgs p) {
         const size_t o = (((size_t)b * p.HO + oy) * p.WO + ox) * p.C + c4 * 4;
         f4 v = acc[r][c];
         if constexpr (EPI == 1) {
-          if (p.noise) v = v + MIGAN_FMUL_RN(p.noise[(size_t)b * p.noise_bstride + (size_t)oy * p.WO + ox], ns);
+          if (p.noise) v = v + MIGAN_FMUL_RN(nz[r][c], ns);
           v = act4(v + ld4(p.bias + c4 * 4));
-          if (p.skip) v = v + ld4once(p.skip + o);
+          if (p.skip) v = v + sk[r][c];
         }
         st4o(p.y + o, v);
       }
@@ -801,7 +862,7 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, 2) cm_fir_kernel(const CmFirArgs p) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// torgb_layer (stylegan.py:330-344) with per-sample modulated weights wm [B][3][C] (cm_style_kernel) + bias +
+// torgb_layer (stylegan.py:330-344) with per-sample modulated weights wm [B][3][C] (cm_style_multi_kernel) + bias +
 // upsample2d of the running image (comodgan.py:334-343).  16 lanes per pixel, wave-shuffle butterfly.
 struct CmRgbArgs {
   const float* x;        // NHWC [B][H][W][C]
@@ -811,9 +872,14 @@ struct CmRgbArgs {
   float* img_out;        // planar [B][3][H][W]
   int B, H, W, C;
 };
+// LPP lanes per pixel (4 for 64 channels ... 16 for >= 256): each lane reads C / (4 LPP) float4 of the pixel, a butterfly over
+// the LPP lanes forms the three sums, lane ch of the group finishes channel ch (bias, upsampled previous image) -- a wave
+// writes 64 / LPP consecutive pixels of each plane.
+template <int LPP>
 MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, 2) cm_torgb_kernel(const CmRgbArgs p) {
-  const int sub = threadIdx.x & 15;
-  const size_t pixel = ((size_t)blockIdx.x * 256 + threadIdx.x) >> 4;
+  static_assert(LPP == 4 || LPP == 8 || LPP == 16, "lanes per pixel");
+  const int sub = threadIdx.x & (LPP - 1);
+  const size_t pixel = ((size_t)blockIdx.x * 256 + threadIdx.x) / LPP;
   const size_t plane = (size_t)p.H * p.W;
   const size_t npix = (size_t)p.B * plane;
   const bool ok = pixel < npix;
@@ -822,7 +888,7 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, 2) cm_torgb_kernel(const CmRgbArgs p)
   if (ok) {
     const float* xp = p.x + pixel * p.C;
     const float* w = p.wm + (size_t)b * 3 * p.C;
-    for (int q = sub; q < (p.C >> 2); q += 16) {
+    for (int q = sub; q < (p.C >> 2); q += LPP) {
       const f4 v = ld4(xp + q * 4);
       const f4 w0 = ld4(w + q * 4), w1 = ld4(w + p.C + q * 4), w2 = ld4(w + 2 * p.C + q * 4);
       // scalar FMA chains, not SLP-vectorised packed-fp32 dot products (profiles/r02_torgb_packed_f32_hazard.md)
@@ -834,21 +900,18 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, 2) cm_torgb_kernel(const CmRgbArgs p)
     }
   }
 #pragma unroll
-  for (int s = 8; s >= 1; s >>= 1) {
+  for (int s = LPP / 2; s >= 1; s >>= 1) {
     r0 += __shfl_xor(r0, s);
     r1 += __shfl_xor(r1, s);
     r2 += __shfl_xor(r2, s);
   }
-  if (ok && sub == 0) {
+  if (ok && sub < 3) {
     const int rem = (int)(pixel % plane);
     const int oy = rem / p.W, ox = rem % p.W;
-    const float rgb[3] = {r0 + p.bias[0], r1 + p.bias[1], r2 + p.bias[2]};
-#pragma unroll
-    for (int ch = 0; ch < 3; ++ch) {
-      float up = 0.0f;
-      if (p.img_prev) up = up_prev3(p.img_prev + ((size_t)b * 3 + ch) * (plane >> 2), p.H >> 1, p.W >> 1, oy, ox);
-      p.img_out[((size_t)b * 3 + ch) * plane + rem] = up + rgb[ch];
-    }
+    const float sum = sub == 0 ? r0 : (sub == 1 ? r1 : r2);
+    float up = 0.0f;
+    if (p.img_prev) up = up_prev3(p.img_prev + ((size_t)b * 3 + sub) * (plane >> 2), p.H >> 1, p.W >> 1, oy, ox);
+    p.img_out[((size_t)b * 3 + sub) * plane + rem] = up + (sum + p.bias[sub]);
   }
 }
 
