@@ -353,7 +353,11 @@ inline size_t comodgan_handle::walk(int batch, const float* x, const float* z, f
       a.GHn = H + (ey == 0); a.GWn = Wd + (ex == 0);
       a.oy_mul = 2; a.ox_mul = 2; a.oy_add = ey; a.ox_add = ex;
     }
-    const int NT = (MTI == 4) ? 256 : ((cw.co % 128 == 0) ? 128 : 64);
+    int NT = (MTI == 4) ? 256 : ((cw.co % 128 == 0) ? 128 : 64);
+    if (mode == CM_CONV_UP4) {
+      const char* e = std::getenv("COMODGAN_UP4_NT");
+      NT = (e && std::atoi(e) == 128 && cw.co % 128 == 0) ? 128 : 64;
+    }
     const int KC = mode == CM_CONV_DOWN ? 16 : 32;          // the (2GH+1)x33-pixel tile of the strided mode is staged 16 channels at a time
     a.tiles_y = cdiv(a.GHn, GH); a.tiles_x = cdiv(a.GWn, 16); a.nchunks = cw.co / NT;
     const size_t pitch = (size_t)4 * KC + 16;                // LDS row: both fp16 planes of KC channels + 16 bytes of padding
@@ -597,10 +601,12 @@ inline size_t comodgan_handle::walk(int batch, const float* x, const float* z, f
       // conv0: modulated transposed convolution (4 output phases) -> FIR + noise + bias + activation, + skip (comodgan.py:329-331)
       const ConvW& c0w = conv_of(b + ".conv0");
       const Mod m0s = style_demod(b + ".conv0", c0w);
-      // all four phases in one launch where Cout is a multiple of 128 (measured: better at <= 64^2, equal at 128^2 / 256^2; with
-      // 64-column tiles, 512^2, the four single-phase launches are 15 % faster).  COMODGAN_UP4=0|1 forces one form (experiments / tests).
+      // all four phases in one launch, on 64-column tiles: 4 x 32 accumulator registers per lane leave room for two waves per SIMD
+      // (251 VGPRs), which the 128-column form (256 accumulators in AGPRs + 169 VGPRs, one wave per SIMD) does not.  Measured at
+      // comodgan-512, batch 16 (profiles/r02_comodgan_up4_forms.txt): seven conv0 layers 3.28 ms (128-column four-phase launches +
+      // four single-phase launches at 512^2) -> 2.86 ms.  COMODGAN_UP4=0|1 and COMODGAN_UP4_NT=64|128 force one form (experiments / tests).
       const char* up4_env = std::getenv("COMODGAN_UP4");
-      if (up4_env ? std::atoi(up4_env) != 0 : (co % 128 == 0))
+      if (up4_env ? std::atoi(up4_env) != 0 : true)
         conv(b + ".conv0.phases", CM_CONV_UP4, 0, 0, xcur, tmp, nullptr, c0w, m0s.sa, m0s.coef, 1.0f, nullptr, nullptr, nullptr, 0, h, h,
              res + 1, res + 1, true);
       else

@@ -102,7 +102,7 @@ MIGAN_DEVICE MIGAN_INLINE int cm_pixel_of_row(int r) {
 //         (-(ky == 2), -(kx == 2))).  The low-resolution input tile is staged once per chunk for all phases instead of once per
 //         phase launch, and the K loop has nine taps per chunk (the unrolled NINE path) instead of 1 / 2 / 2 / 4.
 template <int NT, int KC, int NIA, bool NINE, int MTI, bool UP4 = false>
-MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, ((MTI * NT * (UP4 ? 4 : 1) > 256) ? 1 : 2)) cm_conv_kernel(const CmConvArgs p) {
+MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, ((MTI * NT * (UP4 ? 4 : 1) > 512) ? 1 : 2)) cm_conv_kernel(const CmConvArgs p) {
   MIGAN_DYN_SMEM(smem);
   constexpr int MT = 64 * MTI, GW = 16, GH = MT / GW, WROWS = 32 * MTI;
   constexpr int WCOLS = NT / 2, NTI = WCOLS / 32;

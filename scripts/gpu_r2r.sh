@@ -21,6 +21,11 @@ E="python $R/bench.py --model migan-512 --dtype bf16 --steps 5 --warmup 2 --cpu-
 timeout 300 rocprofv3 --kernel-trace --stats -d $R/$OUT/bf16_512_trace -o t --output-format csv -- $E > $R/$OUT/bf16_512_trace.log 2>&1; echo "bf16-512 trace rc=$?"
 timeout 300 python $R/bench.py --model migan-512 --dtype bf16 --steps 20 --warmup 5 --cpu-images 2 > $R/$OUT/bench_bf16_512.json 2> $R/$OUT/bench_bf16_512.err; echo "bf16-512 bench rc=$?"
 timeout 300 python $R/bench.py --model migan-256 --steps 20 --warmup 5 --cpu-images 2 > $R/$OUT/bench_f32_256.json 2> $R/$OUT/bench_f32_256.err; echo "f32-256 bench rc=$?"
+C="python $R/bench.py --model comodgan-512 --steps 3 --warmup 2 --cpu-images 0"
+timeout 300 rocprofv3 --kernel-trace --stats -d $R/$OUT/cm_trace -o t --output-format csv -- $C > $R/$OUT/cm_trace.log 2>&1; echo "cm trace rc=$?"
+timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $R/$OUT/cm_fetch -o fetch --output-format csv -- $C > $R/$OUT/cm_fetch.log 2>&1; echo "cm fetch rc=$?"
+timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $R/$OUT/cm_write -o write --output-format csv -- $C > $R/$OUT/cm_write.log 2>&1; echo "cm write rc=$?"
+timeout 300 python $R/bench.py --model comodgan-512 --steps 10 --warmup 3 --cpu-images 0 --dump-layers $R/$OUT/cm_layers.json > $R/$OUT/cm_bench.json 2> $R/$OUT/cm_bench.err; echo "cm bench rc=$?"
 cd $R; du -sh $OUT
 python - <<'PY'
 import json

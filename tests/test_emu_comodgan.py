@@ -90,8 +90,20 @@ def test_generator_matches_reference_golden(tag):
     assert np.abs(y - g["y"]).max() <= 1e-3, np.abs(y - g["y"]).max()
     kernels = {i["kernel"] for i in info}
     assert ("migan::cm_conv_kernel<128, 32, 6, true, 2, false>" if "c128" in tag else "migan::cm_conv_kernel<64, 32, 6, true, 2, false>") in kernels
-    # synthesis conv0: all four transposed-convolution phases in one launch with 128-column tiles, one launch per phase with 64
-    assert ("migan::cm_conv_kernel<128, 32, 6, true, 2, true>" if "c128" in tag else "migan::cm_conv_kernel<64, 32, 6, false, 2, false>") in kernels
+    # synthesis conv0: all four transposed-convolution phases in one launch on 64-column tiles (two waves per SIMD)
+    assert "migan::cm_conv_kernel<64, 32, 6, true, 2, true>" in kernels
+
+
+def test_other_forms_of_the_transposed_convolution(monkeypatch):
+    """the 128-column four-phase launch (COMODGAN_UP4_NT=128) and the four single-phase launches (COMODGAN_UP4=0) stay tested"""
+    g, cfg, sd, x, z = case("r32_c128_psi")
+    monkeypatch.setenv("COMODGAN_UP4_NT", "128")
+    y, _, info = run_emu(cfg, sd, x, z, psi=float(g["psi"]))
+    assert np.abs(y - g["y"]).max() <= 1e-3 and "migan::cm_conv_kernel<128, 32, 6, true, 2, true>" in {i["kernel"] for i in info}
+    monkeypatch.delenv("COMODGAN_UP4_NT")
+    monkeypatch.setenv("COMODGAN_UP4", "0")
+    y, _, info = run_emu(cfg, sd, x, z, psi=float(g["psi"]))
+    assert np.abs(y - g["y"]).max() <= 1e-3 and "migan::cm_conv_kernel<128, 32, 6, false, 2, false>" in {i["kernel"] for i in info}
 
 
 @pytest.mark.parametrize("mode", ["none", "random"])
