@@ -312,14 +312,21 @@ inline DwGeo choose_dwfir_geo(int c, int h_in, int w_in) {
 }
 inline unsigned dwfir_grid(const DwGeo& g, int batch) { return (unsigned)(g.tiles_x * g.tiles_y * cdiv(batch, 1 << g.lgIMGS) * g.nkg); }
 typedef void (*DwFirKernelFn)(const DwFirArgs);
+// stv: activation storage format 0/1/2; + 2 (3/4) when the pointwise GEMM behind it is the "f16" variant and takes its A operand
+// ready-made (dwfir_variant)
+inline int dwfir_variant(int stv, int gemmv) { return (gemmv == 3 && stv != 0) ? stv + 2 : stv; }
 inline const char* dwfir_name(const DwGeo& g, int stv = 0) {
-  static const char* n[2][3] = {{"migan::dwfir_kernel<9, false, 0>", "migan::dwfir_kernel<9, false, 1>", "migan::dwfir_kernel<9, false, 2>"},
-                                {"migan::dwfir_kernel<7, true, 0>", "migan::dwfir_kernel<7, true, 1>", "migan::dwfir_kernel<7, true, 2>"}};
+  static const char* n[2][5] = {{"migan::dwfir_kernel<9, false, 0>", "migan::dwfir_kernel<9, false, 1>", "migan::dwfir_kernel<9, false, 2>",
+                                 "migan::dwfir_kernel<9, false, 3>", "migan::dwfir_kernel<9, false, 4>"},
+                                {"migan::dwfir_kernel<7, true, 0>", "migan::dwfir_kernel<7, true, 1>", "migan::dwfir_kernel<7, true, 2>",
+                                 "migan::dwfir_kernel<7, true, 3>", "migan::dwfir_kernel<7, true, 4>"}};
   return n[g.maing ? 1 : 0][stv];
 }
 inline DwFirKernelFn dwfir_fn(bool maing, int stv) {
-  static const DwFirKernelFn f[2][3] = {{dwfir_kernel<9, false, 0>, dwfir_kernel<9, false, 1>, dwfir_kernel<9, false, 2>},
-                                        {dwfir_kernel<7, true, 0>, dwfir_kernel<7, true, 1>, dwfir_kernel<7, true, 2>}};
+  static const DwFirKernelFn f[2][5] = {{dwfir_kernel<9, false, 0>, dwfir_kernel<9, false, 1>, dwfir_kernel<9, false, 2>,
+                                         dwfir_kernel<9, false, 3>, dwfir_kernel<9, false, 4>},
+                                        {dwfir_kernel<7, true, 0>, dwfir_kernel<7, true, 1>, dwfir_kernel<7, true, 2>,
+                                         dwfir_kernel<7, true, 3>, dwfir_kernel<7, true, 4>}};
   return f[maing ? 1 : 0][stv];
 }
 typedef void (*RgbKernelFn)(const RgbArgs);
@@ -347,6 +354,7 @@ inline void prepare_kernels() {
       rt_check(rt::allow_dynamic_lds((const void*)wide_fn(t != 0, sv), 160 * 1024), "hipFuncSetAttribute");
       if (sv) rt_check(rt::allow_dynamic_lds((const void*)wide_fn(t != 0, sv, true), 160 * 1024), "hipFuncSetAttribute");
       rt_check(rt::allow_dynamic_lds((const void*)dwfir_fn(t != 0, sv), 96 * 1024), "hipFuncSetAttribute");
+      if (sv) rt_check(rt::allow_dynamic_lds((const void*)dwfir_fn(t != 0, sv + 2), 96 * 1024), "hipFuncSetAttribute");
     }
   if (dev >= (int)done.size()) done.resize(dev + 1, 0);
   if (dev >= 0) done[dev] = 1;
@@ -746,7 +754,7 @@ inline void migan_handle::build_plan(migan::Plan& P, int H, int W) const {
         L.is_dwfir = true;
         L.hin = hs(res); L.win = ws(res); L.hout = hs(res / 2); L.wout = ws(res / 2);
         L.dg = choose_dwfir_geo(c, L.hin, L.win);
-        L.kernel = dwfir_name(L.dg, stv);
+        L.kernel = dwfir_name(L.dg, dwfir_variant(stv, gemm));
         L.cin = c; L.cout = c;
         L.in_buf = feat[ilog2(res)]; L.out_buf = DWT;
         L.w_dw = slot_index(b + ".conv2.conv1.weight");
@@ -859,7 +867,7 @@ inline void migan_handle::run_range(const migan::Plan& P, const float* x, float*
       DwFirArgs a{};
       a.x = bptr(L.in_buf); a.y = (float*)bptr(L.out_buf); a.wdw = wptr(L.w_dw); a.bdw = wptr(L.b_dw);
       a.B = n; a.H = L.hin; a.W = L.win; a.C = L.cin;
-      launch_dwfir(L.dg, a, stream, stv);
+      launch_dwfir(L.dg, a, stream, dwfir_variant(stv, gemm));
     } else if (L.is_rgb) {
       RgbArgs a{};
       a.x = bptr(L.in_buf); a.w = wptr(L.w_trgb); a.b = wptr(L.b_trgb);
@@ -1284,6 +1292,13 @@ int migan_sepconv_forward(const migan_sepconv_desc* d, void* stream) {
   MIGAN_CHECK(d->noise_const == nullptr || d->noise_strength != nullptr, MIGAN_EINVAL, "noise_const without noise_strength");
   const void* gemm_in = d->x;
   int mode = d->up == 2 ? MODE_UP : MODE_NORMAL, gemm_h = h_in, gemm_w = w_in;
+  // split GEMM variants need room for the 16-bit weight planes; without it the exact fp32 MFMA path runs
+  const size_t wsplit_need = wsplit_elems_of(d->cin, d->cout) * sizeof(unsigned short);
+  const int want = stv != 0 ? (d->gemm == MIGAN_GEMM_F16X2 ? MIGAN_GEMM_F16X2 : MIGAN_GEMM_F16) : (d->gemm >= 0 ? d->gemm : tuning().gemm);
+  MIGAN_CHECK(want >= 0 && want <= 3 && (stv != 0 || want <= 2), MIGAN_EINVAL, "unknown GEMM variant for this storage format");
+  const bool have_planes = d->wsplit != nullptr && d->wsplit_bytes >= wsplit_need;
+  MIGAN_CHECK(stv == 0 || have_planes, MIGAN_EINVAL, "16-bit activation storage needs the wsplit buffer (fp16 GEMM variants)");
+  const int gemmv = have_planes ? want : 0;
   if (d->down == 2) {
     // reference :155-161: depthwise+act+FIR at res_in (dwfir kernel), then the 1x1 at res_in/2
     MIGAN_CHECK(d->fromrgb_weight == nullptr, MIGAN_EINVAL, "fromrgb is only fused into plain layers");
@@ -1294,18 +1309,11 @@ int migan_sepconv_forward(const migan_sepconv_desc* d, void* stream) {
     DwFirArgs fa{};
     fa.x = d->x; fa.y = (float*)d->scratch; fa.wdw = (const float*)d->conv1_weight; fa.bdw = (const float*)d->conv1_bias;
     fa.B = d->batch; fa.H = h_in; fa.W = w_in; fa.C = d->cin;
-    launch_dwfir(dg, fa, (rt::stream_t)stream, stv);
+    launch_dwfir(dg, fa, (rt::stream_t)stream, dwfir_variant(stv, gemmv));
     gemm_in = d->scratch;
     mode = MODE_PW;
     gemm_h = h_out; gemm_w = w_out;
   }
-  // split GEMM variants need room for the 16-bit weight planes; without it the exact fp32 MFMA path runs
-  const size_t wsplit_need = wsplit_elems_of(d->cin, d->cout) * sizeof(unsigned short);
-  const int want = stv != 0 ? (d->gemm == MIGAN_GEMM_F16X2 ? MIGAN_GEMM_F16X2 : MIGAN_GEMM_F16) : (d->gemm >= 0 ? d->gemm : tuning().gemm);
-  MIGAN_CHECK(want >= 0 && want <= 3 && (stv != 0 || want <= 2), MIGAN_EINVAL, "unknown GEMM variant for this storage format");
-  const bool have_planes = d->wsplit != nullptr && d->wsplit_bytes >= wsplit_need;
-  MIGAN_CHECK(stv == 0 || have_planes, MIGAN_EINVAL, "16-bit activation storage needs the wsplit buffer (fp16 GEMM variants)");
-  const int gemmv = have_planes ? want : 0;
   const Geo g = choose_geo(mode, d->cin, d->cout, gemm_h, gemm_w, d->fromrgb_weight != nullptr, d->torgb_weight != nullptr, gemmv, stv);
   if (gemmv) {
     SplitArgs sa{};

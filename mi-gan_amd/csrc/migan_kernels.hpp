@@ -385,7 +385,9 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, MINW) sepconv_kernel(const SepArgs p)
   static_assert(NB >= 1 && NB * kThreads == (BF ? NPL * NT * NSLOT : NT * QC), "weight tile must split evenly over the threads");
   static_assert(!BF || KC == 32 || KC == 16, "the split GEMM variants are built for 32- or 16-channel chunks");
   // input tensor format: the network input planes (FROMRGB) and dwfir_kernel's output (MODE_PW) are always fp32
-  typedef Io<(FROMRGB || MODE == MODE_PW) ? 0 : STV> IoIn;
+  // ... except for the "f16" GEMM variant, whose dwfir_kernel<.., 3|4> writes the A operand itself (fp16 of value x 2^7)
+  constexpr bool PWH = MODE == MODE_PW && GEMMV == 3;
+  typedef Io<PWH ? 2 : ((FROMRGB || MODE == MODE_PW) ? 0 : STV)> IoIn;
   typedef Io<STV> IoOut;
   constexpr int NW4 = KC * 10 / 4;                 // float4s of depthwise weights (9 taps) + bias per chunk
   constexpr int NF4 = FROMRGB ? KC * 5 / 4 : 0;    // float4s of fromrgb weights (4 per channel) + bias
@@ -688,10 +690,19 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, MINW) sepconv_kernel(const SepArgs p)
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
           const int i = tid + j * kThreads;
-          f4 v = IoIn::cvt(rin[j]);
-          if (!(vmask & (1u << j))) v = f4{0.f, 0.f, 0.f, 0.f};
-          if constexpr (F16) v = v * kF16AScale;
-          emit_a(acur, i >> LG_QC, i & (QC - 1), v);
+          if constexpr (PWH) {
+            // the input already is the operand: 4 scaled fp16 values per item, straight into the swizzled plane
+            u2v h = rin[j];
+            if (!(vmask & (1u << j))) h = u2v{0u, 0u};
+            const int m = i >> LG_QC, c4 = i & (QC - 1);
+            char* d = reinterpret_cast<char*>(acur) + m * PB + (((c4 >> 1) ^ swz(m)) << 4) + ((c4 & 1) << 3);
+            *reinterpret_cast<u2v*>(d) = h;
+          } else {
+            f4 v = IoIn::cvt(rin[j]);
+            if (!(vmask & (1u << j))) v = f4{0.f, 0.f, 0.f, 0.f};
+            if constexpr (F16) v = v * kF16AScale;
+            emit_a(acur, i >> LG_QC, i & (QC - 1), v);
+          }
         }
       } else if (wave_all_valid) {
 #pragma unroll
@@ -1485,9 +1496,13 @@ struct DwFirArgs {
   int off_d, off_w;                // LDS carve (floats)
 };
 
+// STV 0/1/2: input stored as fp32 / bf16 / fp16, fp32 output.  STV 3/4: bf16 / fp16 input and the output written as the
+// pointwise GEMM's A operand of the "f16" variant -- fp16(RNE) of value x 2^7, exactly what that kernel would make of the
+// fp32 value (bit-identical results, half the bytes of the intermediate, no conversion in the GEMM kernel).
 template <int NI, bool MAING, int STV = 0>
 MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, 3) dwfir_kernel(const DwFirArgs p) {
-  typedef Io<STV> IoIn;
+  constexpr bool OUT16 = STV >= 3;
+  typedef Io<OUT16 ? STV - 2 : STV> IoIn;
   MIGAN_DYN_SMEM(smem);
   constexpr int KC = 16, QC = 4, LG_QC = 2, MT = 64;
   const int tid = threadIdx.x;
@@ -1508,7 +1523,8 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, 3) dwfir_kernel(const DwFirArgs p) {
   float* d_s = smem + p.off_d;
   float* w_s = smem + p.off_w;
   const char* __restrict__ xb = reinterpret_cast<const char*>(p.x) + (size_t)b0 * p.H * p.W * p.C * IoIn::ESZ;
-  float* __restrict__ yb = p.y + (size_t)b0 * HO * WO * p.C;
+  float* __restrict__ yb = OUT16 ? reinterpret_cast<float*>(reinterpret_cast<char*>(p.y) + (size_t)b0 * HO * WO * p.C * 2)
+                                : p.y + (size_t)b0 * HO * WO * p.C;
 
   // per-thread item descriptors (constant across the channel chunks this workgroup walks)
   unsigned goff[NI];
@@ -1625,7 +1641,9 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, 3) dwfir_kernel(const DwFirArgs p) {
           a += (fy * fx * (1.0f / 64.0f)) * ld4(dp + (ky * DW + kx) * KC);
         }
       }
-      st4o(yb + (unsigned)((((img * HO) + gy0 + oy) * WO + gx0 + ox) * p.C + k0 + c4 * 4), a);
+      const unsigned oel = (unsigned)((((img * HO) + gy0 + oy) * WO + gx0 + ox) * p.C + k0 + c4 * 4);
+      if constexpr (OUT16) Io<2>::st(reinterpret_cast<char*>(yb), oel * 2u, a * kF16AScale);
+      else st4o(yb + oel, a);
     }
   }
 }
