@@ -21,8 +21,17 @@ MAGIC = b"__CLANG_OFFLOAD_BUNDLE__"
 TARGET = "hipv4-amdgcn-amd-amdhsa--gfx950"
 
 
+def code_objects(lib, tmp):
+    """paths of the gfx950 code objects inside the library, one per translation unit"""
+    return [co for co, _ in _unbundle(lib, tmp, disassemble=False)]
+
+
 def device_disassembly(lib, tmp):
     """one disassembly per translation unit of the library (its .hip_fatbin section is a sequence of offload bundles)"""
+    return [text for _, text in _unbundle(lib, tmp, disassemble=True)]
+
+
+def _unbundle(lib, tmp, disassemble):
     fat = os.path.join(tmp, "fat.bin")
     subprocess.run([f"{LLVM}/llvm-objcopy", "-O", "binary", "--only-section=.hip_fatbin", lib, fat], check=True)
     data = open(fat, "rb").read()
@@ -36,7 +45,8 @@ def device_disassembly(lib, tmp):
             f.write(data[o:end])
         subprocess.run([f"{LLVM}/clang-offload-bundler", "--unbundle", "--type=o", f"--targets={TARGET}", f"--input={b}", f"--output={co}"],
                        check=True)
-        out.append(subprocess.run([f"{LLVM}/llvm-objdump", "-d", co], check=True, capture_output=True, text=True).stdout)
+        out.append((co, subprocess.run([f"{LLVM}/llvm-objdump", "-d", co], check=True, capture_output=True, text=True).stdout
+                    if disassemble else ""))
     return out
 
 
@@ -64,3 +74,62 @@ def test_no_packed_fp32_fma_or_add_with_low_lane_operand_swizzle(tmp_path):
     # the scan really saw the product kernels
     assert any("sepconv_kernel" in k for k in kernels) and any("cm_conv_kernel" in k for k in kernels) and mfma > 1000
     assert not bad, "hazardous packed-fp32 instruction form in: " + ", ".join(f"{k[:80]} ({op} x{n})" for (k, op), n in bad.most_common(8))
+
+
+def kernel_resources(lib, tmp):
+    """{demangled-ish kernel name: dict(vgpr, agpr, scratch, sgpr_spill, vgpr_spill)} from the code objects' metadata notes"""
+    res = {}
+    for co in code_objects(lib, tmp):
+        txt = subprocess.run([f"{LLVM}/llvm-readelf", "--notes", co], check=True, capture_output=True, text=True).stdout
+        cur = {}
+        for line in txt.split("\n"):
+            m = re.match(r"\s*-?\s*\.(agpr_count|name|private_segment_fixed_size|sgpr_spill_count|vgpr_count|vgpr_spill_count):\s*(\S+)", line)
+            if not m:
+                continue
+            if m.group(1) == "agpr_count" and cur.get("name"):
+                res[cur["name"]] = cur
+                cur = {}
+            cur[m.group(1)] = m.group(2) if m.group(1) == "name" else int(m.group(2))
+        if cur.get("name"):
+            res[cur["name"]] = cur
+    return res
+
+
+def _targs(sym):
+    """template arguments of a mangled migan kernel symbol as a tuple of ints (bools as 0/1)"""
+    m = re.search(r"I((?:L[ib]n?[0-9]+E)+)E", sym)
+    return tuple(int(v.replace("n", "-")) for _, v in re.findall(r"L([ib])(n?[0-9]+)E", m.group(1))) if m else ()
+
+
+@pytest.mark.skipif(not os.path.exists(f"{LLVM}/llvm-readelf"), reason="needs the ROCm LLVM tools")
+def test_occupancy_budgets_of_the_default_plan_kernels(tmp_path):
+    """Round 2's measured rule: a tile gains 18-21 % from a third workgroup per CU only where it fits the budget
+    WITHOUT spilling.  The kernels the default plans rely on for that must stay inside 168 VGPRs (three waves per SIMD; 128 for
+    four) with no scratch, whatever a later edit or compiler does to them; the Co-Mod-GAN four-phase tile must keep two waves."""
+    pkg = importlib.import_module("mi-gan_amd")
+    res = kernel_resources(pkg.library_path(), str(tmp_path))
+    sep = {_targs(k): v for k, v in res.items() if "sepconv_kernel" in k}
+    dwf = {_targs(k): v for k, v in res.items() if "dwfir_kernel" in k}
+    cmc = {_targs(k): v for k, v in res.items() if "cm_conv_kernel" in k}
+    assert len(sep) > 100 and len(dwf) == 10 and len(cmc) >= 8
+
+    def within(v, vgpr):
+        return v["vgpr_count"] + v["agpr_count"] <= vgpr and v["private_segment_fixed_size"] == 0 and v["vgpr_spill_count"] == 0
+
+    # (MODE, MT, NT, KC, FROMRGB, NI, MINW, MAING, PERSIST, GEMMV, TORGB, STV)
+    for gemmv, stv in ((2, 0), (3, 1), (3, 2)):
+        for torgb in (0, 1):
+            plain = sep[(0, 128, 64, 32, 0, 6, 3, 1, 0, gemmv, torgb, stv)]          # Cin = 64 plain / ToRGB tile, two unrolled chunks
+            assert within(plain, 168 if stv == 0 else 128), plain
+        assert within(sep[(0, 128, 64, 32, 1, 6, 3, 1, 0, gemmv, 0, stv)], 168)       # fused-FromRGB tile
+        if stv:
+            assert within(sep[(2, 128, 64, 32, 0, 6, 2, 1, 0, gemmv, 0, stv)], 168)   # 16-bit FIR-up tile, one tile per workgroup
+    for (ni, maing, stv), v in dwf.items():
+        if maing:
+            assert within(v, 168), (ni, maing, stv, v)                               # depthwise + FIR-down: three workgroups per CU
+    assert within(cmc[(64, 32, 6, 1, 2, 1)], 256)                                     # four-phase transposed conv: two waves per SIMD
+    # no main-geometry kernel of the f16x2 / f16 GEMM variants (what the 256 / 512 plans launch) runs with scratch; known to
+    # spill and not in any default plan: the 3-workgroup FIR-up tile and the 16-channel-chunk tiles at 3-4 workgroups per CU
+    spilled = sorted(k for k, v in sep.items() if v["private_segment_fixed_size"] and k[7] == 1 and k[9] in (2, 3) and k[3] == 32
+                     and not (k[0] == 2 and k[6] == 3))
+    assert spilled == [], spilled
