@@ -72,6 +72,9 @@ def parse(argv=None):
     ap.add_argument("--cpu-images", type=int, default=4, help="sample size of the CPU baseline (0 = skip)")
     ap.add_argument("--no-gather", action="store_true", help="N>1: skip the output all-gather")
     ap.add_argument("--no-secondary", action="store_true", help="N=1 default run: skip the secondary workloads")
+    ap.add_argument("--cpu-all-cores", action="store_true",
+                    help="also time the CPU port on every logical core (on the 256-thread host of the GPU box: 0.015 images/s, ~70 s per "
+                         "image -- oversubscription; off by default so that the default run stays within minutes)")
     ap.add_argument("--cpu-threads", type=int, default=16,
                     help="threads of the CPU baseline (0 = all logical cores); 16 is the fastest setting measured for this\n"
                          "graph of small oneDNN convs on the 256-thread GPU-box host (8: 1.04, 16: 0.94, 32: 1.07, 64: 1.72, 128: 4.4 s/img)")
@@ -350,7 +353,7 @@ def run_workload(args, rank, local_rank, world, dist, dev):
         cpu = {"value": round(n / sec, 4), "unit": "images/sec", "cores": int(threads), "kind": "port",
                "sample": f"{n} image(s) of the same {name}-{res} batch, fp32, {wl['cpu_desc']}, timed after 1 warm-up, "
                          f"{threads} threads (the fastest setting measured on this class of host), host has {cores} logical cores"}
-        if name == "migan" and args.model == "migan-512" and args.dtype == "f32" and not args.resolution:
+        if args.cpu_all_cores and name == "migan":
             if cores > threads:
                 _, _, sec_all = wl["cpu_ref"](1, cores, timed_runs=1)      # the all-cores figure, for the record (1 image, 1 run)
                 cpu["value_all_cores"] = round(1 / sec_all, 4)
