@@ -150,3 +150,42 @@ def test_sharded_comodgan_forward_world2_gloo(pkg, tmp_path):
         got = np.load(tmp_path / f"cm_{r}.npy")
         assert got.shape == want.shape
         assert np.abs(got - want).max() <= 1e-4 * max(1.0, np.abs(want).max())
+
+
+def _worker_u8(rank, world, port, total, res, out_dir):
+    sys.path.insert(0, ROOT)
+    import importlib
+    pkg = importlib.import_module("mi-gan_amd")
+    from oracle import migan_prepost as pp
+    from oracle import migan_torch_cpu as torc
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    sd = pkg.synth.make_state_dict(res, seed=4)
+    img, mask = pkg.synth.make_uint8_input(total, res, seed=4)
+
+    def fwd(img_t, mask_t):                         # stands in for Generator.forward_uint8 (demo.py:56-66, forward, :135-140)
+        i, m = img_t.numpy(), mask_t.numpy()
+        return torch.from_numpy(pp.compose(torc.generator(pp.preprocess(i, m), sd, res).numpy(), i, m))
+
+    out = pkg.distributed.sharded_forward(fwd, (torch.from_numpy(img), torch.from_numpy(mask)))
+    assert out.dtype == torch.uint8 and tuple(out.shape) == (total, res, res, 3)
+    np.save(os.path.join(out_dir, f"u8_{rank}.npy"), out.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("total", [4, 3])
+def test_sharded_uint8_forward_world2_gloo(pkg, tmp_path, total):
+    """the uint8-in / uint8-out form: image + mask sharded alike, composed uint8 shards gathered (a quarter of the
+    fp32 bytes per rank), every rank ends up with the single-process result"""
+    from oracle import migan_prepost as pp
+    from oracle import migan_torch_cpu as torc
+    res, world = 8, 2
+    mp.spawn(_worker_u8, args=(world, _free_port(), total, res, str(tmp_path)), nprocs=world, join=True)
+    sd = pkg.synth.make_state_dict(res, seed=4)
+    img, mask = pkg.synth.make_uint8_input(total, res, seed=4)
+    want = pp.compose(torc.generator(pp.preprocess(img, mask), sd, res).numpy(), img, mask)
+    for r in range(world):
+        np.testing.assert_array_equal(np.load(tmp_path / f"u8_{r}.npy"), want)
