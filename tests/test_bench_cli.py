@@ -57,3 +57,40 @@ def test_uint8_source_of_the_synthetic_input_matches_it():
     img, mask = synth.make_uint8_input(3, 32, seed=5)
     assert img.dtype == np.uint8 and img.shape == (3, 32, 32, 3) and set(np.unique(mask)) <= {0, 255}
     np.testing.assert_array_equal(pp.preprocess(img, mask), synth.make_input(3, 32, seed=5))
+
+
+def test_roofline_arithmetic_on_synthetic_launches():
+    """roofline_from_launches: dominant kernel = largest share of GPU time; its binding roof = the one that gives the longer time
+    for its algorithmic work; achieved = algorithmic bytes (flops) of its launches / their summed duration; attach_traffic looks
+    the kernel up by the symbol rocprofv3 prints and says so when it is missing."""
+    import importlib.util
+    import json as _json
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    batch = 32
+    launches = [
+        dict(layer="a", kernel="k_stream", flops=1e9, mfma_flops=0.5e9, bytes=30e6),      # per image: 32 x 30 MB = 0.96 GB per launch
+        dict(layer="b", kernel="k_stream", flops=1e9, mfma_flops=0.5e9, bytes=30e6),
+        dict(layer="c", kernel="k_gemm", flops=8e9, mfma_flops=8e9, bytes=1e6),
+    ]
+    rounds = [[0.30, 0.30, 0.40], [0.32, 0.28, 0.40], [0.30, 0.30, 0.41]]                # ms per launch, three rounds (median is used)
+    r = b.roofline_from_launches(launches, rounds, batch, "f16x2")
+    assert r["kernel"] == "k_stream" and r["launches"] == 2 and r["bound"] == "hbm" and r["peak"] == 8000.0
+    want = 2 * 32 * 30e6 / 0.60e-3 / 1e9
+    assert abs(r["achieved"] - want) < 0.01 and abs(r["frac"] - want / 8000.0) < 1e-4
+    assert abs(r["avg_launch_ms"] - 0.30) < 1e-9 and abs(r["share_of_gpu_time"] - 0.6) < 1e-3
+    assert r["alg_per_launch"]["bytes"] == 32 * 30e6
+    wf = r["whole_forward"]
+    assert abs(wf["sum_kernel_ms"] - 1.0) < 1e-9 and abs(wf["hbm_gbs"] - (32 * 61e6) / 1e-3 / 1e9) < 0.1
+    # a matrix-bound dominant kernel is priced against the f16x2 ceiling (2500 / 3 algorithmic TFLOP/s)
+    r2 = b.roofline_from_launches(launches, [[0.1, 0.1, 0.9]], batch, "f16x2")
+    assert r2["kernel"] == "k_gemm" and r2["bound"] == "mfma" and abs(r2["peak"] - 833.3) < 0.1
+    assert abs(r2["achieved"] - 32 * 8e9 / 0.9e-3 / 1e12) < 0.01
+    # traffic lookup
+    b.attach_traffic(r, "profiles/pmc_traffic_latest.json", True)
+    assert r["traffic"] is None and "not in" in r["traffic_note"]
+    real = next(iter(_json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic_latest.json")))))
+    r["kernel"] = real
+    b.attach_traffic(r, "profiles/pmc_traffic_latest.json", True)
+    assert r["traffic"] and r["traffic"] > 0
