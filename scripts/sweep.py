@@ -50,6 +50,8 @@ VARIANTS = [
     ("bf16_nopersist_s1", {"persist_min": 1 << 30}, 1, "bf16"),
     ("bf16_s1", {}, 1, "bf16"),
     ("bf16_s2", {}, 2, "bf16"),
+    ("bf16_s2_stag8", {"stagger": 8}, 2, "bf16"),
+    ("bf16_s2_stag12", {"stagger": 12}, 2, "bf16"),
     ("bf16_s2_stag14", {"stagger": 14}, 2, "bf16"),
     ("bf16_s4_stag7", {"stagger": 7}, 4, "bf16"),
     ("f16_s2", {}, 2, "f16"),
