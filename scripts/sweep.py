@@ -23,6 +23,8 @@ VARIANTS = [
     # label, tuning overrides, streams, dtype
     ("base_s1", {}, 1, "f32"),
     ("base_s2", {}, 2, "f32"),
+    ("base_s3", {}, 3, "f32"),
+    ("bf16_s3", {}, 3, "bf16"),
 ] + [(f"s2_stag{k}", {"stagger": k}, 2, "f32") for k in (8, 10, 12, 14, 16, 18, 22)] + [
     (f"s4_stag{k}", {"stagger": k}, 4, "f32") for k in (3, 5, 7, 9, 11, 14)] + [
     ("kc16_plain_w3_s1", {"kc16": 1, "kc16_minw": 3}, 1, "f32"),
