@@ -292,6 +292,8 @@ inline size_t comodgan_handle::walk(int batch, const float* x, const float* z, f
   // ---------------------------------------------------------------- helpers for the layers
   auto dense = [&](const std::string& layer, const float* xin, const float* xin2, int K, int K1, const std::string& wname, int O,
                    float* out, float lr_multi, bool act, bool norm, int in_c, int out_c, const float* add, const float* lerp0) {
+    // (the kernel's NHWC-bottleneck path walks channels x 16 positions of ONE input tensor)
+    MIGAN_CHECK(in_c == 0 || (K == 16 * in_c && K1 == K && xin2 == nullptr), MIGAN_EINVAL, "internal: bottleneck dense layer must read one [N][16][C] tensor");
     CmDenseArgs a{};
     a.x = xin; a.x2 = xin2; a.w = dry ? nullptr : W(wname + ".weight"); a.b = dry ? nullptr : W(wname + ".bias");
     a.add = add; a.lerp0 = lerp0; a.y = out;
