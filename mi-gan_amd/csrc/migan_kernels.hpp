@@ -32,8 +32,10 @@
 namespace migan {
 
 typedef float f4 __attribute__((ext_vector_type(4)));
+typedef float f2v __attribute__((ext_vector_type(2)));
 typedef float f16v __attribute__((ext_vector_type(16)));
 typedef unsigned u2v __attribute__((ext_vector_type(2)));
+typedef unsigned u4v __attribute__((ext_vector_type(4)));
 
 constexpr int kThreads = 256;          // 4 wave64 per workgroup, one per SIMD
 
