@@ -9,6 +9,7 @@ kernels (migan_hip.hip) and one unit per slice of the fused-SeparableConv2d kern
 """
 from __future__ import annotations
 
+import hashlib
 import os
 import shutil
 import subprocess
@@ -50,22 +51,38 @@ def units(extra: Sequence[str] = ()) -> List[Tuple[str, List[str]]]:
     return [(o, cmd + ["-o", o]) for o, cmd in out]
 
 
-def is_fresh() -> bool:
-    if not os.path.exists(OUT):
+STAMP = OUT + ".flags"
+
+
+def flags_digest(extra: Sequence[str] = ()) -> str:
+    """what the library was compiled with (a measurement build with -DMIGAN_ABLATE / -DMIGAN_PHASE_PROF must never pass for the product)"""
+    return hashlib.sha256(" ".join([*FLAGS, *extra, *(f"{g}.{s}" for g, s in SLICES)]).encode()).hexdigest()[:16]
+
+
+def is_fresh(extra: Sequence[str] = ()) -> bool:
+    if not os.path.exists(OUT) or not os.path.exists(STAMP):
+        return False
+    if open(STAMP).read().strip() != flags_digest(extra):
         return False
     return os.path.getmtime(OUT) >= max(os.path.getmtime(s) for s in SOURCES)
 
 
-def build(force: bool = False, verbose: bool = False, extra: Sequence[str] = (), jobs: int = 0) -> str:
-    if not force and not extra and is_fresh():
+def build(force: bool = False, verbose: bool = False, extra: Sequence[str] = (), jobs: int = 0, lint: bool = True) -> str:
+    if not force and is_fresh(extra):
         return OUT
     os.makedirs(OBJ, exist_ok=True)
     us = units(extra)
+    if os.path.exists(STAMP):
+        os.remove(STAMP)                      # a failed build must not leave a stamp that vouches for a stale library
 
     def run(u):
         if verbose:
             print(" ".join(u[1]), flush=True)
-        subprocess.run(u[1], check=True, cwd=CSRC, stderr=None if verbose else subprocess.DEVNULL)
+        r = subprocess.run(u[1], cwd=CSRC, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+        if verbose and r.stderr:
+            print(r.stderr, flush=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"hipcc failed ({r.returncode}) on {os.path.basename(u[0])}:\n{r.stderr[-4000:]}")
         return u[0]
 
     with ThreadPoolExecutor(max_workers=jobs or min(len(us), os.cpu_count() or 1)) as ex:
@@ -73,7 +90,23 @@ def build(force: bool = False, verbose: bool = False, extra: Sequence[str] = (),
     link = [hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC", *objs, "-o", OUT]
     if verbose:
         print(" ".join(link), flush=True)
-    subprocess.run(link, check=True, cwd=CSRC)
+    r = subprocess.run(link, cwd=CSRC, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"link failed ({r.returncode}):\n{r.stderr[-4000:]}")
+    if lint:
+        # the packed-fp32 op_sel hazard cannot be expressed in the source: refuse a library that contains it
+        import importlib.util
+        spec = importlib.util.spec_from_file_location("migan_isa_lint", os.path.join(HERE, "isa_lint.py"))
+        isa_lint = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(isa_lint)
+        if isa_lint.available():
+            try:
+                isa_lint.check(OUT)
+            except RuntimeError:
+                os.replace(OUT, OUT + ".rejected")
+                raise
+    with open(STAMP, "w") as f:
+        f.write(flags_digest(extra) + "\n")
     return OUT
 
 

@@ -823,16 +823,29 @@ inline void migan_handle::build_plan(migan::Plan& P, int H, int W) const {
   P.shared_bytes = wbytes + noise_bytes;
   // the next sub-batch starts when the previous one is about a fifth of its launches in (measured on MI355X, migan-512 and
   // migan-256, batch 32: +6 % at launch 8..12 of 46 / 40, nothing at 4 or 20; profiles/r02_streams_stagger_sweep.txt)
-  P.stagger = std::max(0, (int)P.launches.size() * tuning().stagger_pct / 100);
-  if (tuning().stagger >= 0) P.stagger = std::min((int)P.launches.size() - 1, tuning().stagger);
+  P.stagger = (int)P.launches.size() * tuning().stagger_pct / 100;
+  if (tuning().stagger >= 0) P.stagger = tuning().stagger;
+  // always a launch that exists: the event recorded after it is what orders the next sub-batch behind the weight / noise planes
+  P.stagger = std::min(std::max(0, (int)P.launches.size() - 1), std::max(0, P.stagger));
+  // the kernels address every per-image tensor with 32-bit lane BYTE offsets and int element indices
+  for (const Launch& L : P.launches) {
+    const unsigned long long ein = (unsigned long long)L.hin * L.win * (unsigned long long)std::max(L.cin, 4);
+    const unsigned long long eout = (unsigned long long)L.hout * L.wout * (unsigned long long)std::max(L.cout, 4);
+    MIGAN_CHECK(std::max(ein, eout) < (1ull << 31) && std::max(ein, eout) * 4ull < (1ull << 32), MIGAN_EINVAL,
+                "image too large: layer " + L.layer + " would exceed the 32-bit per-image offsets of the kernels");
+  }
 }
 
 inline migan::Plan& migan_handle::plan_for(int H, int W) {
   if (H == resolution && W == resolution) return plan;
   for (auto& P : hw_plans)
     if (P.H == H && P.W == W) return P;
-  hw_plans.emplace_back();
-  build_plan(hw_plans.back(), H, W);
+  // built aside: a plan that fails half-way (geometry check, missing kernel instantiation, bad_alloc) must never be found later
+  migan::Plan fresh;
+  build_plan(fresh, H, W);
+  constexpr size_t kMaxCachedPlans = 16;
+  if (hw_plans.size() >= kMaxCachedPlans) hw_plans.erase(hw_plans.begin());     // oldest first
+  hw_plans.push_back(std::move(fresh));
   return hw_plans.back();
 }
 
@@ -1191,7 +1204,11 @@ static void migan_check_hw(const migan_handle* h, int height, int width) {
   const int q = h->resolution / 4;
   MIGAN_CHECK(height >= q && width >= q && height % q == 0 && width % q == 0, MIGAN_EINVAL,
               "height and width must be positive multiples of resolution / 4 (the network halves its input log2(resolution) - 2 times)");
-  MIGAN_CHECK((long long)height * width <= 4096ll * 4096ll, MIGAN_EINVAL, "image too large");
+  // per-layer bound on the 32-bit per-image offsets of the kernels: the largest tensor of the plan at this size is
+  // h * w * channels_at(resolution) elements at full resolution (build_plan re-checks every layer)
+  const unsigned long long top = (unsigned long long)height * width * (unsigned long long)migan::channels_at(h->resolution);
+  MIGAN_CHECK(top < (1ull << 31) && top * 4ull < (1ull << 32), MIGAN_EINVAL,
+              "image too large: height * width * channels must stay below 2^30 elements per image (32-bit offsets in the kernels)");
 }
 int migan_workspace_bytes_hw(migan_handle* h, int batch, int height, int width, size_t* bytes) {
   MIGAN_API_BEGIN

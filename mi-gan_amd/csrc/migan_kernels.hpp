@@ -248,6 +248,21 @@ MIGAN_DEVICE MIGAN_INLINE void torgb_partial(f4 v, f4 tw0, f4 tw1, f4 tw2, float
   r0 = r0 + v.w * tw0.w; MIGAN_OPAQUE_F(r0); r1 = r1 + v.w * tw1.w; MIGAN_OPAQUE_F(r1); r2 = r2 + v.w * tw2.w; MIGAN_OPAQUE_F(r2);
 }
 
+// Four output channels of EncoderBlock.fromrgb (reference :186, :194): bias + sum over the 4 input planes, as scalar FMA chains
+// separated by optimisation barriers for the same reason as torgb_partial (the operands raw.y / raw.w live in the high halves of
+// register pairs: exactly what the hazardous op_sel form of v_pk_fma_f32 reads).
+MIGAN_DEVICE MIGAN_INLINE f4 fromrgb_quad(f4 raw, f4 w0, f4 w1, f4 w2, f4 w3, f4 bb) {
+  float t0 = w0.x * raw.x, t1 = w0.y * raw.x, t2 = w0.z * raw.x, t3 = w0.w * raw.x;
+  MIGAN_OPAQUE_F(t0); MIGAN_OPAQUE_F(t1); MIGAN_OPAQUE_F(t2); MIGAN_OPAQUE_F(t3);
+  t0 = t0 + w1.x * raw.y; MIGAN_OPAQUE_F(t0); t1 = t1 + w1.y * raw.y; MIGAN_OPAQUE_F(t1);
+  t2 = t2 + w1.z * raw.y; MIGAN_OPAQUE_F(t2); t3 = t3 + w1.w * raw.y; MIGAN_OPAQUE_F(t3);
+  t0 = t0 + w2.x * raw.z; MIGAN_OPAQUE_F(t0); t1 = t1 + w2.y * raw.z; MIGAN_OPAQUE_F(t1);
+  t2 = t2 + w2.z * raw.z; MIGAN_OPAQUE_F(t2); t3 = t3 + w2.w * raw.z; MIGAN_OPAQUE_F(t3);
+  t0 = t0 + w3.x * raw.w; MIGAN_OPAQUE_F(t0); t1 = t1 + w3.y * raw.w; MIGAN_OPAQUE_F(t1);
+  t2 = t2 + w3.z * raw.w; MIGAN_OPAQUE_F(t2); t3 = t3 + w3.w * raw.w; MIGAN_OPAQUE_F(t3);
+  return f4{bb.x + t0, bb.y + t1, bb.z + t2, bb.w + t3};
+}
+
 // XCD-aware workgroup order (MI355X: block b runs on XCD b%8, each XCD has a private 4 MiB L2):
 // give every XCD one contiguous range of logical tiles so halo rows shared by neighbouring tiles
 // and the Cout chunks of one tile hit the same L2.  Bijective for any grid size.
@@ -663,11 +678,11 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, MINW) sepconv_kernel(const SepArgs p)
     if constexpr (FROMRGB) {
       if (c == 0 && tid < npix_in) st4(rgb_s + tid * 4, rraw);
       __syncthreads();                              // w_s (fromrgb weights of this chunk) and rgb_s visible
-      // x = act(fromrgb(img)) (reference :194-195), 4 -> CI pointwise with bias, per halo pixel
-      // (Do not "tidy" this loop: with the weight reads hoisted out of it, or the FMA chain started from the bias, hipcc 7.2
-      // emits v_pk_fma_f32 with low-lane op_sel swizzles for the raw.y products -- the instruction form that gives
-      // intermittently wrong results on MI355X (profiles/r02_torgb_packed_f32_hazard.md; measured: 1-2 % of the first
-      // layer's outputs wrong, different ones every launch).  tests/test_isa_lint.py scans the built code for that form.)
+      // x = act(fromrgb(img)) (reference :194-195), 4 -> CI pointwise with bias, per halo pixel.  Scalar FMA chains the vectoriser
+      // cannot fuse (fromrgb_quad): the packed form of this dot product is where hipcc 7.2 emitted v_pk_fma_f32 with low-lane
+      // op_sel swizzles for the raw.y products -- the instruction form that gives intermittently wrong results on MI355X
+      // (profiles/r02_torgb_packed_f32_hazard.md; measured: 1-2 % of the first layer's outputs wrong, different ones every
+      // launch).  mi-gan_amd/build.py scans every freshly linked library for that form and refuses it.
 #pragma unroll
       for (int j = 0; j < NI; ++j) {
         if (emask & (1u << j)) {
@@ -680,7 +695,7 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, MINW) sepconv_kernel(const SepArgs p)
             const float* wr = w_s + KC * 10 + c4 * 4;
             const f4 w0 = ld4(wr), w1 = ld4(wr + KC), w2 = ld4(wr + 2 * KC), w3 = ld4(wr + 3 * KC);   // per input, 4 channels
             const f4 bb = ld4(w_s + KC * 14 + c4 * 4);
-            v = act4(bb + (w0 * raw.x + w1 * raw.y + w2 * raw.z + w3 * raw.w));
+            v = act4(fromrgb_quad(raw, w0, w1, w2, w3, bb));
           }
           st4(in_s + i * 4, v);
         }

@@ -203,6 +203,10 @@ class MiganHandle:
     # -- per-handle options
     def set_gemm(self, variant) -> None:
         code = GEMMS[variant] if isinstance(variant, str) else int(variant)
+        if code < 0:
+            # MIGAN_GEMM_DEFAULT: what migan_create picks for this storage format (f16x2 for fp32 storage unless MIGAN_GEMM says
+            # otherwise, f16 for 16-bit storage)
+            code = GEMMS[self.lib.lib.migan_gemm_variant().decode()] if self.dtype == 0 else GEMMS["f16"]
         self.lib.check(self.lib.lib.migan_set_gemm(self._h, code))
 
     def gemm(self) -> str:

@@ -8,7 +8,6 @@ elements every launch, while the CPU emulator -- which executes the same source 
 (scalar FMA chains with optimisation barriers where the vectoriser would build it); this test keeps it that way by scanning every
 kernel of every code object.  `v_pk_mul_f32` with op_sel (used by the activation code of every kernel, run billions of times in the
 GPU parity and determinism tests) is not part of the pattern."""
-import collections
 import importlib
 import os
 import re
@@ -17,63 +16,38 @@ import subprocess
 import pytest
 
 LLVM = "/opt/rocm/lib/llvm/bin"
-MAGIC = b"__CLANG_OFFLOAD_BUNDLE__"
-TARGET = "hipv4-amdgcn-amd-amdhsa--gfx950"
+
+
+def _lint():
+    return importlib.import_module("mi-gan_amd.isa_lint")
 
 
 def code_objects(lib, tmp):
     """paths of the gfx950 code objects inside the library, one per translation unit"""
-    return [co for co, _ in _unbundle(lib, tmp, disassemble=False)]
-
-
-def device_disassembly(lib, tmp):
-    """one disassembly per translation unit of the library (its .hip_fatbin section is a sequence of offload bundles)"""
-    return [text for _, text in _unbundle(lib, tmp, disassemble=True)]
-
-
-def _unbundle(lib, tmp, disassemble):
-    fat = os.path.join(tmp, "fat.bin")
-    subprocess.run([f"{LLVM}/llvm-objcopy", "-O", "binary", "--only-section=.hip_fatbin", lib, fat], check=True)
-    data = open(fat, "rb").read()
-    offs = [m.start() for m in re.finditer(MAGIC, data)]
-    assert offs, "no device code objects found in the library"
-    out = []
-    for k, o in enumerate(offs):
-        end = offs[k + 1] if k + 1 < len(offs) else len(data)
-        b, co = os.path.join(tmp, f"b{k}.bin"), os.path.join(tmp, f"b{k}.co")
-        with open(b, "wb") as f:
-            f.write(data[o:end])
-        subprocess.run([f"{LLVM}/clang-offload-bundler", "--unbundle", "--type=o", f"--targets={TARGET}", f"--input={b}", f"--output={co}"],
-                       check=True)
-        out.append((co, subprocess.run([f"{LLVM}/llvm-objdump", "-d", co], check=True, capture_output=True, text=True).stdout
-                    if disassemble else ""))
-    return out
+    return [co for co, _ in _lint().unbundle(lib, tmp, disassemble=False)]
 
 
 @pytest.mark.skipif(not os.path.exists(f"{LLVM}/llvm-objdump"), reason="needs the ROCm LLVM tools")
 def test_no_packed_fp32_fma_or_add_with_low_lane_operand_swizzle(tmp_path):
+    """the same scan mi-gan_amd/build.py runs after every link (a hit fails the build), here on whatever the package would load"""
     pkg = importlib.import_module("mi-gan_amd")
     lib = pkg.library_path()
     if not os.path.exists(lib):
         importlib.import_module("mi-gan_amd.build").build()
-    bad = collections.Counter()
-    kernels = set()
-    mfma = 0
-    for text in device_disassembly(lib, str(tmp_path)):
-        cur = None
-        for line in text.split("\n"):
-            m = re.match(r"^[0-9a-f]+ <(\S+)>:", line)
-            if m:
-                cur = m.group(1)
-                kernels.add(cur)
-                continue
-            mfma += "v_mfma_f32_32x32x16_f16" in line
-            m = re.search(r"\b(v_pk_(?:fma|add)_f32)\b.*\bop_sel:\[([01,]+)\]", line)
-            if m and "1" in m.group(2):
-                bad[(cur, m.group(1))] += 1
+    r = _lint().scan(lib, str(tmp_path))
+    bad, kernels, mfma = r["bad"], r["kernels"], r["mfma"]
     # the scan really saw the product kernels
     assert any("sepconv_kernel" in k for k in kernels) and any("cm_conv_kernel" in k for k in kernels) and mfma > 1000
     assert not bad, "hazardous packed-fp32 instruction form in: " + ", ".join(f"{k[:80]} ({op} x{n})" for (k, op), n in bad.most_common(8))
+
+
+def test_build_refuses_measurement_builds_as_fresh(tmp_path, monkeypatch):
+    """a library compiled with extra flags (-DMIGAN_ABLATE, -DMIGAN_PHASE_PROF) must not pass for the product on the next plain build()"""
+    b = importlib.import_module("mi-gan_amd.build")
+    assert b.flags_digest(()) != b.flags_digest(("-DMIGAN_ABLATE",))
+    if os.path.exists(b.OUT) and os.path.exists(b.STAMP):
+        assert b.is_fresh(()) in (True, False)
+        assert not b.is_fresh(("-DMIGAN_PHASE_PROF",))
 
 
 def kernel_resources(lib, tmp):
