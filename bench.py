@@ -71,6 +71,10 @@ def parse(argv=None):
                          "last kernels, migan_forward_u8); the all-gather then moves uint8 shards (4x fewer bytes)")
     ap.add_argument("--cpu-images", type=int, default=4, help="sample size of the CPU baseline (0 = skip)")
     ap.add_argument("--no-gather", action="store_true", help="N>1: skip the output all-gather")
+    ap.add_argument("--force-pg", action="store_true",
+                    help="N=1: also create a one-rank NCCL (= RCCL) process group and time the same steps through the pipelined output "
+                         "gather (rccl_world1 on the line): the collective path on the hardware without a second GPU")
+    ap.add_argument("--no-latency", action="store_true", help="skip the batch-1 latency measurement (latency_b1_ms)")
     ap.add_argument("--no-secondary", action="store_true", help="N=1 default run: skip the secondary workloads")
     ap.add_argument("--cpu-all-cores", action="store_true",
                     help="also time the CPU port on every logical core (on the 256-thread host of the GPU box: 0.015 images/s, ~70 s per "
@@ -140,16 +144,43 @@ def roofline_from_launches(launches, ms_rounds, batch, gemm="f32"):
         },
         "per_kernel": {k: {"ms": round(v["ms"], 4), "launches": v["n"],
                            "mfma_tflops": round(v["mfma"] / (v["ms"] * 1e-3) / 1e12, 2) if v["ms"] > 0 else 0.0,
-                           "gbs": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1) if v["ms"] > 0 else 0.0}
+                           "gbs": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1) if v["ms"] > 0 else 0.0,
+                           "alg_bytes_per_launch": round(v["bytes"] / v["n"]),
+                           "hbm_frac": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9 / PEAK_HBM_GBS, 4) if v["ms"] > 0 else 0.0,
+                           "mfma_frac": round(v["mfma"] / (v["ms"] * 1e-3) / 1e12 / peak_mfma, 4) if v["ms"] > 0 else 0.0}
                        for k, v in groups.items()},
     }
     return roof
 
 
+def flush_c_stdio():
+    """RCCL prints a version banner through C stdio when a communicator is created; with stdout redirected that text sits in libc's
+    buffer until exit and would land AFTER the JSON line.  Push it out now so that the JSON line stays the last line."""
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:   # pragma: no cover
+        pass
+    sys.stdout.flush()
+
+
+def kernel_source_sha():
+    """digest of the kernel + host sources the loaded library was built from (what a PMC traffic table must have been measured on)"""
+    import hashlib
+    csrc = os.path.join(ROOT, "mi-gan_amd", "csrc")
+    h = hashlib.sha256()
+    for f in sorted(os.listdir(csrc)):
+        if f.endswith((".hpp", ".h", ".inc", ".hip")):
+            h.update(f.encode())
+            h.update(open(os.path.join(csrc, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def attach_traffic(roof, path_rel, applies):
-    """HBM bytes per launch of the dominant kernel from the PMC passes of this same command (rocprofv3 --pmc FETCH_SIZE /
-    WRITE_SIZE in separate runs; scripts/pmc_traffic.py applies the guide's KiB unit and gfx950 x2 read correction),
-    committed under profiles/.  A kernel symbol that is not in the file is reported, not silently dropped."""
+    """HBM bytes per launch from the PMC passes of this same command (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate
+    runs; scripts/pmc_traffic.py applies the guide's KiB unit and gfx950 x2 read correction), committed under profiles/.
+    The table carries the digest of the kernel sources it was measured on: `traffic_stale` says whether that is the code
+    that just ran.  A kernel symbol that is not in the file is reported, not silently dropped."""
     path = os.path.join(ROOT, path_rel)
     if not applies:
         roof["traffic_note"] = "no PMC traffic file for this configuration"
@@ -162,9 +193,18 @@ def attach_traffic(roof, path_rel, applies):
     except Exception as e:   # pragma: no cover
         roof["traffic_note"] = f"{path_rel}: {e}"
         return
+    meta = table.get("_meta", {})
+    roof["traffic_stale"] = meta.get("kernel_source_sha") != kernel_source_sha()
+    roof["traffic_measured_on"] = meta.get("kernel_source_sha")
+    for k, v in roof.get("per_kernel", {}).items():          # every kernel of the primary: ms, algorithmic bytes, PMC bytes, fraction of the HBM peak
+        t = table.get(k)
+        if t:
+            v["pmc_bytes_per_launch"] = round(t["hbm_bytes_per_launch"])
+            if v.get("alg_bytes_per_launch"):
+                v["pmc_over_alg"] = round(t["hbm_bytes_per_launch"] / v["alg_bytes_per_launch"], 3)
     t = table.get(roof["kernel"])
     if not t:
-        roof["traffic_note"] = f"kernel symbol not in {path_rel} (stale PMC file: re-run scripts/gpu_round.sh); symbols there: {len(table)}"
+        roof["traffic_note"] = f"kernel symbol not in {path_rel} (stale PMC file: re-run the `pmc` step of scripts/gpu_visit.sh); symbols there: {len(table)}"
         print(f"bench.py: warning: dominant kernel {roof['kernel']} has no entry in {path_rel}", file=sys.stderr)
         return
     roof["traffic"] = round(t["hbm_bytes_per_launch"])
@@ -173,6 +213,44 @@ def attach_traffic(roof, path_rel, applies):
 
 # ------------------------------------------------------------------------------------------------------------------------
 # workloads: build(dev) -> dict with step(), timed(), parity_and_cpu(), descriptions
+def reference_migan(res, sd):
+    """lib/model_zoo/migan_inference.py::Generator of the reference repository with these weights, or None where the repository
+    is not present (MIGAN_REFERENCE or /root/reference; the GPU box has neither)"""
+    root = os.environ.get("MIGAN_REFERENCE", "/root/reference")
+    if not os.path.exists(os.path.join(root, "lib", "model_zoo", "migan_inference.py")):
+        return None
+    try:
+        sys.dont_write_bytecode = True
+        if root not in sys.path:
+            sys.path.append(root)
+        mod = importlib.import_module("lib.model_zoo.migan_inference")
+        m = mod.Generator(resolution=res)
+        m.load_state_dict({k: torch.from_numpy(np.array(v, copy=True)) for k, v in sd.items()}, strict=True)
+        return m.eval()
+    except Exception as e:   # pragma: no cover
+        print(f"bench.py: reference module not usable ({type(e).__name__}: {e}); timing the port", file=sys.stderr)
+        return None
+
+
+def all_cores_cpu_rate(model, cap_s=60):
+    """the CPU port on every logical core, one image, in a child process with a time limit (on the 256-thread GPU-box host one
+    migan-512 image takes longer than that: oversubscription; the 16-thread figure is the fastest measured)"""
+    import subprocess
+    code = ("import sys, time, os, importlib, torch; sys.path.insert(0, %r); pkg = importlib.import_module('mi-gan_amd'); "
+            "from oracle import migan_torch_cpu as torc; res = %d; torch.set_num_threads(os.cpu_count()); "
+            "sd = pkg.synth.make_state_dict(res, seed=0, regime='export'); x = pkg.synth.make_input(1, res, seed=100, kind='demo'); "
+            "t = time.perf_counter(); torc.generator(x, sd, res); print('RATE', 1 / (time.perf_counter() - t))"
+            % (ROOT, model))
+    try:
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=cap_s)
+        for line in r.stdout.splitlines():
+            if line.startswith("RATE"):
+                return round(float(line.split()[1]), 4), None
+        return None, "child failed: " + r.stderr[-200:]
+    except subprocess.TimeoutExpired:
+        return None, f"one image (first call, no warm-up) did not finish within the {cap_s} s cap on all {os.cpu_count()} logical cores"
+
+
 def build_migan(pkg, args, res, batch, dev, rank):
     sd = pkg.synth.make_state_dict(res, seed=0, regime="export")
     model = pkg.Generator(resolution=res, activation_dtype=args.dtype)
@@ -194,12 +272,18 @@ def build_migan(pkg, args, res, batch, dev, rank):
         torch.set_num_threads(threads)
         storage = None if args.dtype == "f32" else args.dtype
         ref = torc.generator(x_np[:n], sd, res, storage=storage)                    # warm-up + parity reference
-        times = []
-        for _ in range(timed_runs):
-            c0 = time.perf_counter()
-            torc.generator(x_np[:n], sd, res)
-            times.append(time.perf_counter() - c0)
+        refmod = reference_migan(res, sd)                   # the reference's own module when its repository is present (not on the GPU box)
+        fwd = (lambda: refmod(torch.from_numpy(x_np[:n]))) if refmod is not None else (lambda: torc.generator(x_np[:n], sd, res))
+        with torch.no_grad():
+            if refmod is not None:
+                fwd()
+            times = []
+            for _ in range(timed_runs):
+                c0 = time.perf_counter()
+                fwd()
+                times.append(time.perf_counter() - c0)
         ref32 = ref if storage is None else torc.generator(x_np[:n], sd, res)
+        cpu_ref.kind = "reference" if refmod is not None else "port"
         return ref, ref32, float(np.median(times))
 
     step, out_shape, out_dtype, post = (lambda: model(x)), (batch, 3, res, res), torch.float32, None
@@ -350,14 +434,17 @@ def run_workload(args, rank, local_rank, world, dist, dev):
         cores = os.cpu_count() or 1
         threads = min(args.cpu_threads or cores, cores)
         ref, ref32, sec = wl["cpu_ref"](n, threads)
-        cpu = {"value": round(n / sec, 4), "unit": "images/sec", "cores": int(threads), "kind": "port",
+        cpu = {"value": round(n / sec, 4), "unit": "images/sec", "cores": int(threads), "kind": getattr(wl["cpu_ref"], "kind", "port"),
                "sample": f"{n} image(s) of the same {name}-{res} batch, fp32, {wl['cpu_desc']}, timed after 1 warm-up, "
                          f"{threads} threads (the fastest setting measured on this class of host), host has {cores} logical cores"}
-        if args.cpu_all_cores and name == "migan":
-            if cores > threads:
-                _, _, sec_all = wl["cpu_ref"](1, cores, timed_runs=1)      # the all-cores figure, for the record (1 image, 1 run)
-                cpu["value_all_cores"] = round(1 / sec_all, 4)
-                cpu["all_cores"] = cores
+        if cpu["kind"] == "reference":
+            cpu["sample"] = cpu["sample"].replace(wl["cpu_desc"], "lib/model_zoo/migan_inference.py::Generator of the reference repository itself")
+        if name == "migan" and cores > threads and (args.cpu_all_cores or primary_default(args)):
+            # north star: "the node's host cores (core count stated)": the all-cores figure beside the fastest setting, capped
+            rate, why = all_cores_cpu_rate(res, cap_s=600 if args.cpu_all_cores else 100)
+            cpu["value_all_cores"], cpu["all_cores"] = rate, cores
+            if why:
+                cpu["all_cores_note"] = why
         if wl.get("post"):                                   # uint8 output: compare in uint8 steps with the composed oracle output
             parity = float((y[:n].cpu().to(torch.int16) - wl["post"](ref, n)).abs().max())
             parity32 = float((y[:n].cpu().to(torch.int16) - wl["post"](ref32, n)).abs().max())
@@ -384,6 +471,28 @@ def run_workload(args, rank, local_rank, world, dist, dev):
         "rccl_ranks": ranks_seen,
         "device": torch.cuda.get_device_name(local_rank),
     }
+    out["arith"] = {"f32": "exact fp32 MFMA (v_mfma_f32_32x32x2_f32), fp32 accumulate",
+                    "bf16x3": "bf16x3-split MFMA (6 bf16 products per fp32 product), fp32 accumulate",
+                    "f16x2": "fp16x2-split MFMA, fp32 accumulate",
+                    "f16": "fp16 MFMA on fp16-rounded operands, fp32 accumulate"}.get(wl["gemm"], wl["gemm"]) + \
+                   "; depthwise 3x3, FIR, activations, epilogues in fp32 VALU"
+    if name == "migan" and world == 1 and not args.no_latency and args.io == "f32" and not getattr(args, "is_secondary", False):
+        try:
+            lat, y1, x1 = latency_batch1(wl["model"], pkg, res, dev)
+            if args.cpu_images > 0:
+                from oracle import migan_torch_cpu as torc
+                sd1 = pkg.synth.make_state_dict(res, seed=0, regime="export")
+                ref1 = torc.generator(x1, sd1, res, storage=None if args.dtype == "f32" else args.dtype)
+                lat["max_abs_vs_ref"] = float((y1.cpu() - ref1).abs().max())
+            out["latency_b1_ms"] = lat.pop("latency_b1_ms")
+            out["latency_b1"] = lat
+        except Exception as e:   # pragma: no cover
+            out["latency_b1"] = {"error": f"{type(e).__name__}: {e}"}
+    if world == 1 and (args.force_pg or primary_default(args)):
+        try:
+            out["rccl_world1"] = rccl_world1(wl, pkg, batch, dev, max(3, min(args.steps, 10)))
+        except Exception as e:
+            out["rccl_world1"] = {"error": f"{type(e).__name__}: {str(e)[:300]}"}
     if parity32 is not None and args.dtype != "f32" and name == "migan":
         out["max_abs_vs_ref"] = parity
         out["max_abs_vs_fp32_ref"] = parity32
@@ -402,10 +511,71 @@ def run_workload(args, rank, local_rank, world, dist, dev):
     return out
 
 
+def primary_default(args):
+    """the driver's default line: BASELINE configs[2] with nothing overridden"""
+    return (args.model == "migan-512" and not args.resolution and not args.batch and args.dtype == "f32" and args.gemm == "f16x2"
+            and args.io == "f32" and not getattr(args, "is_secondary", False))
+
+
+def latency_batch1(wl_model, pkg, res, dev, n=60):
+    """scripts/demo.py:122-134 calls the model one image at a time: hipEvent time of a batch-1 forward (input on device -> output on
+    device), median / min / p90 of n after 10 warm-up calls, and its parity against the CPU port"""
+    x_np = pkg.synth.make_input(1, res, seed=900, kind="demo")
+    x = torch.from_numpy(x_np).to(dev)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
+    with torch.no_grad():
+        for _ in range(10):
+            y = wl_model(x)
+        torch.cuda.synchronize()
+        for a, b in ev:
+            a.record()
+            y = wl_model(x)
+            b.record()
+        torch.cuda.synchronize()
+    ms = sorted(a.elapsed_time(b) for a, b in ev)
+    return {"latency_b1_ms": round(ms[len(ms) // 2], 4), "min_ms": round(ms[0], 4), "p90_ms": round(ms[int(0.9 * (len(ms) - 1))], 4), "calls": n,
+            "measured": "hipEvent pair on the caller's stream around model(x), x = [1,4,R,R] resident in HBM"}, y, x_np
+
+
+def rccl_world1(wl, pkg, batch, dev, steps):
+    """a one-rank NCCL (= RCCL) process group on this GPU: the pipelined all-gather of bench.py --gpus N at world size 1"""
+    import torch.distributed as dist
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ["MASTER_PORT"] = str(free_port())
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        warm = torch.zeros(8, device=dev)
+        dist.all_reduce(warm)                               # creates the communicator (and prints RCCL's banner) now
+        torch.cuda.synchronize()
+        flush_c_stdio()
+        pipe = pkg.distributed.OutputGather(wl["out_shape"], wl.get("out_dtype", torch.float32), dev)
+        with torch.no_grad():
+            y = wl["step"]()
+            slot = pipe.submit(y)
+            same = bool(torch.equal(pipe.result(slot), y))
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                pipe.submit(wl["step"]())
+            pipe.drain()
+            torch.cuda.synchronize()
+            el = time.perf_counter() - t0
+        return {"backend": dist.get_backend(), "ranks": dist.get_world_size(), "gathered_equals_forward": same,
+                "ms_per_step": round(el / steps * 1e3, 4), "steps": steps,
+                "what": "init_process_group('nccl', world_size=1, device_id=...) + OutputGather.submit per step (all_gather_into_tensor on RCCL's stream)"}
+    finally:
+        if created:
+            dist.destroy_process_group()
+
+
 def secondary_line(base_args, **over):
     """run another workload with the same protocol in this process and return its (trimmed) line"""
     a = argparse.Namespace(**vars(base_args))
     a.dump_layers = ""
+    a.is_secondary = True
     for k, v in over.items():
         setattr(a, k, v)
     try:
@@ -472,6 +642,10 @@ def worker(rank, local_rank, world, args):
         dev = torch.device("cuda", local_rank)
         if world > 1:
             dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
+            warm = torch.zeros(8, device=dev)
+            dist.all_reduce(warm)
+            torch.cuda.synchronize()
+            flush_c_stdio()
         out = run_workload(args, rank, local_rank, world, dist, dev)
         name, res, batch = split_model(args)
         if out is not None and world == 1 and not args.no_secondary and args.model == "migan-512" and not args.resolution \
@@ -483,6 +657,8 @@ def worker(rank, local_rank, world, args):
             out["exact_f32"] = {k: ex.get(k) for k in ("value", "ms_per_step", "error") if k in ex}
             if "roofline" in ex:
                 out["exact_f32"]["whole_forward"] = ex["roofline"]["whole_forward"]
+                out["exact_f32"]["frac_vs_fp32_mfma_peak"] = round(
+                    ex["roofline"]["whole_forward"]["alg_mfma_flop"] / (ex["ms_per_step"] * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)
                 out["exact_f32"]["note"] = ("same workload with the 1x1 convs on v_mfma_f32_32x32x2_f32 (exact fp32 products): the number "
                                             "comparable to SURVEY's 5 940 images/s fp32-MFMA ceiling")
             out["secondary"] = [
@@ -496,6 +672,7 @@ def worker(rank, local_rank, world, args):
         if out.get("rccl_ranks") != args.gpus or out.get("n_gpus") != args.gpus:
             out["error"] = f"--gpus {args.gpus} but {out.get('rccl_ranks')} rank(s) took part (n_gpus {out.get('n_gpus')})"
             ok = False
+        flush_c_stdio()
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -42,7 +42,12 @@ class MiganError(RuntimeError):
 
 
 def library_path() -> str:
+    """the in-tree libmigan_hip.so; MIGAN_HIP_LIBRARY may name ANOTHER BUILD OF THE SAME LIBRARY (measurement builds for same-box
+    A/B runs: scripts/phase_profile.py) -- whatever is loaded must report the gfx950 backend, see MiganLib"""
     return os.environ.get("MIGAN_HIP_LIBRARY", os.path.join(_HERE, "csrc", _LIBNAME))
+
+
+PRODUCT_BACKEND = "hip:gfx950"
 
 
 class SepConvDesc(C.Structure):
@@ -82,7 +87,10 @@ NOISE_MODES = {"none": 0, "const": 1, "random": 2}
 class MiganLib:
     """Typed view of one loaded libmigan_hip.so."""
 
-    def __init__(self, path: Optional[str] = None):
+    def __init__(self, path: Optional[str] = None, allow_test_backend: bool = False):
+        """allow_test_backend: only the CPU test-suite passes True, with an explicit path, to drive the same host code + kernel
+        source through the fiber emulator (tests/emu); the package itself never does, so no environment variable can make the
+        product run on anything but the HIP library."""
         self.path = path or library_path()
         if not os.path.exists(self.path):
             raise MiganError(
@@ -143,6 +151,10 @@ class MiganLib:
         L.migan_last_error.restype = C.c_char_p
         L.migan_backend.restype = C.c_char_p
         L.migan_gemm_variant.restype = C.c_char_p
+        L.migan_backend.restype = C.c_char_p
+        if not allow_test_backend and L.migan_backend().decode() != PRODUCT_BACKEND:
+            raise MiganError(f"{self.path} reports backend {L.migan_backend().decode()!r}, not {PRODUCT_BACKEND!r}: only the gfx950 HIP "
+                             f"library is a product backend (the CPU emulator build is test infrastructure)")
         for name in EXPORTS:
             if name not in ("migan_last_error", "migan_backend", "migan_gemm_variant"):
                 getattr(L, name).restype = ci

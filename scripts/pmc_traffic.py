@@ -8,8 +8,23 @@ against the layers whose algorithmic read is known exactly).
 """
 import collections
 import csv
+import hashlib
 import json
+import os
 import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def kernel_source_sha():
+    """same digest as bench.py::kernel_source_sha: the sources the measured library was built from"""
+    csrc = os.path.join(ROOT, "mi-gan_amd", "csrc")
+    h = hashlib.sha256()
+    for f in sorted(os.listdir(csrc)):
+        if f.endswith((".hpp", ".h", ".inc", ".hip")):
+            h.update(f.encode())
+            h.update(open(os.path.join(csrc, f), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def avg_by_kernel(path, counter):
@@ -23,7 +38,8 @@ def avg_by_kernel(path, counter):
 
 fetch = avg_by_kernel(sys.argv[1], "FETCH_SIZE")
 write = avg_by_kernel(sys.argv[2], "WRITE_SIZE")
-out = {}
+out = {"_meta": {"kernel_source_sha": kernel_source_sha(),
+                 "note": "bench.py compares this digest with the sources of the library it runs and reports roofline.traffic_stale"}}
 for k in fetch:
     f, n = fetch[k]
     w = write.get(k, (0.0, 0))[0]

@@ -14,7 +14,7 @@ if ROOT not in sys.path:
 def emu_lib():
     from tests.emu.build_emu import build
     pkg = importlib.import_module("mi-gan_amd")
-    return pkg.hipbind.MiganLib(build())
+    return pkg.hipbind.MiganLib(build(), allow_test_backend=True)
 
 
 def nhwc(a):
