@@ -83,6 +83,8 @@ def parse(argv=None):
                     help="threads of the CPU baseline (0 = all logical cores); 16 is the fastest setting measured for this\n"
                          "graph of small oneDNN convs on the 256-thread GPU-box host (8: 1.04, 16: 0.94, 32: 1.07, 64: 1.72, 128: 4.4 s/img)")
     ap.add_argument("--dump-layers", type=str, default="", help="write per-launch hipEvent durations to this JSON file")
+    ap.add_argument("--tune", action="append", default=[], metavar="KEY=VALUE",
+                    help="experiments: migan_set_tuning(KEY, VALUE) before the model is planned (the line records it in config.tuning)")
     ap.add_argument("--backend", type=str, default="nccl", choices=["nccl", "gloo"], help="gloo: only with --dry (CPU box)")
     ap.add_argument("--dry", action="store_true",
                     help="exercise rank spawning, the process group, the output gather and the JSON line without a GPU: the forward\n"
@@ -252,6 +254,9 @@ def all_cores_cpu_rate(model, cap_s=60):
 
 
 def build_migan(pkg, args, res, batch, dev, rank):
+    for kv in args.tune:
+        k, _, v = kv.partition("=")
+        pkg.load_library().set_tuning(k, int(v))
     sd = pkg.synth.make_state_dict(res, seed=0, regime="export")
     model = pkg.Generator(resolution=res, activation_dtype=args.dtype)
     model.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd.items()})
@@ -304,7 +309,7 @@ def build_migan(pkg, args, res, batch, dev, rank):
                          ("profiles/pmc_traffic_migan256_bf16_latest.json", res == 256 and batch == 32 and args.dtype == "bf16" and gemm == "f16")),
                 data="synthetic (seeded export-like weights, demo.py-style mask+image batches)",
                 gemm_text=GEMM_TEXT.get(gemm, gemm),
-                extra_cfg=dict({"activation_storage": args.dtype, "streams": args.streams,
+                extra_cfg=dict({"activation_storage": args.dtype, "streams": args.streams, **({"tuning": args.tune} if args.tune else {}),
                                 "weights": "static (migan_assume_static_weights: 1x1 operand planes prepared once)"},
                                **({"io": "uint8 HWC image + mask in, composed uint8 image out (scripts/demo.py:56-66,135-140 inside the "
                                          "first / last kernels); parity in uint8 steps against compose(oracle output)"}
@@ -514,7 +519,7 @@ def run_workload(args, rank, local_rank, world, dist, dev):
 def primary_default(args):
     """the driver's default line: BASELINE configs[2] with nothing overridden"""
     return (args.model == "migan-512" and not args.resolution and not args.batch and args.dtype == "f32" and args.gemm == "f16x2"
-            and args.io == "f32" and not getattr(args, "is_secondary", False))
+            and args.io == "f32" and not getattr(args, "is_secondary", False) and not args.tune and not args.no_secondary and args.streams == 2)
 
 
 def latency_batch1(wl_model, pkg, res, dev, n=60):

@@ -77,7 +77,10 @@ struct Tuning {
   int gemm = 2;                // MIGAN_GEMM=f32|bf16x3|f16x2: 0 exact fp32 MFMA; 1 error-compensated bf16 MFMA (6 products of
                                // 3-way bf16 splits); 2 (default) error-compensated fp16 MFMA (3 products of scaled 2-way
                                // fp16 splits); all accumulate in fp32 and have the same end-to-end error
-  int wide = 1;                // MIGAN_WIDE=0|1: 8-wave 128 x 256 tiles for plain layers with Cout % 256 == 0 (f16x2 GEMM only)
+  int wide = 3;                // MIGAN_WIDE=0..3: 8-wave 128 x 256 tiles for plain layers with Cout % 256 == 0 (f16x2 / f16 GEMM): 1 = round-1 form
+                               // (waves 0-3 depthwise + half the MFMAs), 2 = waves 4-7 run all the MFMAs (-3..6 % per layer), 3 (default) = 2 +
+                               // LDS-DMA staging of the input tile and the weight planes where the storage is fp32 (another -5..10 %):
+                               // profiles/r03_wide_kernel.md
   int nt256 = 1;               // MIGAN_NT256=0|1: 64-pixel x 256-channel tiles for the 256-channel layer that feeds ToRGB (fuses it)
   int ablate = 0;              // MIGAN_ABLATE (measurement builds compiled with -DMIGAN_ABLATE only)
   int persist_min = 8192;      // MIGAN_PERSIST_MIN: launches with at least this many tiles run persistent workgroups
@@ -90,6 +93,8 @@ struct Tuning {
                                // per CU, 164 VGPRs) and the plain / ToRGB layers with Cin = 64, whose two K chunks unroll at compile time
                                // (135 VGPRs instead of 184; synthesis.b512.conv2 1.34 -> 1.07 ms).  The FIR-up tile (4 chunks) needs 60 bytes
                                // of scratch at that budget and loses 10 %: profiles/r02_w3_and_persistence_sweep.txt
+  int mt64 = 0;                // experiment (round 3): plain full-tile layers with Cin >= 128 on 64-pixel tiles: 1 = 64 x 128 at 3 workgroups per CU,
+                               // 2 = 64 x 256 at 2 per CU (instead of the 8-wave 128 x 256 tile / the 128 x 128 tile)
   int streams = 2;             // MIGAN_STREAMS=1|2: default of migan_set_streams
   int stagger = -1;            // MIGAN_STAGGER: launch index of the first half after which the second half starts (-1: plan default)
   int debug_split = 0;         // diagnostics: keep the two-sub-batch execution in keep-intermediates mode
@@ -100,7 +105,7 @@ inline Tuning& tuning() {
     Tuning v;
     if (const char* e = std::getenv("MIGAN_SINGLE_B")) v.force_single_b = std::atoi(e) != 0;
     if (const char* e = std::getenv("MIGAN_GEMM")) v.gemm = std::string(e) == "f32" ? 0 : (std::string(e) == "bf16x3" ? 1 : 2);
-    if (const char* e = std::getenv("MIGAN_WIDE")) v.wide = std::atoi(e) != 0;
+    if (const char* e = std::getenv("MIGAN_WIDE")) v.wide = std::atoi(e);
     if (const char* e = std::getenv("MIGAN_NT256")) v.nt256 = std::atoi(e) != 0;
     if (const char* e = std::getenv("MIGAN_ABLATE")) v.ablate = std::atoi(e);
     if (const char* e = std::getenv("MIGAN_PERSIST_MIN")) v.persist_min = std::max(1, std::atoi(e));
@@ -135,7 +140,12 @@ inline Geo choose_geo(int mode, int cin, int cout, int h_in, int w_in, bool from
   int GH, GW, IMGS;
   if (mode == MODE_NORMAL) {
     g.MT = 128; g.KC = 32;
-    if (full && cout % 256 == 0 && !fromrgb && g.gemmv >= 2 && tuning().wide) {
+    const int mt64 = (full && !fromrgb && g.gemmv >= 2 && cin >= 128 && h_in % 4 == 0) ? tuning().mt64 : 0;
+    if (mt64 == 2 && cout % 256 == 0) {
+      g.MT = 64; g.NT = 256; GH = 4; GW = 16; IMGS = 1;
+    } else if (mt64 == 1 && cout % 128 == 0) {
+      g.MT = 64; g.NT = 128; GH = 4; GW = 16; IMGS = 1;
+    } else if (full && cout % 256 == 0 && !fromrgb && g.gemmv >= 2 && tuning().wide) {
       // wide layers: one 8-wave workgroup owns 256 output channels of 8x16 pixels; half of its waves run the
       // depthwise stage of the next K chunk while the other half keeps the matrix cores busy (sepconv_wide_kernel)
       g.wide = true; g.NT = 256; GH = 8; GW = 16; IMGS = 1;
@@ -190,6 +200,7 @@ inline Geo choose_geo(int mode, int cin, int cout, int h_in, int w_in, bool from
     // (the plain 3-workgroup tiles are compiled for exactly two K chunks: Cin == 64, the layers they were measured on)
     if ((tuning().w3 & bit) && (bit != 1 || cin == 64)) g.MINW = 3;
   }
+  if (g.MT == 64 && g.NT == 128 && mode == MODE_NORMAL) g.MINW = 3;   // 32 accumulator registers per lane: three workgroups per CU
   if (mode == MODE_PW || g.MT == 64) g.NI = 4;
   else if (g.KC == 16) g.NI = 3;
   else g.NI = g.maing ? 6 : 9;
@@ -247,22 +258,28 @@ inline const std::vector<KernelEntry>& kernel_table() {
   return t;
 }
 
-inline const char* wide_name(const Geo& g) {
-  static const char* n[2][2][3] = {
-      {{"migan::sepconv_wide_kernel<false, 0, false>", "migan::sepconv_wide_kernel<false, 1, false>", "migan::sepconv_wide_kernel<false, 2, false>"},
-       {"migan::sepconv_wide_kernel<true, 0, false>", "migan::sepconv_wide_kernel<true, 1, false>", "migan::sepconv_wide_kernel<true, 2, false>"}},
-      {{"", "migan::sepconv_wide_kernel<false, 1, true>", "migan::sepconv_wide_kernel<false, 2, true>"},
-       {"", "migan::sepconv_wide_kernel<true, 1, true>", "migan::sepconv_wide_kernel<true, 2, true>"}}};
-  return n[g.gemmv == 3 ? 1 : 0][g.torgb ? 1 : 0][g.stv];
+// sepconv_wide_kernel<TORGB, STV, X1, BALL, DMA>: x1 = GEMM variant "f16" (one fp16 piece per operand; 16-bit storage only);
+// ball = waves 4-7 run all the MFMAs (tuning().wide >= 2); dma = LDS-DMA staging (tuning().wide == 3, fp32 storage)
+#define MIGAN_WIDE_ROW(T, X, B) {sepconv_wide_kernel<T, 0, X, B>, sepconv_wide_kernel<T, 1, X, B>, sepconv_wide_kernel<T, 2, X, B>}
+#define MIGAN_WIDE_NAMES(T, X, B) {"migan::sepconv_wide_kernel<" #T ", 0, " #X ", " #B ", false>", "migan::sepconv_wide_kernel<" #T ", 1, " #X ", " #B ", false>", \
+                                   "migan::sepconv_wide_kernel<" #T ", 2, " #X ", " #B ", false>"}
+inline bool wide_ball() { return tuning().wide >= 2; }
+inline bool wide_dma(int stv, bool x1) { return tuning().wide == 3 && stv == 0 && !x1; }
+inline SepKernelFn wide_fn(bool torgb, int stv, bool x1 = false, bool ball = false, bool dma = false) {
+  static const SepKernelFn f[2][2][2][3] = {
+      {{MIGAN_WIDE_ROW(false, false, false), MIGAN_WIDE_ROW(true, false, false)}, {MIGAN_WIDE_ROW(false, true, false), MIGAN_WIDE_ROW(true, true, false)}},
+      {{MIGAN_WIDE_ROW(false, false, true), MIGAN_WIDE_ROW(true, false, true)}, {MIGAN_WIDE_ROW(false, true, true), MIGAN_WIDE_ROW(true, true, true)}}};
+  if (x1 && stv == 0) return nullptr;       // the "f16" GEMM variant exists for 16-bit storage only
+  if (dma) return torgb ? sepconv_wide_kernel<true, 0, false, true, true> : sepconv_wide_kernel<false, 0, false, true, true>;
+  return f[ball ? 1 : 0][x1 ? 1 : 0][torgb ? 1 : 0][stv];
 }
-// x1: GEMM variant "f16" (one fp16 piece per operand; 16-bit storage only)
-inline SepKernelFn wide_fn(bool torgb, int stv, bool x1 = false) {
-  static const SepKernelFn f[2][2][3] = {
-      {{sepconv_wide_kernel<false, 0, false>, sepconv_wide_kernel<false, 1, false>, sepconv_wide_kernel<false, 2, false>},
-       {sepconv_wide_kernel<true, 0, false>, sepconv_wide_kernel<true, 1, false>, sepconv_wide_kernel<true, 2, false>}},
-      {{nullptr, sepconv_wide_kernel<false, 1, true>, sepconv_wide_kernel<false, 2, true>},
-       {nullptr, sepconv_wide_kernel<true, 1, true>, sepconv_wide_kernel<true, 2, true>}}};
-  return f[x1 ? 1 : 0][torgb ? 1 : 0][stv];
+inline const char* wide_name(const Geo& g) {
+  static const char* n[2][2][2][3] = {
+      {{MIGAN_WIDE_NAMES(false, false, false), MIGAN_WIDE_NAMES(true, false, false)}, {MIGAN_WIDE_NAMES(false, true, false), MIGAN_WIDE_NAMES(true, true, false)}},
+      {{MIGAN_WIDE_NAMES(false, false, true), MIGAN_WIDE_NAMES(true, false, true)}, {MIGAN_WIDE_NAMES(false, true, true), MIGAN_WIDE_NAMES(true, true, true)}}};
+  if (wide_dma(g.stv, g.gemmv == 3))
+    return g.torgb ? "migan::sepconv_wide_kernel<true, 0, false, true, true>" : "migan::sepconv_wide_kernel<false, 0, false, true, true>";
+  return n[wide_ball() ? 1 : 0][g.gemmv == 3 ? 1 : 0][g.torgb ? 1 : 0][g.stv];
 }
 inline const char* kernel_name(const Geo& g);
 inline const KernelEntry& pick_kernel(const Geo& g) {
@@ -351,8 +368,11 @@ inline void prepare_kernels() {
   for (const auto& e : kernel_table()) rt_check(rt::allow_dynamic_lds((const void*)e.fn, 96 * 1024), "hipFuncSetAttribute");
   for (int t = 0; t < 2; ++t)
     for (int sv = 0; sv < 3; ++sv) {
-      rt_check(rt::allow_dynamic_lds((const void*)wide_fn(t != 0, sv), 160 * 1024), "hipFuncSetAttribute");
-      if (sv) rt_check(rt::allow_dynamic_lds((const void*)wide_fn(t != 0, sv, true), 160 * 1024), "hipFuncSetAttribute");
+      for (int ball = 0; ball < 2; ++ball) {
+        rt_check(rt::allow_dynamic_lds((const void*)wide_fn(t != 0, sv, false, ball != 0), 160 * 1024), "hipFuncSetAttribute");
+        if (sv) rt_check(rt::allow_dynamic_lds((const void*)wide_fn(t != 0, sv, true, ball != 0), 160 * 1024), "hipFuncSetAttribute");
+      }
+      if (sv == 0) rt_check(rt::allow_dynamic_lds((const void*)wide_fn(t != 0, 0, false, true, true), 160 * 1024), "hipFuncSetAttribute");
       rt_check(rt::allow_dynamic_lds((const void*)dwfir_fn(t != 0, sv), 96 * 1024), "hipFuncSetAttribute");
       if (sv) rt_check(rt::allow_dynamic_lds((const void*)dwfir_fn(t != 0, sv + 2), 96 * 1024), "hipFuncSetAttribute");
     }
@@ -434,7 +454,8 @@ inline void launch_sepconv(Geo g, const SepArgs& a, rt::stream_t stream) {
               "ToRGB can only be fused into a plain layer whose output channels fit one column tile");
   if (g.wide) {
     MIGAN_CHECK(a.wsplit != nullptr, MIGAN_EINVAL, "internal: the wide kernel needs the fp16 weight planes");
-    rt_check(rt::launch(wide_fn(fused_rgb, g.stv, g.gemmv == 3), a, tiles_of(g, a.B), kWideThreads, g.lds_bytes, stream), wide_name(g));
+    rt_check(rt::launch(wide_fn(fused_rgb, g.stv, g.gemmv == 3, wide_ball(), wide_dma(g.stv, g.gemmv == 3)), a, tiles_of(g, a.B), kWideThreads, g.lds_bytes,
+                        stream), wide_name(g));
     return;
   }
   const KernelEntry& k = pick_kernel(g);
@@ -1411,8 +1432,9 @@ int migan_set_tuning(const char* key, int value) {
   if (k == "kc16") t.kc16 = value;
   else if (k == "kc16_minw") t.kc16_minw = std::min(4, std::max(2, value));
   else if (k == "w3") t.w3 = value;
-  else if (k == "wide") t.wide = value != 0;
+  else if (k == "wide") t.wide = value;
   else if (k == "nt256") t.nt256 = value != 0;
+  else if (k == "mt64") t.mt64 = value;
   else if (k == "persist_min") t.persist_min = std::max(1, value);
   else if (k == "persist_grid") t.persist_grid = std::max(8, value / 8 * 8);
   else if (k == "streams") t.streams = std::min(4, std::max(1, value));

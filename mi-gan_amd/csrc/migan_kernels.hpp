@@ -1140,8 +1140,19 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, MINW) sepconv_kernel(const SepArgs p)
 // Everything the K loop touches is double buffered (input tile, taps, A planes, B planes: 145 KB), so one
 // barrier per chunk suffices.  MFMA wave grid 2 x 4, each wave 64 x 64 (same fragments as sepconv_kernel).
 constexpr int kWideThreads = 512;
-template <bool TORGB, int STV = 0, bool X1 = false>
+// BALL (round 3): waves 4-7 run ALL the MFMAs (each 64 x 128 of the tile, 128 accumulator registers), waves 0-3 only the depthwise stage.
+// The ablation of the original split (profiles/r03_wide_ablation.txt) showed its A waves run depthwise and their half of the MFMAs
+// back to back while the B waves wait at the barrier: 2.5k cycles per K chunk where the matrix pipe needs 1.5k and the depthwise
+// stage 1.6k.  The two K loops are separate code paths so that the accumulators and the depthwise temporaries share registers.
+// DMA (round 3, fp32 storage): the input tile and the weight planes of a K chunk go from global memory straight into LDS
+// (buffer_load_dwordx4 ... lds) instead of through 32 prefetch registers and seven ds_write_b128 per thread -- the phase profile of
+// the register path (profiles/r03_wide_phase_profile.txt) has 60 % of a chunk in "registers -> LDS + wait for the loads".  The
+// image is a buffer descriptor, so pixels outside it (conv zero padding) are lane offsets beyond its range and arrive as zeros;
+// the XOR swizzle of the weight planes is applied to the SOURCE address (the LDS destination of a DMA is linear in the lane).
+// hipcc waits for outstanding DMAs (vmcnt(0)) at every __syncthreads(), which is exactly where the loop needs them.
+template <bool TORGB, int STV = 0, bool X1 = false, bool BALL = false, bool DMA = false>
 MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(kWideThreads, 2) sepconv_wide_kernel(const SepArgs p) {
+  static_assert(!DMA || (STV == 0 && BALL), "the LDS-DMA staging is built for fp32 storage on the dedicated-MFMA-wave form");
   typedef Io<STV> IoT;
   constexpr unsigned OE = IoT::ESZ;
   MIGAN_DYN_SMEM(smem);
@@ -1154,7 +1165,7 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(kWideThreads, 2) sepconv_wide_kernel(const
   constexpr int NB = NPL * NT * NSLOT / kWideThreads;                       // 4 float4 weight-plane items per thread and chunk
   static_assert(NB * kWideThreads == NPL * NT * NSLOT, "weight tile must split evenly over the threads");
   constexpr int NW4 = KC * 10 / 4;
-  constexpr int WN = 4, WROWS = 64, WCOLS = 64, MTI = 2, NTI = 2;
+  constexpr int WN = BALL ? 2 : 4, WROWS = 64, WCOLS = BALL ? 128 : 64, MTI = 2, NTI = BALL ? 4 : 2;
   constexpr int SEGH = 4;
   // LDS carve (floats)
   constexpr int IN_SZ = NPIX * KC, W_SZ = KC * 10, A_SZ = NPL * MT * PB / 4, B_SZ = NPL * NT * PB / 4;
@@ -1168,7 +1179,7 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(kWideThreads, 2) sepconv_wide_kernel(const
   const float* __restrict__ gnoise = p.noise;
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
-  const int wm = wave / WN, wn = wave % WN;
+  const int wm = BALL ? ((wave & 3) >> 1) : wave / WN, wn = BALL ? (wave & 1) : wave % WN;     // BALL: the 2 x 2 grid of waves 4-7
   const int l31 = lane & 31, half = lane >> 5;
   const bool groupA = tid < 256;
   PROF_BEGIN();
@@ -1214,16 +1225,90 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(kWideThreads, 2) sepconv_wide_kernel(const
   const char* __restrict__ xb = gx_ + (size_t)b0 * p.H * p.W * p.CI * OE;
   typename IoT::raw4 rin[NI];
   f4 rb[NB], rw;
-  auto load_in = [&](int k0) {                     // input tile + depthwise taps of one chunk
+  // ---- DMA form: lane offsets into the image / the weight planes, wave-uniform LDS destinations -----------------------------------
+  // MIGAN_DMA_WHO (measurement builds): which waves issue the DMAs -- 0 all eight, 1 the MFMA waves (4-7), 2 the depthwise waves (0-3)
+#ifndef MIGAN_DMA_WHO
+#define MIGAN_DMA_WHO 0
+#endif
+  constexpr int LT = MIGAN_DMA_WHO == 0 ? kWideThreads : 256;                 // loader threads
+  constexpr int DNI = DMA ? (NITEMS + LT - 1) / LT : 1, DNB = DMA ? NPL * NT * NSLOT / LT : 1;
+  const int wave_u = MIGAN_UNIFORM(wave);
+  const bool loader = MIGAN_DMA_WHO == 0 || (MIGAN_DMA_WHO == 1 ? wave_u >= 4 : wave_u < 4);
+  const int lt = MIGAN_DMA_WHO == 1 ? tid - 256 : tid, lwave = MIGAN_DMA_WHO == 1 ? wave_u - 4 : wave_u;
+  unsigned dgoff[DNI], dboff[DNB], demask = 0;
+  if constexpr (DMA) {
 #pragma unroll
-    for (int j = 0; j < NI; ++j) rin[j] = IoT::ld(xb + (size_t)k0 * OE, goff[j]);
+    for (int j = 0; j < DNI; ++j) {
+      const int i = lt + j * LT;
+      unsigned g = 0xfffff000u;                        // padding pixel: beyond the buffer -> zeros
+      if (i < NITEMS && i >= 0) {
+        demask |= 1u << j;
+        const int c4 = i & (QC - 1), pix = i >> LG_QC;
+        const int ix = pix % IGW, iy = pix / IGW;
+        const int yy = gy0 - 1 + iy, xx = gx0 - 1 + ix;
+        if (yy >= 0 && yy < p.H && xx >= 0 && xx < p.W) g = (unsigned)((yy * p.W + xx) * p.CI + c4 * 4) * OE;
+      }
+      dgoff[j] = g;
+    }
+#pragma unroll
+    for (int j = 0; j < DNB; ++j) {
+      const int i = (lt & (LT - 1)) + j * LT;          // 16-byte unit number inside the LDS image of the weight tile (linear)
+      const int plane = i / (NT * NSLOT), rem = i % (NT * NSLOT);
+      const int n = rem / NSLOT, sp = rem % NSLOT;     // LDS row n, stored slot sp holds source slot sp ^ swizzle(n)
+      dboff[j] = (unsigned)(plane * p.CO * p.CI + (n0 + n) * KC + ((sp ^ ((n >> 2) & (NSLOT - 1))) * 8)) * 2u;
+    }
+  }
+  const MIGAN_BUF xbuf = MIGAN_MAKE_BUF(xb, (unsigned)(p.H * p.W * p.CI) * OE);
+  const MIGAN_BUF wbuf = MIGAN_MAKE_BUF(p.wsplit, 0x7ffffff0u);
+  auto load_taps = [&](int k0) {
+    if (tid < KC * 9 / 4) rw = ld4(p.wdw + (size_t)k0 * 9 + (unsigned)(tid * 4));
+    else if (tid < NW4) rw = ld4(p.bdw + k0 + (unsigned)((tid - KC * 9 / 4) * 4));
+  };
+  auto store_taps = [&](int buf) {
+    float* w_s = smem + OFF_W + buf * W_SZ;
+    if (tid < KC * 9 / 4) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int f = tid * 4 + e;                   // flat index into [KC][9] -> tap-major [9][KC]
+        w_s[(f % 9) * KC + f / 9] = rw[e];
+      }
+    } else if (tid < NW4) {
+      st4(w_s + tid * 4, rw);
+    }
+  };
+  auto dma_in = [&](int k0, int buf) {               // input tile of one chunk -> in_s[buf]
+    float* in_s = smem + OFF_IN + buf * IN_SZ;
+    if (!loader) return;
+#pragma unroll
+    for (int j = 0; j < DNI; ++j)
+      if (demask & (1u << j)) MIGAN_LDS_DMA16(xbuf, dgoff[j], (unsigned)k0 * OE, in_s + (j * LT + lwave * 64) * 4);
+  };
+  auto dma_b = [&](int k0, int buf) {                // fp16 planes of the 1x1 weights of one chunk -> b_s[buf]
+    float* bb = smem + OFF_B + buf * B_SZ;
+    if (!loader) return;
+#pragma unroll
+    for (int j = 0; j < DNB; ++j) MIGAN_LDS_DMA16(wbuf, dboff[j], (unsigned)k0 * (unsigned)p.CO * 2u, bb + (j * LT + lwave * 64) * 4);
+  };
+  auto load_in = [&](int k0) {                     // input tile + depthwise taps of one chunk
+    if (MIGAN_ABL(16)) {
+#pragma unroll
+      for (int j = 0; j < NI; ++j) rin[j] = IoT::zero();
+    } else {
+#pragma unroll
+      for (int j = 0; j < NI; ++j) rin[j] = IoT::ld(xb + (size_t)k0 * OE, goff[j]);
+    }
     if (tid < KC * 9 / 4) rw = ld4(p.wdw + (size_t)k0 * 9 + (unsigned)(tid * 4));
     else if (tid < NW4) rw = ld4(p.bdw + k0 + (unsigned)((tid - KC * 9 / 4) * 4));
   };
   auto load_b = [&](int k0) {                      // fp16 planes of the 1x1 weights of one chunk
     const unsigned short* __restrict__ wk = p.wsplit + (size_t)k0 * p.CO;
+    if (MIGAN_ABL(32)) {
 #pragma unroll
-    for (int j = 0; j < NB; ++j) rb[j] = ld4(at_bytes(reinterpret_cast<const float*>(wk), boff[j]));
+      for (int j = 0; j < NB; ++j) rb[j] = f4{1.f, 2.f, 3.f, (float)k0};
+    } else {
+#pragma unroll
+      for (int j = 0; j < NB; ++j) rb[j] = ld4(at_bytes(reinterpret_cast<const float*>(wk), boff[j]));
+    }
   };
   auto store_in = [&](int buf) {
     float* in_s = smem + OFF_IN + buf * IN_SZ;
@@ -1308,12 +1393,14 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(kWideThreads, 2) sepconv_wide_kernel(const
     }
   };
   f16v acc[MTI][NTI];
+  auto zero_acc = [&]() {
 #pragma unroll
-  for (int i = 0; i < MTI; ++i)
+    for (int i = 0; i < MTI; ++i)
 #pragma unroll
-    for (int j = 0; j < NTI; ++j)
+      for (int j = 0; j < NTI; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+  };
   auto mfma_chunk = [&](int buf) {
     const char* ab = reinterpret_cast<const char*>(smem + OFF_A + buf * A_SZ);
     const char* bb = reinterpret_cast<const char*>(smem + OFF_B + buf * B_SZ);
@@ -1346,56 +1433,118 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(kWideThreads, 2) sepconv_wide_kernel(const
         }
     }
   };
+  // accumulator fragment -> LDS result tile (C/D layout of the 32x32 MFMA: lane holds column l&31, rows (r&3) + 8*(r>>2) + 4*(l>>5))
+  auto acc_to_lds = [&]() {
+    int tw_ = tid;
+    MIGAN_OPAQUE(tw_);
+    const int lanee = tw_ & 63, wavee = tw_ >> 6;
+    const int wme = BALL ? ((wavee & 3) >> 1) : wavee / WN, wne = BALL ? (wavee & 1) : wavee % WN, l31e = lanee & 31, halfe = lanee >> 5;
+#pragma unroll
+    for (int i = 0; i < MTI; ++i)
+#pragma unroll
+      for (int j = 0; j < NTI; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = wme * WROWS + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * halfe;
+          const int col = wne * WCOLS + j * 32 + l31e;
+          g_s[row * GS + col] = acc[i][j][r];
+        }
+  };
 
   // ---- prologue: chunk 0 complete in LDS (input, taps, A planes, B planes), chunk 1 input in LDS ----------
   const int nkc = p.CI / KC;
-  load_in(0);
-  load_b(0);
-  store_in(0);
-  store_b(0);
-  if (1 < nkc) { load_in(KC); load_b(KC); }
-  __syncthreads();
-  if (groupA) depthwise(0, 0);
-  if (1 < nkc) store_in(1);
-  if (2 < nkc) load_in(2 * KC);
-  __syncthreads();
+  if constexpr (DMA) {
+    dma_in(0, 0);
+    dma_b(0, 0);
+    load_taps(0);
+    store_taps(0);
+    if (1 < nkc) {
+      dma_in(KC, 1);
+      load_taps(KC);
+      store_taps(1);
+    }
+    __syncthreads();
+    if (groupA) depthwise(0, 0);
+    __syncthreads();
+  } else {
+    load_in(0);
+    load_b(0);
+    store_in(0);
+    store_b(0);
+    if (1 < nkc) { load_in(KC); load_b(KC); }
+    __syncthreads();
+    if (groupA) depthwise(0, 0);
+    if (1 < nkc) store_in(1);
+    if (2 < nkc) load_in(2 * KC);
+    __syncthreads();
+  }
   // ---- K loop: one barrier per chunk ------------------------------------------------------------------------
   // at the top of iteration c: a_s[c&1], b_s[c&1] = chunk c; in_s/w_s[(c+1)&1] = chunk c+1;
   // registers: weight planes of chunk c+1, input tile of chunk c+2
-  for (int c = 0; c < nkc; ++c) {
-    if (c + 1 < nkc) store_b((c + 1) & 1);        // last read by the MFMAs of chunk c-1
+  auto stage = [&](int c) {                          // all 512 threads: registers -> LDS, next global loads
+    if constexpr (DMA) {
+      // in_s / w_s[c&1] were last read by the depthwise stage of chunk c (previous iteration), b_s[(c+1)&1] by the MFMAs of chunk c-1
+      if (c + 2 < nkc) {
+        dma_in((c + 2) * KC, c & 1);
+        load_taps((c + 2) * KC);
+      }
+      if (c + 1 < nkc) dma_b((c + 1) * KC, (c + 1) & 1);
+      PROF_MARK(pslot + 0);
+      return;
+    }
+    if (c + 1 < nkc && !MIGAN_ABL(64)) store_b((c + 1) & 1);        // last read by the MFMAs of chunk c-1
+    if constexpr (BALL) PROF_MARK(pslot + 0);        // (phase profile of the BALL form: [weight tile -> LDS, input tile -> LDS + loads, depthwise | MFMA, barrier])
     if (c + 2 < nkc) {
-      store_in(c & 1);                            // last read by the depthwise stage of chunk c
+      if (!MIGAN_ABL(128)) store_in(c & 1);       // last read by the depthwise stage of chunk c
       load_b((c + 2) * KC);
     }
     if (c + 3 < nkc) load_in((c + 3) * KC);
-    PROF_MARK(pslot + 0);
-    if (groupA && c + 1 < nkc) depthwise((c + 1) & 1, (c + 1) & 1);   // a_s[(c+1)&1] last read by the MFMAs of chunk c-1
-    PROF_MARK(pslot + 1);
-    mfma_chunk(c & 1);
-    PROF_MARK(pslot + 2);
-    __syncthreads();
-    PROF_MARK(pslot + 3);
+  };
+  if constexpr (BALL) {
+    if (groupA) {
+      for (int c = 0; c < nkc; ++c) {
+        stage(c);
+        PROF_MARK(pslot + 1);
+        if (c + 1 < nkc && !MIGAN_ABL(4)) depthwise((c + 1) & 1, (c + 1) & 1);
+        PROF_MARK(pslot + 2);
+        if constexpr (DMA) { if (c + 2 < nkc) store_taps(c & 1); }
+        __syncthreads();
+        PROF_MARK(pslot + 3);
+      }
+    } else {
+      zero_acc();
+      for (int c = 0; c < nkc; ++c) {
+        stage(c);
+        PROF_MARK(pslot + 1);
+        if (!MIGAN_ABL(8)) mfma_chunk(c & 1);
+        PROF_MARK(pslot + 2);
+        if constexpr (DMA) { if (c + 2 < nkc) store_taps(c & 1); }
+        __syncthreads();
+        PROF_MARK(pslot + 3);
+      }
+      acc_to_lds();                               // (every wave is past the last chunk's barrier: a_s / b_s are dead)
+    }
+  } else {
+    zero_acc();
+    for (int c = 0; c < nkc; ++c) {
+      stage(c);
+      PROF_MARK(pslot + 0);
+      if (groupA && c + 1 < nkc && !MIGAN_ABL(4)) depthwise((c + 1) & 1, (c + 1) & 1);   // a_s[(c+1)&1] last read by the MFMAs of chunk c-1
+      PROF_MARK(pslot + 1);
+      if (!MIGAN_ABL(8)) mfma_chunk(c & 1);
+      PROF_MARK(pslot + 2);
+      __syncthreads();
+      PROF_MARK(pslot + 3);
+    }
+    acc_to_lds();
   }
   PROF_END_WIDE();
 
   // ======================================= epilogue ========================================
   int tide = tid;
   MIGAN_OPAQUE(tide);
-  const int lanee = tide & 63, wavee = tide >> 6;
-  const int wme = wavee / WN, wne = wavee % WN, l31e = lanee & 31, halfe = lanee >> 5;
   const float acc_scale = reinterpret_cast<const float*>(p.wsplit)[-4];
   const float gain_s = 1.41421356237309515f * acc_scale;
-#pragma unroll
-  for (int i = 0; i < MTI; ++i)
-#pragma unroll
-    for (int j = 0; j < NTI; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = wme * WROWS + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * halfe;
-        const int col = wne * WCOLS + j * 32 + l31e;
-        g_s[row * GS + col] = acc[i][j][r];
-      }
   __syncthreads();
 
   const bool has_noise = gnoise != nullptr;
@@ -1456,7 +1605,7 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(kWideThreads, 2) sepconv_wide_kernel(const
         }
         f4 outv = v;
         if constexpr (HS) outv = v + IoT::cvt(sk[u]);
-        IoT::st(yb + (size_t)upix[u] * p.CO * OE, off_t, outv);
+        if (!MIGAN_ABL(1)) IoT::st(yb + (size_t)upix[u] * p.CO * OE, off_t, outv);
         if constexpr (TORGB) {
           v = IoT::rounded(outv);
           float r0, r1, r2;

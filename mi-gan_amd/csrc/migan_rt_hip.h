@@ -55,6 +55,21 @@ __device__ __forceinline__ float migan_swizzle_xor(float v) {
 #define MIGAN_CLOCK() __builtin_readcyclecounter()
 #define MIGAN_ATOMIC_ADD_U64(p, v) atomicAdd((p), (v))
 
+// ---- LDS-DMA staging (sepconv_wide_kernel<..., DMA>) ---------------------------------------------------------------------------
+// wave-uniform value the compiler can keep in an SGPR (threadIdx-derived values are divergent to it even when they are not)
+#define MIGAN_UNIFORM(x) __builtin_amdgcn_readfirstlane(x)
+// raw buffer descriptor over [ptr, ptr + bytes): an access whose lane byte offset is >= bytes returns 0 (the hardware range check
+// is the zero padding of the convolution)
+typedef __amdgpu_buffer_rsrc_t MIGAN_BUF;
+__device__ __forceinline__ MIGAN_BUF migan_make_buf(const void* p, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
+}
+#define MIGAN_MAKE_BUF(ptr, bytes) migan_make_buf((ptr), (bytes))
+// buffer_load_dwordx4 ... lds: 16 bytes per active lane from buf[voff + soff] straight into LDS at (wave-uniform) ldsp + 16 * lane,
+// no VGPR and no ds_write in between.  Completion is tracked by vmcnt; hipcc waits for it (vmcnt(0)) at the next __syncthreads().
+#define MIGAN_LDS_DMA16(buf, voff, soff, ldsp) \
+  __builtin_amdgcn_raw_ptr_buffer_load_lds((buf), (__attribute__((address_space(3))) void*)(ldsp), 16, (int)(voff), (int)(soff), 0, 0)
+
 namespace rt {
 typedef hipStream_t stream_t;
 typedef hipEvent_t event_t;

@@ -17,6 +17,9 @@ import torch
 pkg = importlib.import_module("mi-gan_amd")
 R = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 32
+for kv in sys.argv[3:]:
+    k, _, v = kv.partition("=")
+    pkg.load_library().set_tuning(k, int(v))
 model = pkg.Generator(R); model.set_streams(1)
 model.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in pkg.synth.make_state_dict(R, seed=0).items()})
 model = model.to("cuda").eval()
@@ -38,7 +41,7 @@ for i, (L, t) in enumerate(zip(launches, ms)):
     n = max(1, out[8])
     if "wide" in L["kernel"]:
         cyc = [out[k] / n for k in range(8)]
-        print(f"{L['layer']:26s} {t:8.3f} {out[8]:7d}  wide A[store/wait, depthwise, mfma, barrier] " + " ".join(f"{c:8.0f}" for c in cyc[:4])
+        print(f"{L['layer']:26s} {t:8.3f} {out[8]:7d}  wide A[w->lds, in->lds+loads, dw (wide=2; else store/wait, dw, mfma), barrier] " + " ".join(f"{c:8.0f}" for c in cyc[:4])
               + "   B: " + " ".join(f"{c:8.0f}" for c in cyc[4:]))
         continue
     cyc = [out[k] / n for k in range(6)]

@@ -17,7 +17,7 @@ sys.path.insert(0, ROOT)
 import numpy as np
 import torch
 
-DEFAULTS = dict(kc16=0, kc16_minw=3, w3=3, wide=1, nt256=1, persist_min=8192, persist_grid=512, single_b=0, stagger=-1, stagger_pct=22)
+DEFAULTS = dict(kc16=0, kc16_minw=3, w3=3, wide=3, nt256=1, persist_min=8192, persist_grid=512, single_b=0, stagger=-1, stagger_pct=22)
 
 VARIANTS = [
     # label, tuning overrides, streams, dtype

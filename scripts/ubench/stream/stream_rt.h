@@ -2,19 +2,25 @@
 // hardware range checks, wave-level LDS ordering, and the DPP depthwise taps.  Experiment only -- not part of libmigan_hip.so.
 #pragma once
 // wave-uniform value the compiler can keep in an SGPR (threadIdx-derived values are divergent to it even when they are not)
+#ifndef MIGAN_UNIFORM
 #define MIGAN_UNIFORM(x) __builtin_amdgcn_readfirstlane(x)
+#endif
 // lanes of ONE wave exchanging data through LDS: a wave's LDS instructions execute in order, so no barrier instruction is needed,
 // only the compiler must not move the accesses across this point
 #define MIGAN_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
 // raw buffer descriptor over [ptr, ptr + bytes): accesses at byte offset voffset + soffset >= bytes return 0 / are dropped
 // (the hardware range check is the zero padding of the convolution and the mask of partial strips)
+#ifndef MIGAN_MAKE_BUF
 typedef __amdgpu_buffer_rsrc_t MIGAN_BUF;
+#endif
 typedef unsigned migan_u4 __attribute__((ext_vector_type(4)));
 typedef float migan_f4 __attribute__((ext_vector_type(4)));
+#ifndef MIGAN_MAKE_BUF
 __device__ __forceinline__ MIGAN_BUF migan_make_buf(const void* p, unsigned bytes) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
 }
 #define MIGAN_MAKE_BUF(ptr, bytes) migan_make_buf((ptr), (bytes))
+#endif
 #define MIGAN_BUF_LOAD4(buf, voff, soff) __builtin_bit_cast(migan_f4, __builtin_amdgcn_raw_buffer_load_b128((buf), (int)(voff), (int)(soff), 0))
 #define MIGAN_BUF_STORE4(buf, voff, soff, v) \
   __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(migan_u4, (v)), (buf), (int)(voff), (int)(soff), 2 /* nt */)

@@ -264,6 +264,23 @@ inline emu_f16v hipemu_mfma_16b_32x32x16(emu_f4 a, emu_f4 bv, emu_f16v c, bool f
 #define MIGAN_MFMA_BF16_32X32X16(a, b, c) hipemu_mfma_16b_32x32x16((a), (b), (c), false)
 #define MIGAN_MFMA_F16_32X32X16(a, b, c) hipemu_mfma_16b_32x32x16((a), (b), (c), true)
 
+
+// ---- LDS-DMA staging: buffer descriptor with the hardware's range check, and the direct global -> LDS copy (executed at once:
+// the emulator has no asynchronous memory; the product relies on the vmcnt(0) hipcc places before every barrier)
+#define MIGAN_UNIFORM(x) (x)
+struct MIGAN_BUF {
+  const char* p;
+  unsigned n;
+};
+#define MIGAN_MAKE_BUF(ptr, bytes) (MIGAN_BUF{reinterpret_cast<const char*>(ptr), (unsigned)(bytes)})
+inline void hipemu_lds_dma16(MIGAN_BUF b, unsigned voff, unsigned soff, float* wave_base) {
+  const int lane = hipemu::tl_blk->cur & 63;
+  char* dst = reinterpret_cast<char*>(wave_base) + 16 * lane;
+  if ((unsigned long long)voff + 16ull > (unsigned long long)b.n) std::memset(dst, 0, 16);      // range check on the lane offset
+  else std::memcpy(dst, b.p + voff + soff, 16);
+}
+#define MIGAN_LDS_DMA16(buf, voff, soff, ldsp) hipemu_lds_dma16((buf), (voff), (soff), (ldsp))
+
 // ---- the runtime surface the host code uses ----------------------------------------------------------
 namespace rt {
 typedef void* stream_t;

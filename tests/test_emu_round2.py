@@ -20,7 +20,7 @@ def lib():
 def tuned(lib):
     """set process-wide tuning knobs for one test, restore the defaults afterwards"""
     changed = {}
-    defaults = dict(kc16=0, kc16_minw=3, w3=3, wide=1, nt256=1, persist_min=8192, persist_grid=512, streams=2, stagger=-1)
+    defaults = dict(kc16=0, kc16_minw=3, w3=3, wide=3, nt256=1, persist_min=8192, persist_grid=512, streams=2, stagger=-1)
 
     def set_(key, value):
         changed[key] = True
@@ -343,3 +343,35 @@ def test_forward_hw_vs_reference_goldens(pkg, lib, golden_dir):
         ws = np.zeros(need // 4 + 64, np.float32)
         h.forward_hw(x.ctypes.data, y.ctypes.data, n, hh, ww, ws.ctypes.data, need)
         np.testing.assert_allclose(y, g["y"], rtol=0, atol=3e-5 * max(1.0, float(g["y_absmax"])), err_msg=os.path.basename(f))
+
+
+# ------------------------------------------------------------------------------------------------ 64-pixel tiles (round-3 experiment knob)
+@pytest.mark.parametrize("mt64,case", [
+    (1, dict(cin=128, cout=128, h=16, batch=2, noise=True, skip=True)),
+    (1, dict(cin=128, cout=128, h=16, batch=1, noise=True, torgb=True, with_prev=True)),
+    (1, dict(cin=128, cout=256, h=16, w=32, batch=1, noise=True)),
+    (2, dict(cin=128, cout=256, h=16, batch=2, noise=True, skip=True)),
+    (2, dict(cin=256, cout=512, h=16, batch=1)),
+])
+def test_sepconv_64_pixel_tiles(lib, pkg, mt64, case):
+    lib.set_tuning("mt64", mt64)
+    try:
+        _sepconv(lib, pkg, gemm=2, **case)
+    finally:
+        lib.set_tuning("mt64", 0)
+
+
+# ------------------------------------------------------------------------------------------------ wide tile, all MFMAs on waves 4-7 (round 3)
+@pytest.mark.parametrize("storage,gemm", [("f32", 2), ("bf16", -1), ("f16", 2)])
+@pytest.mark.parametrize("case", [
+    dict(cin=64, cout=256, h=16, batch=2, noise=True, skip=True),
+    dict(cin=96, cout=512, h=16, w=32, batch=1, noise=True),
+    dict(cin=64, cout=256, h=16, batch=1, noise=True, torgb=True, with_prev=True),
+])
+@pytest.mark.parametrize("wide", [2, 3])
+def test_sepconv_wide_tile_with_dedicated_mfma_waves(lib, pkg, storage, gemm, case, wide):
+    lib.set_tuning("wide", wide)          # 3: + LDS-DMA staging (fp32 storage; other storage formats keep the register path)
+    try:
+        _sepconv(lib, pkg, storage=storage, gemm=gemm, **case)
+    finally:
+        lib.set_tuning("wide", 3)

@@ -25,7 +25,7 @@ def dev():
 def tuned(pkg):
     lib = pkg.load_library()
     changed = {}
-    defaults = dict(kc16=0, kc16_minw=3, w3=3, wide=1, nt256=1, persist_min=8192, persist_grid=512, streams=2, stagger=-1)
+    defaults = dict(kc16=0, kc16_minw=3, w3=3, wide=3, nt256=1, persist_min=8192, persist_grid=512, streams=2, stagger=-1)
 
     def set_(key, value):
         changed[key] = True
