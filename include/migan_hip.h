@@ -128,6 +128,30 @@ typedef struct migan_io_u8 {
 int migan_forward_u8(migan_handle* h, const void* img_hwc_u8, const void* mask_u8, void* out_hwc_u8, int batch,
                      void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- the deployed pipeline around the generator (second half) ----
+ * reference scripts/create_onnx_pipeline.py::MIGAN_Pipeline (:118-264), the module the reference exports as
+ * migan_pipeline_v2.onnx: any-size uint8 image [3][H][W] (CHW) + mask [H][W] (255 = known pixel), batch 1.
+ *   migan_pipeline_bbox   get_masked_bbox (:132-231): bbox = {x_min, x_max, y_min, y_max} of the masked region, padded
+ *                         and grown to at least resolution x resolution, clipped to the image.  Row / column flags are
+ *                         reduced on the device; the call synchronises `stream` to read them (the crop size decides the
+ *                         launch sizes of everything after it -- the reference has the same dependency).
+ *   migan_pipeline_pre    preprocess (:233-239) of the crop: bilinear resize (torchvision tensor resize: no antialias,
+ *                         rounded back to uint8) of the image, nearest resize of the mask, x = cat([mask/255 - 0.5,
+ *                         (image*2/255 - 1) * mask/255]) -> x [1][4][R][R] fp32, the generator's input
+ *   migan_pipeline_post   postprocess (:241-250) + paste (:263), in place on the image: y -> ((y*0.5+0.5)*255).clamp,
+ *                         bilinear resize to the crop, mask feathering (3x3 max-pool, 5x5 gaussian with reflect padding,
+ *                         GaussianSmoothing :51-115), composed = image*mask + output*(1-mask), clamp, truncate to uint8.
+ *                         gauss25: the module's 5x5 weight buffer (host pointer), or NULL for kernel_size=5, sigma=1.
+ * `scratch` is migan_pipeline_scratch_bytes(H, W) bytes of device memory, shared by the three calls.  Results: bbox and
+ * the uint8 resize are exact; fp32 sums may associate differently from ATen's (<= 1 uint8 step in the result). */
+int migan_pipeline_scratch_bytes(int height, int width, size_t* bytes);
+int migan_pipeline_bbox(const void* mask_u8, int height, int width, int resolution, int padding, void* scratch,
+                        int bbox[4], void* stream);
+int migan_pipeline_pre(const void* image_chw_u8, const void* mask_u8, int height, int width, const int bbox[4],
+                       int resolution, void* x_nchw, void* stream);
+int migan_pipeline_post(void* image_chw_u8, const void* mask_u8, int height, int width, const int bbox[4], int resolution,
+                        const void* y_nchw, const float* gauss25, void* scratch, void* stream);
+
 /* ---- measurement and debugging ---------------------------------------------------------- */
 
 /* The forward is a fixed sequence of kernel launches (one per SeparableConv2d, plus un-fused

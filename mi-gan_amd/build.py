@@ -23,7 +23,7 @@ OUT = os.path.join(CSRC, "libmigan_hip.so")
 OBJ = os.path.join(CSRC, "_obj")
 SOURCES = [os.path.join(CSRC, f) for f in ("migan_hip.hip", "migan_k_slice.hip", "migan_k_slice.inc", "migan_table.hpp",
                                             "migan_kernels.hpp", "migan_host.hpp", "migan_rt_hip.h",
-                                            "comodgan_kernels.hpp", "comodgan_host.hpp")] + [
+                                            "comodgan_kernels.hpp", "comodgan_host.hpp", "migan_pipeline.hpp")] + [
     os.path.join(ROOT, "include", "migan_hip.h"), os.path.join(ROOT, "include", "comodgan_hip.h")]
 ARCH = "gfx950"
 # (GEMM variant, activation storage format) slices of the sepconv_kernel table; 16-bit storage is built for the fp16 GEMM variants (f16x2 = 2, f16 = 3)

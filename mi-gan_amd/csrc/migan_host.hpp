@@ -93,8 +93,6 @@ struct Tuning {
                                // per CU, 164 VGPRs) and the plain / ToRGB layers with Cin = 64, whose two K chunks unroll at compile time
                                // (135 VGPRs instead of 184; synthesis.b512.conv2 1.34 -> 1.07 ms).  The FIR-up tile (4 chunks) needs 60 bytes
                                // of scratch at that budget and loses 10 %: profiles/r02_w3_and_persistence_sweep.txt
-  int mt64 = 0;                // experiment (round 3): plain full-tile layers with Cin >= 128 on 64-pixel tiles: 1 = 64 x 128 at 3 workgroups per CU,
-                               // 2 = 64 x 256 at 2 per CU (instead of the 8-wave 128 x 256 tile / the 128 x 128 tile)
   int streams = 2;             // MIGAN_STREAMS=1|2: default of migan_set_streams
   int stagger = -1;            // MIGAN_STAGGER: launch index of the first half after which the second half starts (-1: plan default)
   int debug_split = 0;         // diagnostics: keep the two-sub-batch execution in keep-intermediates mode
@@ -140,12 +138,7 @@ inline Geo choose_geo(int mode, int cin, int cout, int h_in, int w_in, bool from
   int GH, GW, IMGS;
   if (mode == MODE_NORMAL) {
     g.MT = 128; g.KC = 32;
-    const int mt64 = (full && !fromrgb && g.gemmv >= 2 && cin >= 128 && h_in % 4 == 0) ? tuning().mt64 : 0;
-    if (mt64 == 2 && cout % 256 == 0) {
-      g.MT = 64; g.NT = 256; GH = 4; GW = 16; IMGS = 1;
-    } else if (mt64 == 1 && cout % 128 == 0) {
-      g.MT = 64; g.NT = 128; GH = 4; GW = 16; IMGS = 1;
-    } else if (full && cout % 256 == 0 && !fromrgb && g.gemmv >= 2 && tuning().wide) {
+    if (full && cout % 256 == 0 && !fromrgb && g.gemmv >= 2 && tuning().wide) {
       // wide layers: one 8-wave workgroup owns 256 output channels of 8x16 pixels; half of its waves run the
       // depthwise stage of the next K chunk while the other half keeps the matrix cores busy (sepconv_wide_kernel)
       g.wide = true; g.NT = 256; GH = 8; GW = 16; IMGS = 1;
@@ -1405,6 +1398,95 @@ int migan_compose_output(const void* y_nchw, const void* img_hwc_u8, const void*
   return migan_prepost_launch(false, y_nchw, img_hwc_u8, mask_u8, nullptr, out_hwc_u8, batch, resolution, stream);
 }
 
+// ---- the deployed pipeline around the generator (reference scripts/create_onnx_pipeline.py::MIGAN_Pipeline :118-264) ----
+static void migan_pipeline_check(const void* mask, int height, int width, int resolution) {
+  MIGAN_CHECK(mask, MIGAN_EINVAL, "null mask");
+  MIGAN_CHECK(height >= 3 && width >= 3 && (unsigned long long)height * width < (1ull << 30), MIGAN_EINVAL,
+              "image must be at least 3x3 (reflect padding of the 5x5 blur) and below 2^30 pixels");
+  MIGAN_CHECK(resolution >= 8 && (resolution & (resolution - 1)) == 0, MIGAN_EINVAL, "resolution must be a power of two >= 8");
+}
+static void migan_pipeline_check_bbox(const int bbox[4], int height, int width) {
+  MIGAN_CHECK(bbox, MIGAN_EINVAL, "null bbox");
+  MIGAN_CHECK(bbox[0] >= 0 && bbox[1] <= width && bbox[2] >= 0 && bbox[3] <= height && bbox[1] - bbox[0] >= 3 && bbox[3] - bbox[2] >= 3,
+              MIGAN_EINVAL, "bbox = {x_min, x_max, y_min, y_max} must lie inside the image and be at least 3x3");
+}
+int migan_pipeline_scratch_bytes(int height, int width, size_t* bytes) {
+  MIGAN_API_BEGIN
+  MIGAN_CHECK(bytes && height > 0 && width > 0, MIGAN_EINVAL, "bad argument");
+  *bytes = migan::align256((size_t)(height + width) * sizeof(int)) + migan::align256((size_t)height * width);
+  MIGAN_API_END
+}
+// get_masked_bbox (:132-231).  The per-row / per-column "contains a pixel below 255" flags are computed on the device, copied to
+// the host (this call synchronises `stream`), and the box arithmetic -- a dozen integer min/max, the reference's own order -- runs here.
+int migan_pipeline_bbox(const void* mask_u8, int height, int width, int resolution, int padding, void* scratch, int bbox[4], void* stream) {
+  MIGAN_API_BEGIN
+  using namespace migan;
+  migan_pipeline_check(mask_u8, height, width, resolution);
+  MIGAN_CHECK(scratch && bbox && padding >= 0, MIGAN_EINVAL, "bad argument");
+  PipeArgs a{};
+  a.mask = (const unsigned char*)mask_u8; a.flags = (int*)scratch; a.H = height; a.W = width; a.R = resolution;
+  rt_check(rt::launch(pipe_flags_clear_kernel, a, (unsigned)cdiv(height + width, kThreads), kThreads, 0, (rt::stream_t)stream), "migan::pipe_flags_clear_kernel");
+  rt_check(rt::launch(pipe_flags_kernel, a, (unsigned)cdiv(height * width, kThreads), kThreads, 0, (rt::stream_t)stream), "migan::pipe_flags_kernel");
+  std::vector<int> f((size_t)height + width);
+  rt_check(rt::memcpy_d2h(f.data(), scratch, f.size() * sizeof(int), (rt::stream_t)stream), "hipMemcpy (bbox flags)");
+  int x_min = width, x_max = 0, y_min = height, y_max = 0;                         // :149-152 (min over [..., w], max over [..., 0])
+  for (int x = 0; x < width; ++x) if (f[x]) { x_min = std::min(x_min, x); x_max = std::max(x_max, x); }
+  for (int y = 0; y < height; ++y) if (f[width + y]) { y_min = std::min(y_min, y); y_max = std::max(y_max, y); }
+  x_min = std::min(x_min, x_max); x_max = std::max(x_min, x_max);                  // :154-172
+  y_min = std::min(y_min, y_max); y_max = std::max(y_min, y_max);
+  const int cnt_x = (x_min + x_max) / 2, cnt_y = (y_min + y_max) / 2;              // :174-175
+  int crop = std::max(x_max - x_min, y_max - y_min) + 2 * padding;                 // :177-180
+  crop = std::max(crop, resolution);                                               // :181-184
+  const int off = crop / 2;                                                        // :186
+  x_min = std::max(cnt_x - off, 0); x_max = std::min(cnt_x + off, width);          // :187-202
+  y_min = std::max(cnt_y - off, 0); y_max = std::min(cnt_y + off, height);
+  const int xe = std::max(crop - (x_max - x_min), 0), ye = std::max(crop - (y_max - y_min), 0);   // :204-211
+  x_min = std::max(x_min - xe, 0); x_max = std::min(x_max + xe, width);            // :213-229
+  y_min = std::max(y_min - ye, 0); y_max = std::min(y_max + ye, height);
+  bbox[0] = x_min; bbox[1] = x_max; bbox[2] = y_min; bbox[3] = y_max;
+  MIGAN_API_END
+}
+// preprocess (:233-239) of image[:, y_min:y_max, x_min:x_max] -> the network input x [1][4][R][R]
+int migan_pipeline_pre(const void* image_chw_u8, const void* mask_u8, int height, int width, const int bbox[4], int resolution, void* x_nchw,
+                       void* stream) {
+  MIGAN_API_BEGIN
+  using namespace migan;
+  migan_pipeline_check(mask_u8, height, width, resolution);
+  migan_pipeline_check_bbox(bbox, height, width);
+  MIGAN_CHECK(image_chw_u8 && x_nchw, MIGAN_EINVAL, "null tensor");
+  PipeArgs a{};
+  a.image = (unsigned char*)image_chw_u8; a.mask = (const unsigned char*)mask_u8; a.x = (float*)x_nchw;
+  a.H = height; a.W = width; a.R = resolution; a.x_min = bbox[0]; a.x_max = bbox[1]; a.y_min = bbox[2]; a.y_max = bbox[3];
+  rt_check(rt::launch(pipe_pre_kernel, a, (unsigned)cdiv(resolution * resolution, kThreads), kThreads, 0, (rt::stream_t)stream), "migan::pipe_pre_kernel");
+  MIGAN_API_END
+}
+// postprocess (:241-250) and the paste back into the image (:263), in place
+int migan_pipeline_post(void* image_chw_u8, const void* mask_u8, int height, int width, const int bbox[4], int resolution, const void* y_nchw,
+                        const float* gauss25, void* scratch, void* stream) {
+  MIGAN_API_BEGIN
+  using namespace migan;
+  migan_pipeline_check(mask_u8, height, width, resolution);
+  migan_pipeline_check_bbox(bbox, height, width);
+  MIGAN_CHECK(image_chw_u8 && y_nchw && scratch, MIGAN_EINVAL, "null tensor");
+  PipeArgs a{};
+  a.image = (unsigned char*)image_chw_u8; a.mask = (const unsigned char*)mask_u8; a.y = (const float*)y_nchw;
+  a.pooled = (unsigned char*)scratch + align256((size_t)(height + width) * sizeof(int));
+  a.H = height; a.W = width; a.R = resolution; a.x_min = bbox[0]; a.x_max = bbox[1]; a.y_min = bbox[2]; a.y_max = bbox[3];
+  if (gauss25) {
+    for (int i = 0; i < 25; ++i) a.gauss[i] = gauss25[i];
+  } else {                                                                         // GaussianSmoothing(3, 5, 1) (:63-85)
+    float g[5], sum = 0.0f;
+    for (int i = 0; i < 5; ++i) { const float t = ((float)i - 2.0f) / 2.0f; g[i] = (float)(1.0 / std::sqrt(2.0 * M_PI)) * std::exp(-(t * t)); }
+    for (int i = 0; i < 25; ++i) { a.gauss[i] = g[i / 5] * g[i % 5]; sum += a.gauss[i]; }
+    for (int i = 0; i < 25; ++i) a.gauss[i] /= sum;
+  }
+  const unsigned grid = (unsigned)cdiv((bbox[1] - bbox[0]) * (bbox[3] - bbox[2]), kThreads);
+  rt_check(rt::launch(pipe_maxpool_kernel, a, grid, kThreads, 0, (rt::stream_t)stream), "migan::pipe_maxpool_kernel");
+  rt_check(rt::launch(pipe_post_kernel, a, grid, kThreads, 0, (rt::stream_t)stream), "migan::pipe_post_kernel");
+  MIGAN_API_END
+}
+
+
 #ifdef MIGAN_PHASE_PROF
 // debug builds only: cumulative cycles of thread 0 per phase [prologue, S1, S2, MFMA, acc->LDS, epilogue, -, -, #workgroups]
 int migan_prof_read(unsigned long long out[16], int reset) {
@@ -1434,7 +1516,6 @@ int migan_set_tuning(const char* key, int value) {
   else if (k == "w3") t.w3 = value;
   else if (k == "wide") t.wide = value;
   else if (k == "nt256") t.nt256 = value != 0;
-  else if (k == "mt64") t.mt64 = value;
   else if (k == "persist_min") t.persist_min = std::max(1, value);
   else if (k == "persist_grid") t.persist_grid = std::max(8, value / 8 * 8);
   else if (k == "streams") t.streams = std::min(4, std::max(1, value));

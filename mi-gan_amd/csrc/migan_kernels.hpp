@@ -2018,3 +2018,5 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, 2) compose_output_kernel(const PrePos
 
 
 }  // namespace migan
+
+#include "migan_pipeline.hpp"

@@ -13,6 +13,8 @@
 // v_mfma_f32_32x32x2_f32: exact-f32 matrix FMA (D = A[32x2] * B[2x32] + C), 64 cycles per SIMD
 #define MIGAN_MFMA_F32_32X32X2(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 #define MIGAN_FMUL_RN(a, b) __fmul_rn((a), (b))
+#define MIGAN_FADD_RN(a, b) __fadd_rn((a), (b))
+#define MIGAN_FSUB_RN(a, b) __fsub_rn((a), (b))
 // v_mfma_f32_32x32x16_bf16: D = A[32x16] * B[16x32] + C, operands as 8 bf16 (16 bytes) per lane
 typedef __bf16 migan_bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 migan_bf16x2 __attribute__((ext_vector_type(2)));

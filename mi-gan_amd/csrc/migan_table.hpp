@@ -40,8 +40,7 @@ struct KernelEntry {
   /* plain layers whose epilogue also produces the running RGB image (CO == NT) */                                              \
   MIGAN_K(0, 128, 128, 32, false, 6, 2, true, false, G, true, S), MIGAN_K(0, 128, 128, 32, false, 9, 2, false, false, G, true, S),   \
   MIGAN_K(0, 128, 64, 32, false, 6, 2, true, false, G, true, S), MIGAN_K(0, 128, 64, 32, false, 9, 2, false, false, G, true, S),     \
-  MIGAN_K(0, 64, 256, 32, false, 4, 2, true, false, G, true, S), MIGAN_K(0, 64, 256, 32, false, 4, 2, true, false, G, false, S),  \
-  MIGAN_K(0, 64, 128, 32, false, 4, 3, true, false, G, false, S), MIGAN_K(0, 64, 128, 32, false, 4, 3, true, false, G, true, S),  \
+  MIGAN_K(0, 64, 256, 32, false, 4, 2, true, false, G, true, S),                                                                 \
   /* FIR-up layers */                                                                                                            \
   MIGAN_K(2, 128, 128, 32, false, 6, 2, true, false, G, false, S), MIGAN_K(2, 128, 128, 32, false, 9, 2, false, false, G, false, S), \
   MIGAN_K(2, 128, 64, 32, false, 6, 2, true, false, G, false, S), MIGAN_K(2, 128, 64, 32, false, 9, 2, false, false, G, false, S),   \

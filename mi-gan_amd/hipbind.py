@@ -67,6 +67,7 @@ EXPORTS = (
     "migan_num_launches", "migan_launch_info",
     "migan_forward_timed", "migan_set_debug", "migan_debug_tensor", "migan_sepconv_forward",
     "migan_pack_input", "migan_compose_output",
+    "migan_pipeline_scratch_bytes", "migan_pipeline_bbox", "migan_pipeline_pre", "migan_pipeline_post",
     "migan_set_tuning", "migan_last_error", "migan_backend", "migan_gemm_variant", "migan_version",
     # include/comodgan_hip.h
     "comodgan_create", "comodgan_destroy", "comodgan_num_weights", "comodgan_weight_info", "comodgan_set_weight",
@@ -115,6 +116,10 @@ class MiganLib:
         L.migan_workspace_bytes_hw.argtypes = [vp, ci, ci, ci, C.POINTER(C.c_size_t)]
         L.migan_forward_hw.argtypes = [vp, vp, vp, ci, ci, ci, vp, C.c_size_t, vp]
         L.migan_forward_u8.argtypes = [vp, vp, vp, vp, ci, vp, C.c_size_t, vp]
+        L.migan_pipeline_scratch_bytes.argtypes = [ci, ci, C.POINTER(C.c_size_t)]
+        L.migan_pipeline_bbox.argtypes = [vp, ci, ci, ci, ci, vp, C.POINTER(ci), vp]
+        L.migan_pipeline_pre.argtypes = [vp, vp, ci, ci, C.POINTER(ci), ci, vp, vp]
+        L.migan_pipeline_post.argtypes = [vp, vp, ci, ci, C.POINTER(ci), ci, vp, C.POINTER(C.c_float), vp, vp]
         L.migan_num_weights.argtypes = [vp, C.POINTER(ci)]
         L.migan_weight_info.argtypes = [vp, ci, C.POINTER(C.c_char_p), C.POINTER(C.c_int64), C.POINTER(ci), C.POINTER(ci)]
         L.migan_set_weight.argtypes = [vp, C.c_char_p, vp, C.POINTER(C.c_int64), ci]
@@ -189,6 +194,30 @@ class MiganLib:
                        stream: int = 0) -> None:
         self.check(self.lib.migan_compose_output(C.c_void_p(y_ptr), C.c_void_p(img_ptr), C.c_void_p(mask_ptr),
                                                  C.c_void_p(out_ptr), int(batch), int(resolution), C.c_void_p(stream)))
+
+    # the deployed pipeline (include/migan_hip.h, reference scripts/create_onnx_pipeline.py:118-264)
+    def pipeline_scratch_bytes(self, height: int, width: int) -> int:
+        n = C.c_size_t()
+        self.check(self.lib.migan_pipeline_scratch_bytes(int(height), int(width), C.byref(n)))
+        return int(n.value)
+
+    def pipeline_bbox(self, mask_ptr: int, height: int, width: int, resolution: int, padding: int, scratch_ptr: int, stream: int = 0):
+        box = (C.c_int * 4)()
+        self.check(self.lib.migan_pipeline_bbox(C.c_void_p(mask_ptr), int(height), int(width), int(resolution), int(padding),
+                                                C.c_void_p(scratch_ptr), box, C.c_void_p(stream)))
+        return tuple(int(v) for v in box)
+
+    def pipeline_pre(self, image_ptr: int, mask_ptr: int, height: int, width: int, bbox, resolution: int, x_ptr: int, stream: int = 0) -> None:
+        box = (C.c_int * 4)(*[int(v) for v in bbox])
+        self.check(self.lib.migan_pipeline_pre(C.c_void_p(image_ptr), C.c_void_p(mask_ptr), int(height), int(width), box, int(resolution),
+                                               C.c_void_p(x_ptr), C.c_void_p(stream)))
+
+    def pipeline_post(self, image_ptr: int, mask_ptr: int, height: int, width: int, bbox, resolution: int, y_ptr: int, scratch_ptr: int,
+                      gauss25=None, stream: int = 0) -> None:
+        box = (C.c_int * 4)(*[int(v) for v in bbox])
+        g = None if gauss25 is None else (C.c_float * 25)(*[float(v) for v in gauss25])
+        self.check(self.lib.migan_pipeline_post(C.c_void_p(image_ptr), C.c_void_p(mask_ptr), int(height), int(width), box, int(resolution),
+                                                C.c_void_p(y_ptr), g, C.c_void_p(scratch_ptr), C.c_void_p(stream)))
 
     def sepconv_forward(self, stream: int = 0, **kw) -> None:
         d = SepConvDesc()

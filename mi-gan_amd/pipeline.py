@@ -3,6 +3,8 @@
 C ABI (``migan_pack_input`` / ``migan_compose_output``).  Like the generator there is no CPU path."""
 from __future__ import annotations
 
+import math
+
 import torch
 
 from .hipbind import load_library
@@ -40,3 +42,71 @@ def compose(y: torch.Tensor, img_u8: torch.Tensor, mask_u8: torch.Tensor) -> tor
     load_library().compose_output(y.contiguous().data_ptr(), img_u8.data_ptr(), mask_u8.data_ptr(), out.data_ptr(), n, r,
                                   int(torch.cuda.current_stream(img_u8.device).cuda_stream))
     return out
+
+
+class MIGAN_Pipeline(torch.nn.Module):
+    """The reference's deployed pipeline, scripts/create_onnx_pipeline.py::MIGAN_Pipeline (:118-264, exported there as
+    migan_pipeline_v2.onnx), on the GPU through the C ABI: masked bounding box -> crop -> resize to the network resolution ->
+    generator -> resize back -> feathered blend into the image (``migan_pipeline_bbox / _pre / _post`` either side of
+    ``migan_forward``).  Same constructor and ``forward(image, mask)`` contract as the reference module:
+
+      image (1, 3, H, W) uint8, mask (1, 1, H, W) uint8 (255 = known pixel); the image is modified in place and returned.
+
+    ``model_path`` is a reference ``migan_*.pt`` state dict, or an already built ``mi-gan_amd`` Generator.  The mask must already
+    have the image's size (the reference's first line resizes it).  No CPU path."""
+
+    def __init__(self, model_path, resolution: int, padding: int = 128, device="cuda"):
+        super().__init__()
+        from .migan_inference import Generator
+        if isinstance(model_path, torch.nn.Module):
+            self.model = model_path
+        else:
+            self.model = Generator(resolution=resolution)
+            self.model.load_state_dict(torch.load(model_path, map_location="cpu"))
+        self.model = self.model.to(device).eval()
+        self.res = int(resolution)
+        self.padding = int(padding)
+        # GaussianSmoothing(channels=1, kernel_size=5, sigma=1.0, dim=2).weight (:63-85), in torch fp32 like the reference buffer
+        ax = torch.arange(5, dtype=torch.float32)
+        g = 1 / (1.0 * math.sqrt(2 * math.pi)) * torch.exp(-((ax - 2.0) / (2 * 1.0)) ** 2)
+        k = g[:, None] * g[None, :]
+        self.gaussian_weight = (k / k.sum()).contiguous()          # host side: handed to migan_pipeline_post by value
+        self._gauss = self.gaussian_weight.flatten().tolist()
+        self._scratch = None
+
+    def _scratch_for(self, lib, h: int, w: int, device) -> torch.Tensor:
+        need = lib.pipeline_scratch_bytes(h, w)
+        if self._scratch is None or self._scratch.numel() < need or self._scratch.device != device:
+            self._scratch = torch.empty(need, dtype=torch.uint8, device=device)
+        return self._scratch
+
+    def get_masked_bbox(self, mask: torch.Tensor):
+        """(:132-231) -> x_min, x_max, y_min, y_max"""
+        lib = load_library()
+        h, w = int(mask.shape[-2]), int(mask.shape[-1])
+        scratch = self._scratch_for(lib, h, w, mask.device)
+        return lib.pipeline_bbox(mask.data_ptr(), h, w, self.res, self.padding, scratch.data_ptr(),
+                                 int(torch.cuda.current_stream(mask.device).cuda_stream))
+
+    @torch.no_grad()
+    def forward(self, image: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
+        if not (image.is_cuda and mask.is_cuda):
+            raise RuntimeError("mi-gan_amd.pipeline needs tensors on an MI355X (HIP) device; there is no CPU path")
+        if image.dtype != torch.uint8 or mask.dtype != torch.uint8:
+            raise RuntimeError("image and mask must be uint8 (reference create_onnx_pipeline.py:254-255)")
+        if image.dim() != 4 or image.shape[0] != 1 or image.shape[1] != 3 or not image.is_contiguous():
+            raise RuntimeError(f"expected a contiguous image (1, 3, H, W), got {list(image.shape)}")
+        h, w = int(image.shape[2]), int(image.shape[3])
+        if tuple(mask.shape) != (1, 1, h, w):
+            raise RuntimeError(f"expected mask (1, 1, {h}, {w}), got {list(mask.shape)}")
+        mask = mask.contiguous()
+        lib = load_library()
+        stream = int(torch.cuda.current_stream(image.device).cuda_stream)
+        scratch = self._scratch_for(lib, h, w, image.device)
+        bbox = lib.pipeline_bbox(mask.data_ptr(), h, w, self.res, self.padding, scratch.data_ptr(), stream)
+        x = torch.empty((1, 4, self.res, self.res), dtype=torch.float32, device=image.device)
+        lib.pipeline_pre(image.data_ptr(), mask.data_ptr(), h, w, bbox, self.res, x.data_ptr(), stream)
+        y = self.model(x).contiguous()
+        lib.pipeline_post(image.data_ptr(), mask.data_ptr(), h, w, bbox, self.res, y.data_ptr(), scratch.data_ptr(),
+                          gauss25=self._gauss, stream=stream)
+        return image

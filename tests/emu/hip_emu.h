@@ -123,6 +123,8 @@ void run_grid(void (*invoke)(const void*), const void* arg, unsigned grid, unsig
 #define MIGAN_LAUNCH_BOUNDS(a, b)
 #define MIGAN_DYN_SMEM(name) float* name = hipemu::tl_blk->smem
 #define MIGAN_FMUL_RN(a, b) ((float)((a) * (b)))
+#define MIGAN_FADD_RN(a, b) ((float)((a) + (b)))
+#define MIGAN_FSUB_RN(a, b) ((float)((a) - (b)))
 inline float __shfl_xor(float v, int mask);
 #define MIGAN_CLAMP(v, lo, hi) fminf(fmaxf((v), (lo)), (hi))
 #define MIGAN_SWIZZLE_XOR(v, m) __shfl_xor((v), (m))

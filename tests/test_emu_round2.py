@@ -345,22 +345,6 @@ def test_forward_hw_vs_reference_goldens(pkg, lib, golden_dir):
         np.testing.assert_allclose(y, g["y"], rtol=0, atol=3e-5 * max(1.0, float(g["y_absmax"])), err_msg=os.path.basename(f))
 
 
-# ------------------------------------------------------------------------------------------------ 64-pixel tiles (round-3 experiment knob)
-@pytest.mark.parametrize("mt64,case", [
-    (1, dict(cin=128, cout=128, h=16, batch=2, noise=True, skip=True)),
-    (1, dict(cin=128, cout=128, h=16, batch=1, noise=True, torgb=True, with_prev=True)),
-    (1, dict(cin=128, cout=256, h=16, w=32, batch=1, noise=True)),
-    (2, dict(cin=128, cout=256, h=16, batch=2, noise=True, skip=True)),
-    (2, dict(cin=256, cout=512, h=16, batch=1)),
-])
-def test_sepconv_64_pixel_tiles(lib, pkg, mt64, case):
-    lib.set_tuning("mt64", mt64)
-    try:
-        _sepconv(lib, pkg, gemm=2, **case)
-    finally:
-        lib.set_tuning("mt64", 0)
-
-
 # ------------------------------------------------------------------------------------------------ wide tile, all MFMAs on waves 4-7 (round 3)
 @pytest.mark.parametrize("storage,gemm", [("f32", 2), ("bf16", -1), ("f16", 2)])
 @pytest.mark.parametrize("case", [
