@@ -448,8 +448,8 @@ def run_workload(args, rank, local_rank, world, dist, dev):
             # north star: "the node's host cores (core count stated)": the all-cores figure beside the fastest setting, capped
             rate, why = all_cores_cpu_rate(res, cap_s=600 if args.cpu_all_cores else 100)
             cpu["value_all_cores"], cpu["all_cores"] = rate, cores
-            if why:
-                cpu["all_cores_note"] = why
+            cpu["all_cores_note"] = why or ("one un-warmed image in a child process with torch.set_num_threads(all logical cores): slower than the "
+                                            f"{threads}-thread figure above because the port's small oneDNN ops oversubscribe; `value` is the fastest setting")
         if wl.get("post"):                                   # uint8 output: compare in uint8 steps with the composed oracle output
             parity = float((y[:n].cpu().to(torch.int16) - wl["post"](ref, n)).abs().max())
             parity32 = float((y[:n].cpu().to(torch.int16) - wl["post"](ref32, n)).abs().max())
