@@ -90,7 +90,11 @@ def test_roofline_arithmetic_on_synthetic_launches():
     # traffic lookup
     b.attach_traffic(r, "profiles/pmc_traffic_latest.json", True)
     assert r["traffic"] is None and "not in" in r["traffic_note"]
-    real = next(iter(_json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic_latest.json")))))
+    table = _json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic_latest.json")))
+    real = next(k for k in table if not k.startswith("_"))
     r["kernel"] = real
     b.attach_traffic(r, "profiles/pmc_traffic_latest.json", True)
     assert r["traffic"] and r["traffic"] > 0
+    # the table names the sources it was measured on; the line says whether those are the sources of the library that ran
+    assert table["_meta"]["kernel_source_sha"] == r["traffic_measured_on"]
+    assert r["traffic_stale"] == (r["traffic_measured_on"] != b.kernel_source_sha())
