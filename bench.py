@@ -139,7 +139,9 @@ def roofline_from_launches(launches, ms_rounds, batch, gemm="f32"):
         "whole_forward": {
             "sum_kernel_ms": round(total_ms, 4),
             "mfma_tflops": round(tot_mfma / (total_ms * 1e-3) / 1e12, 3),
-            "mfma_frac": round(tot_mfma / (total_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+            "mfma_frac": round(tot_mfma / (total_ms * 1e-3) / 1e12 / peak_mfma, 4),          # of this GEMM variant's ceiling (algorithmic flops)
+            "mfma_peak_tflops": round(peak_mfma, 1),
+            "frac_vs_fp32_mfma_peak": round(tot_mfma / (total_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
             "hbm_gbs": round(tot_bytes / (total_ms * 1e-3) / 1e9, 1),
             "hbm_frac": round(tot_bytes / (total_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
             "alg_bytes": tot_bytes, "alg_mfma_flop": tot_mfma,
