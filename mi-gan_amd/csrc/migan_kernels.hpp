@@ -80,7 +80,7 @@ struct SepArgs {
   int b_stride;                    // floats between the two 1x1-weight buffers (0 = single buffered)
   int a_stride;                    // MODE_PW: floats between the two A-operand buffers
   int ablate;                      // measurement builds only (MIGAN_ABLATE): bit0 no epilogue stores, bit1 no epilogue,
-                                   // bit2 no depthwise stage, bit3 no MFMA, bit4 no global input loads; 0 in production
+                                   // bit2 no depthwise stage, bit3 no MFMA, bit4 no global input loads, bit5 no 1x1-weight loads; 0 in production
 };
 
 struct RgbArgs {
@@ -597,8 +597,13 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, MINW) sepconv_kernel(const SepArgs p)
     }
     if constexpr (BF) {
       const unsigned short* __restrict__ wk = p.wsplit + (size_t)(k0 >> 5) * 32 * p.CO + (k0 & 31);   // 32-channel block k0/32, column k0%32
+      if (MIGAN_ABL(32)) {
 #pragma unroll
-      for (int j = 0; j < NB; ++j) rb[j] = ld4(at_bytes(reinterpret_cast<const float*>(wk), boff_[j]));
+        for (int j = 0; j < NB; ++j) rb[j] = f4{0.f, 0.f, 0.f, 0.f};
+      } else {
+#pragma unroll
+        for (int j = 0; j < NB; ++j) rb[j] = ld4(at_bytes(reinterpret_cast<const float*>(wk), boff_[j]));
+      }
     } else {
       const float* __restrict__ wk = gwpw + k0;
 #pragma unroll
