@@ -93,6 +93,8 @@ struct Tuning {
                                // per CU, 164 VGPRs) and the plain / ToRGB layers with Cin = 64, whose two K chunks unroll at compile time
                                // (135 VGPRs instead of 184; synthesis.b512.conv2 1.34 -> 1.07 ms).  The FIR-up tile (4 chunks) needs 60 bytes
                                // of scratch at that budget and loses 10 %: profiles/r02_w3_and_persistence_sweep.txt
+  int small = 1;               // f16x2 / fp32 storage: plain and pointwise launches of at most small_max_wgs 32-row tiles use them
+  int small_max_wgs = 512;     // (MIGAN_GEOMETRIES_SMALL; single-image latency and the <= 16x16 layers)
   int streams = 2;             // MIGAN_STREAMS=1|2: default of migan_set_streams
   int stagger = -1;            // MIGAN_STAGGER: launch index of the first half after which the second half starts (-1: plan default)
   int debug_split = 0;         // diagnostics: keep the two-sub-batch execution in keep-intermediates mode
@@ -120,7 +122,10 @@ inline Tuning& tuning() {
 
 // Tile geometry for a layer whose GEMM runs on an h_in x w_in pixel grid.  Square power-of-two sizes (the reference's
 // fixed resolutions) get the tuned geometries; any other size (migan_forward_hw) gets 8x16 tiles with ragged edges.
-inline Geo choose_geo(int mode, int cin, int cout, int h_in, int w_in, bool fromrgb, bool with_torgb = false, int gemmv = -1, int stv = 0) {
+// small: the 32-row variant of a plain / pointwise layer for launches of few workgroups (MIGAN_GEOMETRIES_SMALL): 4x8-pixel tiles, or two
+// 4x4 images per tile; never wide, never with a fused ToRGB tail.
+inline Geo choose_geo(int mode, int cin, int cout, int h_in, int w_in, bool fromrgb, bool with_torgb = false, int gemmv = -1, int stv = 0,
+                      bool small = false) {
   Geo g;
   g.gemmv = gemmv < 0 ? tuning().gemm : gemmv;
   g.stv = stv;
@@ -138,7 +143,10 @@ inline Geo choose_geo(int mode, int cin, int cout, int h_in, int w_in, bool from
   int GH, GW, IMGS;
   if (mode == MODE_NORMAL) {
     g.MT = 128; g.KC = 32;
-    if (full && cout % 256 == 0 && !fromrgb && g.gemmv >= 2 && tuning().wide) {
+    if (small) {
+      g.MT = 32; g.NT = 128; GH = 4;
+      if (sq2 && h_in == 4) { GW = 4; IMGS = 2; } else { GW = 8; IMGS = 1; }
+    } else if (full && cout % 256 == 0 && !fromrgb && g.gemmv >= 2 && tuning().wide) {
       // wide layers: one 8-wave workgroup owns 256 output channels of 8x16 pixels; half of its waves run the
       // depthwise stage of the next K chunk while the other half keeps the matrix cores busy (sepconv_wide_kernel)
       g.wide = true; g.NT = 256; GH = 8; GW = 16; IMGS = 1;
@@ -157,12 +165,17 @@ inline Geo choose_geo(int mode, int cin, int cout, int h_in, int w_in, bool from
     // pointwise GEMM at h_in x w_in (second half of a down=2 layer; its input is dwfir_kernel's output)
     MIGAN_CHECK(!fromrgb, MIGAN_EINVAL, "fromrgb is only fused into plain layers");
     g.MT = 128; g.KC = 32;
-    if (sq2 && h_in == 8) { GH = 8; GW = 8; IMGS = 2; }
+    if (small) {
+      g.MT = 32; g.NT = 128; GH = 4;
+      if (sq2 && h_in == 4) { GW = 4; IMGS = 2; } else { GW = 8; IMGS = 1; }
+    }
+    else if (sq2 && h_in == 8) { GH = 8; GW = 8; IMGS = 2; }
     else if (sq2 && h_in == 4) { GH = 4; GW = 4; IMGS = 8; }
     else { GH = 8; GW = 16; IMGS = 1; }
     g.sy = GH; g.sx = GW; g.off = 0;
     g.tiles_y = cdiv(h_in, GH); g.tiles_x = cdiv(w_in, GW);
   } else {
+    MIGAN_CHECK(!small, MIGAN_EINVAL, "internal: no 32-row variant of FIR-up layers");
     MIGAN_CHECK(!fromrgb, MIGAN_EINVAL, "fromrgb is only fused into plain layers");
     g.MT = 128; g.KC = 32;
     if (sq2 && h_in < 8) { GH = 8; GW = 8; IMGS = 2; }
@@ -180,7 +193,9 @@ inline Geo choose_geo(int mode, int cin, int cout, int h_in, int w_in, bool from
   }
   MIGAN_CHECK(IMGS * GH * GW == g.MT, MIGAN_EINVAL, "internal: tile geometry does not fill the GEMM tile");
   const int QC = g.KC / 4;
-  const int rs = GH / 4 > 0 ? GH / 4 : 1;        // depthwise strips are 4 output rows tall
+  if (small) MIGAN_CHECK(g.gemmv == 2 && stv == 0 && cout % 128 == 0 && !fromrgb && h_in % 4 == 0 && w_in % GW == 0, MIGAN_EINVAL,
+                         "internal: no 32-row variant of this layer");
+  const int rs = g.MT == 32 ? GH / 2 : (GH / 4 > 0 ? GH / 4 : 1);   // depthwise strips are 4 output rows tall (2 in the 32- and 64-row tiles)
   g.lgRS = ilog2(rs);
   const int halo = (mode == MODE_PW) ? 0 : 1;
   g.npix_in = IMGS * (GH + 2 * halo) * (GW + 2 * halo);
@@ -194,7 +209,8 @@ inline Geo choose_geo(int mode, int cin, int cout, int h_in, int w_in, bool from
     if ((tuning().w3 & bit) && (bit != 1 || cin == 64)) g.MINW = 3;
   }
   if (g.MT == 64 && g.NT == 128 && mode == MODE_NORMAL) g.MINW = 3;   // 32 accumulator registers per lane: three workgroups per CU
-  if (mode == MODE_PW || g.MT == 64) g.NI = 4;
+  if (g.MT == 32) g.NI = mode == MODE_PW ? 1 : 3;
+  else if (mode == MODE_PW || g.MT == 64) g.NI = 4;
   else if (g.KC == 16) g.NI = 3;
   else g.NI = g.maing ? 6 : 9;
   MIGAN_CHECK(items <= g.NI, MIGAN_EINVAL, "internal: input tile too large");
@@ -514,6 +530,8 @@ struct Launch {
   bool is_rgb = false;
   bool is_dwfir = false;
   Geo g;
+  Geo g_small;                       // 32-row variant of g, used when the launch has at most tuning().small_max_wgs of ITS tiles
+  bool has_small = false;
   DwGeo dg;
   int cin = 0, cout = 0, hin = 0, win = 0, hout = 0, wout = 0;
   int in_buf = BUF_NONE, out_buf = BUF_NONE, skip_buf = BUF_NONE, imgprev_buf = BUF_NONE, imgout_buf = BUF_NONE;
@@ -716,6 +734,11 @@ inline void migan_handle::build_plan(migan::Plan& P, int H, int W) const {
     L.g = choose_geo(mode, cin, cout, L.hin, L.win, fromrgb, with_torgb, gemm, stv);
     L.g.torgb = with_torgb && L.g.nchunks == 1;        // one workgroup owns all channels of its pixels: ToRGB fuses
     L.kernel = kernel_name(L.g);
+    if (tuning().small && mode != MODE_UP && gemm == 2 && stv == 0 && !fromrgb && !L.g.torgb && cout % 128 == 0 && L.hin % 4 == 0 &&
+        L.win % (L.hin == 4 && L.win == 4 ? 4 : 8) == 0) {
+      L.g_small = choose_geo(mode, cin, cout, L.hin, L.win, false, false, gemm, stv, true);
+      L.has_small = true;
+    }
     L.cin = cin; L.cout = cout;
     L.in_buf = in_buf; L.out_buf = out_buf; L.skip_buf = skip_buf;
     L.w_dw = slot_index(layer + ".conv1.weight");
@@ -917,9 +940,11 @@ inline void migan_handle::run_range(const migan::Plan& P, const float* x, float*
         a.u8_img = (const unsigned char*)u8->img; a.u8_mask = (const unsigned char*)u8->mask; a.u8_out = (unsigned char*)u8->out;
       }
       a.B = n; a.H = L.hin; a.W = L.win; a.CI = L.cin; a.CO = L.cout; a.HO = L.hout; a.WO = L.wout;
-      fill_geo(a, L.g);
-      launch_sepconv(L.g, a, stream);
-      Geo gl = L.g;
+      // launches that would leave most CUs idle run the 32-row tiles: a quarter of the work per workgroup, four times the workgroups
+      const Geo& G = (L.has_small && (int)tiles_of(L.g_small, n) <= tuning().small_max_wgs) ? L.g_small : L.g;
+      fill_geo(a, G);
+      launch_sepconv(G, a, stream);
+      Geo gl = G;
       gl.persist = use_persistent(gl, n, a.trgb_w != nullptr);
       gl.torgb = a.trgb_w != nullptr;
       L.kernel_last = kernel_name(gl);
@@ -1515,6 +1540,8 @@ int migan_set_tuning(const char* key, int value) {
   else if (k == "kc16_minw") t.kc16_minw = std::min(4, std::max(2, value));
   else if (k == "w3") t.w3 = value;
   else if (k == "wide") t.wide = value;
+  else if (k == "small") t.small = value;
+  else if (k == "small_max_wgs") t.small_max_wgs = value;
   else if (k == "nt256") t.nt256 = value != 0;
   else if (k == "persist_min") t.persist_min = std::max(1, value);
   else if (k == "persist_grid") t.persist_grid = std::max(8, value / 8 * 8);

@@ -65,6 +65,13 @@ struct KernelEntry {
   MIGAN_K(0, 128, 64, 32, false, 6, 3, true, false, G, false, S), MIGAN_K(0, 128, 64, 32, false, 6, 3, true, false, G, true, S),   \
   MIGAN_K(0, 128, 64, 32, true, 6, 3, true, false, G, false, S), MIGAN_K(2, 128, 64, 32, false, 6, 3, true, false, G, false, S)
 
+// 32-row tiles (4x8 pixels, or two 4x4 images) x 128 output channels for launches that would leave most CUs idle: single-image latency,
+// the <= 16x16 layers at any batch.  The stage ablation at batch 1 (profiles/r03_batch1_latency_experiments.txt) shows such a launch is
+// bound by the instruction stream of its (mostly padded, or lone-on-its-CU) 128-row tile, not by memory: a quarter of the work per
+// workgroup, four times the workgroups.  Plain and pointwise layers, f16x2 GEMM, fp32 storage, run-time geometry.
+#define MIGAN_GEOMETRIES_SMALL(G, S)                                                                                               \
+  MIGAN_K(0, 32, 128, 32, false, 3, 2, false, false, G, false, S), MIGAN_K(3, 32, 128, 32, false, 1, 2, false, false, G, false, S)
+
 struct KernelSlice {
   const KernelEntry* entries;
   int n;
