@@ -95,6 +95,8 @@ struct Tuning {
                                // of scratch at that budget and loses 10 %: profiles/r02_w3_and_persistence_sweep.txt
   int small = 1;               // f16x2 / fp32 storage: plain and pointwise launches of at most small_max_wgs 32-row tiles use them
   int small_max_wgs = 512;     // (MIGAN_GEOMETRIES_SMALL; single-image latency and the <= 16x16 layers)
+  int small_kc = 64;           // K chunk of those tiles: 32 or 64 channels (batch 1: 0.85 ms with 32, 0.81 ms with 64)
+  int small_up32 = 1;          // FIR-up layers: try the 32-row tile before the 64-row one
   int streams = 2;             // MIGAN_STREAMS=1|2: default of migan_set_streams
   int stagger = -1;            // MIGAN_STAGGER: launch index of the first half after which the second half starts (-1: plan default)
   int debug_split = 0;         // diagnostics: keep the two-sub-batch execution in keep-intermediates mode
@@ -125,7 +127,7 @@ inline Tuning& tuning() {
 // small: the 32-row variant of a plain / pointwise layer for launches of few workgroups (MIGAN_GEOMETRIES_SMALL): 4x8-pixel tiles, or two
 // 4x4 images per tile; never wide, never with a fused ToRGB tail.
 inline Geo choose_geo(int mode, int cin, int cout, int h_in, int w_in, bool fromrgb, bool with_torgb = false, int gemmv = -1, int stv = 0,
-                      bool small = false) {
+                      int small = 0) {   // 0 regular | 1 small | 2 (FIR-up only) the 32-row tile
   Geo g;
   g.gemmv = gemmv < 0 ? tuning().gemm : gemmv;
   g.stv = stv;
@@ -175,10 +177,11 @@ inline Geo choose_geo(int mode, int cin, int cout, int h_in, int w_in, bool from
     g.sy = GH; g.sx = GW; g.off = 0;
     g.tiles_y = cdiv(h_in, GH); g.tiles_x = cdiv(w_in, GW);
   } else {
-    MIGAN_CHECK(!small, MIGAN_EINVAL, "internal: no 32-row variant of FIR-up layers");
     MIGAN_CHECK(!fromrgb, MIGAN_EINVAL, "fromrgb is only fused into plain layers");
     g.MT = 128; g.KC = 32;
-    if (sq2 && h_in < 8) { GH = 8; GW = 8; IMGS = 2; }
+    if (small == 2) { g.MT = 32; g.NT = 128; GH = 4; GW = 8; IMGS = 1; }   // 4x8 grid of GEMM pixels, 2x6 interior
+    else if (small) { g.MT = 64; g.NT = 128; GH = 8; GW = 8; IMGS = 1; }   // 8x8 grid, 6x6 interior
+    else if (sq2 && h_in < 8) { GH = 8; GW = 8; IMGS = 2; }
     else { GH = 8; GW = 16; IMGS = 1; }
     g.sy = GH - 2; g.sx = GW - 2; g.off = 1;     // 1-pixel halo of GEMM outputs is recomputed per tile
     g.tiles_y = cdiv(h_in, g.sy); g.tiles_x = cdiv(w_in, g.sx);
@@ -193,9 +196,13 @@ inline Geo choose_geo(int mode, int cin, int cout, int h_in, int w_in, bool from
   }
   MIGAN_CHECK(IMGS * GH * GW == g.MT, MIGAN_EINVAL, "internal: tile geometry does not fill the GEMM tile");
   const int QC = g.KC / 4;
-  if (small) MIGAN_CHECK(g.gemmv == 2 && stv == 0 && cout % 128 == 0 && !fromrgb && h_in % 4 == 0 && w_in % GW == 0, MIGAN_EINVAL,
-                         "internal: no 32-row variant of this layer");
-  const int rs = g.MT == 32 ? GH / 2 : (GH / 4 > 0 ? GH / 4 : 1);   // depthwise strips are 4 output rows tall (2 in the 32- and 64-row tiles)
+  if (small) {
+    MIGAN_CHECK(g.gemmv == 2 && stv == 0 && cout % 128 == 0 && !fromrgb && (mode == MODE_UP || (h_in % 4 == 0 && w_in % GW == 0)), MIGAN_EINVAL,
+                "internal: no small-launch variant of this layer");
+    if (tuning().small_kc == 64 && cin % 64 == 0) g.KC = 64;
+  }
+  const int segh = g.MT >= 128 ? 4 : 2;          // output rows per depthwise strip (the kernel's SEGH)
+  const int rs = (g.MT == 32 || (g.MT == 64 && small)) ? GH / segh : (GH / 4 > 0 ? GH / 4 : 1);   // (RS * SEGH = GH)
   g.lgRS = ilog2(rs);
   const int halo = (mode == MODE_PW) ? 0 : 1;
   g.npix_in = IMGS * (GH + 2 * halo) * (GW + 2 * halo);
@@ -209,7 +216,10 @@ inline Geo choose_geo(int mode, int cin, int cout, int h_in, int w_in, bool from
     if ((tuning().w3 & bit) && (bit != 1 || cin == 64)) g.MINW = 3;
   }
   if (g.MT == 64 && g.NT == 128 && mode == MODE_NORMAL) g.MINW = 3;   // 32 accumulator registers per lane: three workgroups per CU
-  if (g.MT == 32) g.NI = mode == MODE_PW ? 1 : 3;
+  if (small) {   // prefetch items per thread of the MIGAN_GEOMETRIES_SMALL instantiations: [K chunk 32 | 64][plain, FIR-up, pointwise]
+    static const int ni_small[2][4] = {{3, 4, 1, 2}, {5, 7, 2, 4}};      // (last column: FIR-up on the 32-row tile)
+    g.NI = ni_small[g.KC == 64][mode == MODE_PW ? 2 : (mode == MODE_UP ? (g.MT == 32 ? 3 : 1) : 0)];
+  }
   else if (mode == MODE_PW || g.MT == 64) g.NI = 4;
   else if (g.KC == 16) g.NI = 3;
   else g.NI = g.maing ? 6 : 9;
@@ -530,8 +540,8 @@ struct Launch {
   bool is_rgb = false;
   bool is_dwfir = false;
   Geo g;
-  Geo g_small;                       // 32-row variant of g, used when the launch has at most tuning().small_max_wgs of ITS tiles
-  bool has_small = false;
+  std::vector<Geo> g_small;          // small-tile variants of g, smallest tile first: the first one whose tile count for the launch is at
+                                     // most tuning().small_max_wgs runs instead of g
   DwGeo dg;
   int cin = 0, cout = 0, hin = 0, win = 0, hout = 0, wout = 0;
   int in_buf = BUF_NONE, out_buf = BUF_NONE, skip_buf = BUF_NONE, imgprev_buf = BUF_NONE, imgout_buf = BUF_NONE;
@@ -734,10 +744,10 @@ inline void migan_handle::build_plan(migan::Plan& P, int H, int W) const {
     L.g = choose_geo(mode, cin, cout, L.hin, L.win, fromrgb, with_torgb, gemm, stv);
     L.g.torgb = with_torgb && L.g.nchunks == 1;        // one workgroup owns all channels of its pixels: ToRGB fuses
     L.kernel = kernel_name(L.g);
-    if (tuning().small && mode != MODE_UP && gemm == 2 && stv == 0 && !fromrgb && !L.g.torgb && cout % 128 == 0 && L.hin % 4 == 0 &&
-        L.win % (L.hin == 4 && L.win == 4 ? 4 : 8) == 0) {
-      L.g_small = choose_geo(mode, cin, cout, L.hin, L.win, false, false, gemm, stv, true);
-      L.has_small = true;
+    if (tuning().small && gemm == 2 && stv == 0 && !fromrgb && !L.g.torgb && cout % 128 == 0 &&
+        (mode == MODE_UP || (L.hin % 4 == 0 && L.win % (L.hin == 4 && L.win == 4 ? 4 : 8) == 0))) {
+      if (mode == MODE_UP && tuning().small_up32) L.g_small.push_back(choose_geo(mode, cin, cout, L.hin, L.win, false, false, gemm, stv, 2));
+      L.g_small.push_back(choose_geo(mode, cin, cout, L.hin, L.win, false, false, gemm, stv, 1));
     }
     L.cin = cin; L.cout = cout;
     L.in_buf = in_buf; L.out_buf = out_buf; L.skip_buf = skip_buf;
@@ -941,7 +951,10 @@ inline void migan_handle::run_range(const migan::Plan& P, const float* x, float*
       }
       a.B = n; a.H = L.hin; a.W = L.win; a.CI = L.cin; a.CO = L.cout; a.HO = L.hout; a.WO = L.wout;
       // launches that would leave most CUs idle run the 32-row tiles: a quarter of the work per workgroup, four times the workgroups
-      const Geo& G = (L.has_small && (int)tiles_of(L.g_small, n) <= tuning().small_max_wgs) ? L.g_small : L.g;
+      const Geo* Gp = &L.g;
+      for (const Geo& gs : L.g_small)
+        if ((int)tiles_of(gs, n) <= tuning().small_max_wgs) { Gp = &gs; break; }
+      const Geo& G = *Gp;
       fill_geo(a, G);
       launch_sepconv(G, a, stream);
       Geo gl = G;
@@ -1542,6 +1555,8 @@ int migan_set_tuning(const char* key, int value) {
   else if (k == "wide") t.wide = value;
   else if (k == "small") t.small = value;
   else if (k == "small_max_wgs") t.small_max_wgs = value;
+  else if (k == "small_kc") t.small_kc = value;
+  else if (k == "small_up32") t.small_up32 = value;
   else if (k == "nt256") t.nt256 = value != 0;
   else if (k == "persist_min") t.persist_min = std::max(1, value);
   else if (k == "persist_grid") t.persist_grid = std::max(8, value / 8 * 8);

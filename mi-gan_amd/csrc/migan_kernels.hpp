@@ -381,8 +381,8 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, MINW) sepconv_kernel(const SepArgs p)
   MIGAN_DYN_SMEM(smem);
 
   constexpr int QC = KC / 4;                       // float4 groups per pixel in a K chunk
-  constexpr int LG_QC = (QC == 8) ? 3 : 2;
-  static_assert(QC == 8 || QC == 4, "KC must be 32 or 16");
+  constexpr int LG_QC = (QC == 16) ? 4 : ((QC == 8) ? 3 : 2);
+  static_assert(QC == 16 || QC == 8 || QC == 4, "KC must be 64, 32 or 16");
   constexpr int AS = KC + 4;                       // A/B row pitch (floats): odd number of 16-B slots -> conflict-free b128
   constexpr int GS = NT + 4;                       // result tile row pitch
   constexpr int QN = NT / 4;
@@ -400,7 +400,8 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, MINW) sepconv_kernel(const SepArgs p)
   constexpr int NSLOT = PB / 16;
   constexpr int NB = BF ? NPL * NT * NSLOT / kThreads : NT * QC / kThreads;   // float4 items of the 1x1 weight tile per thread
   static_assert(NB >= 1 && NB * kThreads == (BF ? NPL * NT * NSLOT : NT * QC), "weight tile must split evenly over the threads");
-  static_assert(!BF || KC == 32 || KC == 16, "the split GEMM variants are built for 32- or 16-channel chunks");
+  static_assert(!BF || KC == 64 || KC == 32 || KC == 16, "the split GEMM variants are built for 64-, 32- or 16-channel chunks");
+  static_assert(KC != 64 || (BF && !FROMRGB && !PERSIST && !TORGB), "64-channel chunks: the small-launch tiles of the split GEMM variants");
   // input tensor format: the network input planes (FROMRGB) and dwfir_kernel's output (MODE_PW) are always fp32
   // ... except for the "f16" GEMM variant, whose dwfir_kernel<.., 3|4> writes the A operand itself (fp16 of value x 2^7)
   constexpr bool PWH = MODE == MODE_PW && GEMMV == 3;
@@ -475,9 +476,10 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, MINW) sepconv_kernel(const SepArgs p)
   float* g_s = smem;                        // after the K loop: [MT][GS], aliases the buffers above
   // A-operand row m, channels 4*c4..4*c4+3 of the current chunk
   // XOR swizzle of the 16-byte slots of a row of a 16-bit operand plane (conflict-free ds_read_b128 of 32 consecutive
-  // rows): 64-byte rows (KC 32) rotate through their 4 slots every 4 rows, 32-byte rows (KC 16) swap their 2 slots
-  // every 8 rows
-  auto swz = [](int row) { return NSLOT == 4 ? ((row >> 2) & 3) : ((row >> 3) & 1); };
+  // rows): 64-byte rows (KC 32) rotate through their 4 slots every 4 rows, 32-byte rows (KC 16) swap their 2 slots every 8 rows,
+  // 128-byte rows (KC 64) rotate through their 8 slots every 2 rows: in each case 16 consecutive rows cover every 16-byte slot
+  // of a 256-byte LDS bank row exactly once
+  auto swz = [](int row) { return NSLOT == 8 ? ((row >> 1) & 7) : (NSLOT == 4 ? ((row >> 2) & 3) : ((row >> 3) & 1)); };
   auto emit_a = [&](float* abase, int m, int c4, f4 v) {
     if constexpr (X1) {
       char* d = reinterpret_cast<char*>(abase) + m * PB + (((c4 >> 1) ^ swz(m)) << 4) + ((c4 & 1) << 3);
@@ -546,7 +548,9 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, MINW) sepconv_kernel(const SepArgs p)
         // item = (plane, row n, 16-byte slot of 8 pieces); offset in 16-bit elements inside one 32-channel block of the
         // chunk-major planes [NPL][CI/32][CO][32] (the weight tile of a 32-channel K chunk is one contiguous run)
         const int plane = i / (NT * NSLOT), rem = i % (NT * NSLOT);
-        boff_[j] = (unsigned)(plane * p.CO * p.CI + (n0_ + rem / NSLOT) * 32 + (rem % NSLOT) * 8) * 2u;    // bytes
+        // (a 64-channel chunk spans two 32-channel blocks: slots 4-7 come from the next block, 32 * CO elements further on)
+        const int slot = rem % NSLOT;
+        boff_[j] = (unsigned)(plane * p.CO * p.CI + (slot >> 2) * 32 * p.CO + (n0_ + rem / NSLOT) * 32 + (slot & 3) * 8) * 2u;    // bytes
       } else {
         boff_[j] = (unsigned)((n0_ + (i >> LG_QC)) * p.CI + (i & (QC - 1)) * 4) * 4u;                      // bytes
       }

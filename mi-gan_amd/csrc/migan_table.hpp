@@ -69,8 +69,14 @@ struct KernelEntry {
 // the <= 16x16 layers at any batch.  The stage ablation at batch 1 (profiles/r03_batch1_latency_experiments.txt) shows such a launch is
 // bound by the instruction stream of its (mostly padded, or lone-on-its-CU) 128-row tile, not by memory: a quarter of the work per
 // workgroup, four times the workgroups.  Plain and pointwise layers, f16x2 GEMM, fp32 storage, run-time geometry.
+// FIR-up layers: 64-row tiles (8x8 grid of GEMM pixels, 6x6 of them interior) or 32-row tiles (4x8 grid, 2x6 interior) for the smallest
+// launches.  KC 64: the same tiles with 64-channel K chunks.
 #define MIGAN_GEOMETRIES_SMALL(G, S)                                                                                               \
-  MIGAN_K(0, 32, 128, 32, false, 3, 2, false, false, G, false, S), MIGAN_K(3, 32, 128, 32, false, 1, 2, false, false, G, false, S)
+  MIGAN_K(0, 32, 128, 32, false, 3, 2, false, false, G, false, S), MIGAN_K(3, 32, 128, 32, false, 1, 2, false, false, G, false, S), \
+  MIGAN_K(2, 64, 128, 32, false, 4, 2, false, false, G, false, S),                                                                 \
+  MIGAN_K(0, 32, 128, 64, false, 5, 2, false, false, G, false, S), MIGAN_K(3, 32, 128, 64, false, 2, 2, false, false, G, false, S), \
+  MIGAN_K(2, 64, 128, 64, false, 7, 2, false, false, G, false, S),                                                                 \
+  MIGAN_K(2, 32, 128, 32, false, 2, 2, false, false, G, false, S), MIGAN_K(2, 32, 128, 64, false, 4, 2, false, false, G, false, S)
 
 struct KernelSlice {
   const KernelEntry* entries;

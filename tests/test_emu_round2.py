@@ -2,6 +2,8 @@
 C ABI: 16-bit activation storage (BASELINE configs[1]), 16-channel K-chunk tiles, two sub-batches, static weights,
 per-handle GEMM variants and persistent workgroups (in-process), the arbitrary-size forward and the
 uint8-in / uint8-out forward (N2)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -20,7 +22,8 @@ def lib():
 def tuned(lib):
     """set process-wide tuning knobs for one test, restore the defaults afterwards"""
     changed = {}
-    defaults = dict(kc16=0, kc16_minw=3, w3=3, wide=3, nt256=1, persist_min=8192, persist_grid=512, streams=2, stagger=-1)
+    defaults = dict(kc16=0, kc16_minw=3, w3=3, wide=3, nt256=1, persist_min=8192, persist_grid=512, streams=2, stagger=-1,
+                    small=1, small_max_wgs=512, small_kc=64, small_up32=1)
 
     def set_(key, value):
         changed[key] = True
@@ -197,6 +200,36 @@ def test_generator_per_handle_gemm_variant(pkg, lib, tuned, gemm):
     assert hb.gemm() == "f16x2"
     with pytest.raises(ValueError):
         h.set_gemm("f16")                                          # fp32 storage keeps fp32-grade products
+
+
+# ------------------------------------------------------------------------------------------------ small-launch tiles (round 3)
+@pytest.mark.parametrize("knobs,expect", [
+    (dict(small=0), ["<0, 128, 128, 32, false, 9, 2, false", "<2, 128, 128, 32, false, 9, 2, false", "<3, 128, 128, 32, false, 4, 2, false"]),
+    (dict(small_kc=32, small_up32=0), ["<0, 32, 128, 32, false, 3, 2", "<2, 64, 128, 32, false, 4, 2", "<3, 32, 128, 32, false, 1, 2"]),
+    (dict(small_kc=64, small_up32=0), ["<0, 32, 128, 64, false, 5, 2", "<2, 64, 128, 64, false, 7, 2", "<3, 32, 128, 64, false, 2, 2"]),
+    (dict(small_kc=32), ["<2, 32, 128, 32, false, 2, 2"]),
+    (dict(), ["<0, 32, 128, 64, false, 5, 2", "<2, 32, 128, 64, false, 4, 2", "<3, 32, 128, 64, false, 2, 2"]),
+    (dict(small_max_wgs=6), ["<0, 128, 128, 32, false, 9, 2, false", "<0, 32, 128, 64, false, 5, 2"]),   # per launch: only the <= 6-tile launches
+], ids=["regular", "kc32", "kc64", "kc32_up32", "default", "threshold"])
+def test_generator_small_launch_tiles(pkg, lib, tuned, golden_dir, knobs, expect):
+    """Launches of few workgroups run 32-row (FIR-up: 32- or 64-row) tiles with 32- or 64-channel K chunks; every combination against
+    the reference golden of a generator whose layers are all "small" (R = 32, 512 channels everywhere below 64x64), plus a batch
+    that is not a multiple of the two-image b4 tile"""
+    for k, v in knobs.items():
+        tuned(k, v)
+    g = np.load(os.path.join(golden_dir, "generator_r32_init.npz"))
+    r, n, seed = int(g["resolution"]), int(g["batch"]), int(g["seed"])
+    h, sd, keep = _bind(pkg, lib, r, seed, regime=str(g["regime"]))
+    x = pkg.synth.make_input(n, r, seed=seed, kind=str(g["kind"])) * np.float32(float(g["scale"]))
+    y, _ = _forward(h, x)
+    np.testing.assert_allclose(y, g["y"], rtol=0, atol=3e-5 * max(1.0, float(g["y_absmax"])))
+    kernels = " ".join(l["kernel"] for l in h.launches())
+    for e in expect:
+        assert e in kernels, (e, kernels)
+    x3 = pkg.synth.make_input(3, r, seed=seed + 1)
+    y3, _ = _forward(h, x3)
+    want = orc.generator(x3, sd, r)
+    np.testing.assert_allclose(y3, want, rtol=0, atol=3e-5 * max(1.0, float(np.abs(want).max())))
 
 
 # ------------------------------------------------------------------------------------------------ two sub-batches

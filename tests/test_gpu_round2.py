@@ -25,7 +25,8 @@ def dev():
 def tuned(pkg):
     lib = pkg.load_library()
     changed = {}
-    defaults = dict(kc16=0, kc16_minw=3, w3=3, wide=3, nt256=1, persist_min=8192, persist_grid=512, streams=2, stagger=-1)
+    defaults = dict(kc16=0, kc16_minw=3, w3=3, wide=3, nt256=1, persist_min=8192, persist_grid=512, streams=2, stagger=-1,
+                    small=1, small_max_wgs=512, small_kc=64, small_up32=1)
 
     def set_(key, value):
         changed[key] = True
@@ -174,6 +175,43 @@ def test_generator_512_with_kc16_tiles(pkg, dev, tuned):
         y = m(torch.from_numpy(x).to(dev)).cpu()
     assert ", 16, " in " ".join(l["kernel"] for l in m.launch_info())
     assert float((y - torc.generator(x, sd, res)).abs().max()) <= TOL
+
+
+# ------------------------------------------------------------------------------------------------ small-launch tiles, batch-1 latency path
+@pytest.mark.parametrize("knobs,expect", [
+    (dict(small=0), "<0, 128, 128, 32, false, 9, 2, false"),
+    (dict(small_kc=32, small_up32=0), "<2, 64, 128, 32, false, 4, 2"),
+    (dict(small_kc=64, small_up32=0), "<2, 64, 128, 64, false, 7, 2"),
+    (dict(small_kc=32), "<2, 32, 128, 32, false, 2, 2"),
+    (dict(), "<0, 32, 128, 64, false, 5, 2"),
+], ids=["regular", "kc32", "kc64", "kc32_up32", "default"])
+def test_generator_512_batch1_small_launch_tiles(pkg, dev, tuned, knobs, expect):
+    """batch 1 at 512x512 (how scripts/demo.py:122-134 calls the model): every layer from 4x4 to 64x64 runs the small-launch tiles;
+    parity against the torch-CPU port within the north star's tolerance, for every tile / chunk combination"""
+    for k, v in knobs.items():
+        tuned(k, v)
+    res, seed = 512, 33
+    m, sd = _model(pkg, res, seed, dev)
+    x = pkg.synth.make_input(1, res, seed=seed, kind="demo")
+    with torch.no_grad():
+        y = m(torch.from_numpy(x).to(dev)).cpu()
+    assert expect in " ".join(l["kernel"] for l in m.launch_info())
+    assert float((y - torc.generator(x, sd, res)).abs().max()) <= TOL
+
+
+def test_small_launch_tiles_do_not_change_results_across_batch_sizes(pkg, dev):
+    """which tile a layer runs on depends on the launch size; an image must not: image 0 of a batch-1, batch-3 and batch-32 forward"""
+    res, seed = 256, 34
+    m, sd = _model(pkg, res, seed, dev)
+    x = torch.from_numpy(pkg.synth.make_input(32, res, seed=seed, kind="demo")).to(dev)
+    with torch.no_grad():
+        y32 = m(x).cpu()
+        y3 = m(x[:3].contiguous()).cpu()
+        y1 = m(x[:1].contiguous()).cpu()
+    ref = torc.generator(x[:3].cpu().numpy(), sd, res)
+    assert float((y3 - ref).abs().max()) <= TOL
+    # different tiles sum the same K in the same order per output element: bit-identical
+    assert torch.equal(y1[0], y3[0]) and torch.equal(y3, y32[:3])
 
 
 # ------------------------------------------------------------------------------------------------ sub-batches on two streams
