@@ -93,7 +93,7 @@ struct Tuning {
                                // per CU, 164 VGPRs) and the plain / ToRGB layers with Cin = 64, whose two K chunks unroll at compile time
                                // (135 VGPRs instead of 184; synthesis.b512.conv2 1.34 -> 1.07 ms).  The FIR-up tile (4 chunks) needs 60 bytes
                                // of scratch at that budget and loses 10 %: profiles/r02_w3_and_persistence_sweep.txt
-  int small = 1;               // f16x2 / fp32 storage: plain and pointwise launches of at most small_max_wgs 32-row tiles use them
+  int small = 1;               // launches of at most small_max_wgs small tiles use them (default GEMM variant of the storage format)
   int small_max_wgs = 512;     // (MIGAN_GEOMETRIES_SMALL; single-image latency and the <= 16x16 layers)
   int small_kc = 64;           // K chunk of those tiles: 32 or 64 channels (batch 1: 0.85 ms with 32, 0.81 ms with 64)
   int small_up32 = 1;          // FIR-up layers: try the 32-row tile before the 64-row one
@@ -124,6 +124,9 @@ inline Tuning& tuning() {
 
 // Tile geometry for a layer whose GEMM runs on an h_in x w_in pixel grid.  Square power-of-two sizes (the reference's
 // fixed resolutions) get the tuned geometries; any other size (migan_forward_hw) gets 8x16 tiles with ragged edges.
+// the small-launch tiles are instantiated for the default GEMM variant of each storage format (migan_k_slice.inc)
+inline bool has_small_tiles(int gemmv, int stv) { return stv == 0 ? gemmv == 2 : gemmv == 3; }
+
 // small: the 32-row variant of a plain / pointwise layer for launches of few workgroups (MIGAN_GEOMETRIES_SMALL): 4x8-pixel tiles, or two
 // 4x4 images per tile; never wide, never with a fused ToRGB tail.
 inline Geo choose_geo(int mode, int cin, int cout, int h_in, int w_in, bool fromrgb, bool with_torgb = false, int gemmv = -1, int stv = 0,
@@ -197,7 +200,7 @@ inline Geo choose_geo(int mode, int cin, int cout, int h_in, int w_in, bool from
   MIGAN_CHECK(IMGS * GH * GW == g.MT, MIGAN_EINVAL, "internal: tile geometry does not fill the GEMM tile");
   const int QC = g.KC / 4;
   if (small) {
-    MIGAN_CHECK(g.gemmv == 2 && stv == 0 && cout % 128 == 0 && !fromrgb && (mode == MODE_UP || (h_in % 4 == 0 && w_in % GW == 0)), MIGAN_EINVAL,
+    MIGAN_CHECK(has_small_tiles(g.gemmv, stv) && cout % 128 == 0 && !fromrgb && (mode == MODE_UP || (h_in % 4 == 0 && w_in % GW == 0)), MIGAN_EINVAL,
                 "internal: no small-launch variant of this layer");
     if (tuning().small_kc == 64 && cin % 64 == 0) g.KC = 64;
   }
@@ -744,7 +747,7 @@ inline void migan_handle::build_plan(migan::Plan& P, int H, int W) const {
     L.g = choose_geo(mode, cin, cout, L.hin, L.win, fromrgb, with_torgb, gemm, stv);
     L.g.torgb = with_torgb && L.g.nchunks == 1;        // one workgroup owns all channels of its pixels: ToRGB fuses
     L.kernel = kernel_name(L.g);
-    if (tuning().small && gemm == 2 && stv == 0 && !fromrgb && !L.g.torgb && cout % 128 == 0 &&
+    if (tuning().small && has_small_tiles(gemm, stv) && !fromrgb && !L.g.torgb && cout % 128 == 0 &&
         (mode == MODE_UP || (L.hin % 4 == 0 && L.win % (L.hin == 4 && L.win == 4 ? 4 : 8) == 0))) {
       if (mode == MODE_UP && tuning().small_up32) L.g_small.push_back(choose_geo(mode, cin, cout, L.hin, L.win, false, false, gemm, stv, 2));
       L.g_small.push_back(choose_geo(mode, cin, cout, L.hin, L.win, false, false, gemm, stv, 1));
