@@ -191,7 +191,8 @@ typedef struct migan_sepconv_desc {
   const void* noise_strength; /* scalar (device) */
   const void* fromrgb_weight; /* [cin][4][1][1] or null: x = act(fromrgb(x)) first (reference :193-196) */
   const void* fromrgb_bias;   /* [cin] */
-  const void* torgb_weight;   /* [3][cout][1][1] or null: also produce img (reference :308-313) */
+  const void* torgb_weight;   /* [3][cout][1][1] or null: also produce img (reference :308-313); fused into the epilogue when one
+                                 workgroup owns all of cout, else a second launch on y */
   const void* torgb_bias;     /* [3] */
   const void* img_prev;       /* planar [batch][3][res_out/2][res_out/2] or null */
   void* img_out;              /* planar [batch][3][res_out][res_out] */

@@ -1394,19 +1394,30 @@ int migan_sepconv_forward(const migan_sepconv_desc* d, void* stream) {
     sa.src[0] = (const float*)d->conv2_weight; sa.dst_off[0] = kSplitHeader; sa.count[0] = (unsigned)(d->cin * d->cout); sa.ci[0] = (unsigned)d->cin; sa.n = 1;
     launch_split(sa, (rt::stream_t)stream);
   }
-  MIGAN_CHECK(d->torgb_weight == nullptr || (g.nchunks == 1 && mode != MODE_UP && d->img_out), MIGAN_EINVAL,
-              "fused ToRGB needs cout <= 128 (or 256 on whole 8x16 tiles), up == 1 and img_out");
+  MIGAN_CHECK(d->torgb_weight == nullptr || (mode != MODE_UP && d->img_out && d->torgb_bias), MIGAN_EINVAL, "ToRGB needs up == 1, torgb_bias and img_out");
+  // one workgroup owns all output channels of its pixels (cout <= 128, or 256 on whole 8x16 tiles): ToRGB fuses into the epilogue;
+  // otherwise torgb_kernel runs on y afterwards, as in the generator plan
+  const bool fuse_rgb = d->torgb_weight != nullptr && g.nchunks == 1;
   SepArgs a{};
   a.x = gemm_in; a.y = d->y; a.skip = d->skip;
   a.wdw = (const float*)d->conv1_weight; a.bdw = (const float*)d->conv1_bias; a.wpw = (const float*)d->conv2_weight;
   a.wsplit = gemmv ? (const unsigned short*)d->wsplit + kSplitHeader : nullptr;
   a.noise = (const float*)d->noise_const; a.noise_strength = (const float*)d->noise_strength;
   a.frgb_w = (const float*)d->fromrgb_weight; a.frgb_b = (const float*)d->fromrgb_bias;
-  a.trgb_w = (const float*)d->torgb_weight; a.trgb_b = (const float*)d->torgb_bias;
-  a.img_prev = (const float*)d->img_prev; a.img_out = (float*)d->img_out;
+  if (fuse_rgb) {
+    a.trgb_w = (const float*)d->torgb_weight; a.trgb_b = (const float*)d->torgb_bias;
+    a.img_prev = (const float*)d->img_prev; a.img_out = (float*)d->img_out;
+  }
   a.B = d->batch; a.H = gemm_h; a.W = gemm_w; a.CI = d->cin; a.CO = d->cout; a.HO = h_out; a.WO = w_out;
   fill_geo(a, g);
   launch_sepconv(g, a, (rt::stream_t)stream);
+  if (d->torgb_weight != nullptr && !fuse_rgb) {
+    RgbArgs r{};
+    r.x = d->y; r.w = (const float*)d->torgb_weight; r.b = (const float*)d->torgb_bias;
+    r.img_prev = (const float*)d->img_prev; r.img_out = (float*)d->img_out;
+    r.B = d->batch; r.H = h_out; r.W = w_out; r.C = d->cout;
+    launch_torgb(r, (rt::stream_t)stream, stv);
+  }
   MIGAN_API_END
 }
 

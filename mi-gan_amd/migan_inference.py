@@ -33,8 +33,8 @@ _NODE_KIND = {
 
 
 class _Node(nn.Module):
-    """Parameter container mirroring one reference sub-module (names only; the
-    arithmetic of the whole tree happens in Generator.forward on the GPU)."""
+    """Parameter container mirroring one reference leaf module (fromrgb / torgb / conv1 / conv2 ``nn.Conv2d``, ``Downsample2d``,
+    ``Upsample2d``): names and parameters only.  Their arithmetic is fused into the SeparableConv2d kernels."""
 
     def __init__(self, kind: str = "Module"):
         super().__init__()
@@ -45,8 +45,146 @@ class _Node(nn.Module):
 
     def forward(self, *args, **kwargs):
         raise NotImplementedError(
-            f"{self._kind}: only Generator.forward is implemented on the MI355X HIP path; "
-            "sub-modules hold the reference-named parameters")
+            f"{self._kind}: this leaf is fused into the SeparableConv2d kernels on the MI355X HIP path and cannot be called on its "
+            "own; call the SeparableConv2d / block / Encoder / Synthesis / Generator that contains it")
+
+
+def _dev_check(t: torch.Tensor, what: str) -> None:
+    if not t.is_cuda:
+        raise RuntimeError(f"{what}: needs a tensor on an MI355X (HIP) device; there is no CPU path")
+    if t.dtype != torch.float32:
+        raise RuntimeError(f"{what}: Input type ({t.dtype}) and weight type (torch.float32) should be the same")
+
+
+class _SepConv(_Node):
+    """``SeparableConv2d`` (reference :106-170) as a callable sub-module: depthwise 3x3 + bias + lrelu_agc, [Downsample2d |
+    Upsample2d], pointwise 1x1, + noise, lrelu_agc -- one ``migan_sepconv_forward`` call (include/migan_hip.h) on NHWC copies of the
+    NCHW arguments.  The fused Generator.forward does not go through here; this is the reference's module-level API."""
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        return self._run(x)[0]
+
+    def _run(self, x, skip=None, fromrgb=None, torgb=None, img_prev=None):
+        _dev_check(x, "SeparableConv2d")
+        lib = load_library()
+        dw, pw = self.conv1, self.conv2                     # the depthwise and pointwise nn.Conv2d of the reference (:122-136)
+        cin, cout = int(dw.weight.shape[0]), int(pw.weight.shape[0])
+        down = 2 if getattr(self, "downsample", None) is not None else 1
+        up = 2 if getattr(self, "upsample", None) is not None else 1
+        n = int(x.shape[0])
+        if fromrgb is not None:
+            if x.dim() != 4 or x.shape[1] != 4:
+                raise RuntimeError(f"expected the 4-channel network input [N, 4, H, W], got {list(x.shape)}")
+            xin = x.contiguous()                                # NCHW: FromRGB reads the planes
+        else:
+            if x.dim() != 4 or x.shape[1] != cin:
+                raise RuntimeError(f"Given groups={cin}, expected input[N, {cin}, H, W], got {list(x.shape)}")
+            xin = x.permute(0, 2, 3, 1).contiguous()            # NHWC
+        h, w = int(x.shape[2]), int(x.shape[3])
+        if down == 2 and (h % 2 or w % 2):
+            raise RuntimeError("Downsample2d needs even sizes")
+        ho, wo = (h // 2, w // 2) if down == 2 else ((h * 2, w * 2) if up == 2 else (h, w))
+        y = torch.empty((n, ho, wo, cout), dtype=torch.float32, device=x.device)
+        kw = dict(x=xin.data_ptr(), y=y.data_ptr(), conv1_weight=dw.weight.data_ptr(), conv1_bias=dw.bias.data_ptr(),
+                  conv2_weight=pw.weight.data_ptr(), batch=n, cin=cin, cout=cout, res_in=h, width_in=w, down=down, up=up)
+        keep = [xin]
+        if getattr(self, "use_noise", False):
+            nc = self.noise_const
+            if tuple(nc.shape) != (ho, wo):
+                raise RuntimeError(f"The size of noise_const {list(nc.shape)} must match the output size [{ho}, {wo}] (reference :166)")
+            kw.update(noise_const=nc.data_ptr(), noise_strength=self.noise_strength.data_ptr())
+        if skip is not None:
+            _dev_check(skip, "SeparableConv2d skip")
+            if tuple(skip.shape) != (n, cout, ho, wo):
+                raise RuntimeError(f"The size of tensor a {[n, cout, ho, wo]} must match the size of tensor b {list(skip.shape)}")
+            sk = skip.permute(0, 2, 3, 1).contiguous()
+            keep.append(sk)
+            kw.update(skip=sk.data_ptr())
+        if fromrgb is not None:
+            kw.update(fromrgb_weight=fromrgb.weight.data_ptr(), fromrgb_bias=fromrgb.bias.data_ptr())
+        img_out = None
+        if torgb is not None:
+            img_out = torch.empty((n, 3, ho, wo), dtype=torch.float32, device=x.device)
+            kw.update(torgb_weight=torgb.weight.data_ptr(), torgb_bias=torgb.bias.data_ptr(), img_out=img_out.data_ptr())
+            if img_prev is not None:
+                _dev_check(img_prev, "SynthesisBlock img")
+                if tuple(img_prev.shape) != (n, 3, ho // 2, wo // 2):
+                    raise RuntimeError(f"expected img [N, 3, {ho // 2}, {wo // 2}], got {list(img_prev.shape)}")
+                ip = img_prev.contiguous()
+                keep.append(ip)
+                kw.update(img_prev=ip.data_ptr())
+        if down == 2:
+            scratch = torch.empty((n * ho * wo * cin,), dtype=torch.float32, device=x.device)
+            keep.append(scratch)
+            kw.update(scratch=scratch.data_ptr(), scratch_bytes=scratch.numel() * 4)
+        wsplit = torch.empty((16 + 6 * cout * cin + 16,), dtype=torch.uint8, device=x.device)
+        keep.append(wsplit)
+        kw.update(wsplit=wsplit.data_ptr(), wsplit_bytes=wsplit.numel())
+        with torch.cuda.device(x.device):
+            lib.sepconv_forward(stream=int(torch.cuda.current_stream(x.device).cuda_stream), **kw)
+        for t in keep:                                           # the launches are asynchronous: tie the temporaries to the stream
+            t.record_stream(torch.cuda.current_stream(x.device))
+        return y.permute(0, 3, 1, 2).contiguous(), img_out
+
+
+class _EncoderBlock(_Node):
+    """``EncoderBlock.forward(x, img)`` (reference :192-200) -> (x, feat)"""
+
+    def forward(self, x, img):
+        if self.fromrgb is not None:
+            if x is not None:
+                raise NotImplementedError("EncoderBlock with fromrgb: the HIP path fuses FromRGB into conv1 and takes x = None "
+                                          "(the only way the reference's Encoder calls it, :236-241)")
+            feat = self.conv1._run(img, fromrgb=self.fromrgb)[0]
+        else:
+            feat = self.conv1(x)
+        return self.conv2(feat), feat
+
+
+class _Encoder(_Node):
+    """``Encoder.forward(img)`` (reference :235-246) -> (x, feats)"""
+
+    def forward(self, img):
+        x, feats = None, {}
+        blocks = sorted(((int(n[1:]), m) for n, m in self.named_children()), reverse=True)
+        for res, block in blocks:
+            x, feat = block(x, img)
+            feats[res] = feat
+        return x, feats
+
+
+class _SynthesisBlock(_Node):
+    """``SynthesisBlockFirst.forward(x, enc_feat)`` (:271-280) / ``SynthesisBlock.forward(x, enc_feat, img)`` (:302-315) -> (x, img)"""
+
+    def forward(self, x, enc_feat, img=None):
+        x = self.conv1._run(x, skip=enc_feat)[0]                 # x = conv1(x); x = x + enc_feat
+        if getattr(self, "torgb", None) is None:
+            raise NotImplementedError("SynthesisBlock without torgb is not part of the inference generator")
+        return self.conv2._run(x, torgb=self.torgb, img_prev=img)     # img = upsample(img) + torgb(x)
+
+
+class _Synthesis(_Node):
+    """``Synthesis.forward(x, enc_feats)`` (reference :347-352) -> img"""
+
+    def forward(self, x, enc_feats):
+        img = None
+        for res, block in sorted((int(n[1:]), m) for n, m in self.named_children()):
+            x, img = block(x, enc_feats[res]) if res == 4 else block(x, enc_feats[res], img)
+        return img
+
+
+def _make_node(parts) -> nn.Module:
+    """the node class of module path `parts` (without the parameter name)"""
+    depth, name = len(parts), parts[-1]
+    if depth == 1:
+        return _Encoder("Encoder") if name == "encoder" else _Synthesis("Synthesis")
+    if depth == 2:
+        if parts[0] == "encoder":
+            return _EncoderBlock("EncoderBlock")
+        return _SynthesisBlock("SynthesisBlockFirst" if name == "b4" else "SynthesisBlock")
+    if depth == 3 and name in ("conv1", "conv2"):
+        return _SepConv("SeparableConv2d")
+    return _Node("Conv2d" if name in ("conv1", "conv2") else _NODE_KIND.get(name, "Module"))
 
 
 def _init_tensor(e: schema.Entry) -> torch.Tensor:
@@ -98,10 +236,9 @@ class Generator(nn.Module):
         for e in schema.entries(resolution):
             node: nn.Module = self
             parts = e.name.split(".")
-            for p in parts[:-1]:
+            for depth, p in enumerate(parts[:-1]):
                 if not hasattr(node, p):
-                    kind = _NODE_KIND.get(p, "EncoderBlock" if parts[0] == "encoder" else "SynthesisBlock")
-                    node.add_module(p, _Node(kind))
+                    node.add_module(p, _make_node(parts[:depth + 1]))
                 node = getattr(node, p)
             t = _init_tensor(e)
             if e.kind == "param":

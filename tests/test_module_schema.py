@@ -76,8 +76,13 @@ def test_no_cpu_fallback(pkg):
         m(torch.zeros(1, 4, 16, 16))
     with pytest.raises(RuntimeError):
         m(torch.zeros(1, 3, 16, 16))          # wrong channel count is still a shape error
-    with pytest.raises(NotImplementedError):
-        m.encoder(torch.zeros(1, 4, 16, 16))  # sub-modules only hold parameters
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        m.encoder(torch.zeros(1, 4, 16, 16))  # sub-modules are callable on the GPU (tests/test_gpu_submodules.py), and only there
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        m.synthesis.b8.conv1(torch.zeros(1, 512, 4, 4))
+    with pytest.raises(NotImplementedError, match="fused into"):
+        m.synthesis.b8.torgb(torch.zeros(1, 512, 8, 8))     # leaf modules (fromrgb / torgb / the two nn.Conv2d of a SeparableConv2d /
+                                                            # Downsample2d / Upsample2d) hold parameters only
 
 
 def test_missing_library_fails_loudly(pkg, tmp_path, monkeypatch):
