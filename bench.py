@@ -483,10 +483,10 @@ def run_workload(args, rank, local_rank, world, dist, dev):
                     "f16x2": "fp16x2-split MFMA, fp32 accumulate",
                     "f16": "fp16 MFMA on fp16-rounded operands, fp32 accumulate"}.get(wl["gemm"], wl["gemm"]) + \
                    "; depthwise 3x3, FIR, activations, epilogues in fp32 VALU"
-    if name == "migan" and world == 1 and not args.no_latency and args.io == "f32" and not getattr(args, "is_secondary", False):
+    if name == "migan" and world == 1 and not args.no_latency and args.io == "f32":
         try:
             lat, y1, x1 = latency_batch1(wl["model"], pkg, res, dev)
-            if args.cpu_images > 0:
+            if args.cpu_images > 0 and not getattr(args, "is_secondary", False):      # (the secondary lines report the time only)
                 from oracle import migan_torch_cpu as torc
                 sd1 = pkg.synth.make_state_dict(res, seed=0, regime="export")
                 ref1 = torc.generator(x1, sd1, res, storage=None if args.dtype == "f32" else args.dtype)

@@ -64,7 +64,7 @@ int comodgan_assume_static_weights(comodgan_handle* h, int on);
                                     comodgan_noise_floats() floats per image in total */
 int comodgan_noise_floats(const comodgan_handle* h, size_t* floats_per_image);
 
-/* Generator.forward(x, z, c=None, truncation_psi, truncation_cutoff=None, noise_mode) (comodgan.py:435-455).
+/* Generator.forward(x, z, c=None, truncation_psi, truncation_cutoff (comodgan_set_truncation_cutoff), noise_mode) (comodgan.py:435-455).
  * x: [batch,4,R,R] = cat([mask-0.5, img*mask]) (scripts/demo.py:56-66); z: [batch,z_dim]; y: [batch,3,R,R]. */
 int comodgan_forward(comodgan_handle* h, const void* x_nchw, const void* z, void* y_nchw, int batch,
                      float truncation_psi, int noise_mode, const void* noise,
@@ -78,6 +78,11 @@ int comodgan_forward_timed(comodgan_handle* h, const void* x_nchw, const void* z
                            float truncation_psi, int noise_mode, const void* noise,
                            void* workspace, size_t workspace_bytes, void* stream, float* launch_ms, int n_launch_ms);
 /* keep_intermediates != 0: every layer output keeps its own workspace region. */
+/* truncation_cutoff of Generator.forward / MappingNetwork.forward (comodgan.py:435,446; stylegan.py:403,432-437): with
+ * truncation_psi != 1 only the first `cutoff` rows of ws are pulled towards w_avg; the layers that read later rows (comodgan.py:399-405:
+ * b4.conv 0, b4.torgb 1, then conv0 / conv1 / torgb of block j at 1+2j, 2+2j, 3+2j) get the un-truncated w.  -1 = None (all rows).
+ * Changes comodgan_workspace_bytes. */
+int comodgan_set_truncation_cutoff(comodgan_handle* h, int cutoff);
 int comodgan_set_debug(comodgan_handle* h, int keep_intermediates);
 /* After a forward with keep_intermediates: NHWC [batch][r][r][c] for "encoder.bR.conv0|conv1", "encoder.b4.conv",
  * "synthesis.b4.conv", "synthesis.bR.conv0|conv1"; planar [batch][3][r][r] for "synthesis.bR.img";

@@ -131,6 +131,7 @@ int migan_forward_u8(migan_handle* h, const void* img_hwc_u8, const void* mask_u
 /* ---- the deployed pipeline around the generator (second half) ----
  * reference scripts/create_onnx_pipeline.py::MIGAN_Pipeline (:118-264), the module the reference exports as
  * migan_pipeline_v2.onnx: any-size uint8 image [3][H][W] (CHW) + mask [H][W] (255 = known pixel), batch 1.
+ *   migan_pipeline_mask_resize  the nearest resize of the mask to the image's size (:256), when their sizes differ
  *   migan_pipeline_bbox   get_masked_bbox (:132-231): bbox = {x_min, x_max, y_min, y_max} of the masked region, padded
  *                         and grown to at least resolution x resolution, clipped to the image.  Row / column flags are
  *                         reduced on the device; the call synchronises `stream` to read them (the crop size decides the
@@ -144,6 +145,10 @@ int migan_forward_u8(migan_handle* h, const void* img_hwc_u8, const void* mask_u
  *                         gauss25: the module's 5x5 weight buffer (host pointer), or NULL for kernel_size=5, sigma=1.
  * `scratch` is migan_pipeline_scratch_bytes(H, W) bytes of device memory, shared by the three calls.  Results: bbox and
  * the uint8 resize are exact; fp32 sums may associate differently from ATen's (<= 1 uint8 step in the result). */
+/* tvF.resize(mask, image size, NEAREST), the first line of MIGAN_Pipeline.forward (:256): only needed when the mask does not
+ * already have the image's size.  out [height][width] uint8. */
+int migan_pipeline_mask_resize(const void* mask_u8, int mask_height, int mask_width, void* out_u8, int height, int width,
+                               void* stream);
 int migan_pipeline_scratch_bytes(int height, int width, size_t* bytes);
 int migan_pipeline_bbox(const void* mask_u8, int height, int width, int resolution, int padding, void* scratch,
                         int bbox[4], void* stream);

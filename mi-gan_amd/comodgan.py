@@ -136,6 +136,7 @@ class Generator(nn.Module):
         self._ws: Optional[torch.Tensor] = None
         self._frozen = False         # freeze_weights(): the caller's promise that parameters no longer change in place
         self._refreeze = True        # the handle has not been told yet
+        self._cutoff: Optional[int] = None   # truncation_cutoff the handle was last told
         self.register_load_state_dict_post_hook(lambda module, incompatible: module._invalidate())
 
     # ------------------------------------------------------------------ plumbing
@@ -179,6 +180,7 @@ class Generator(nn.Module):
             self._handle_device = dev
             self._bound = None
             self._refreeze = True
+            self._cutoff = None
         tensors = self._tensors()
         ptrs = tuple(t.data_ptr() for t in tensors)
         if self._dirty or ptrs != self._bound:
@@ -206,8 +208,11 @@ class Generator(nn.Module):
                 noise_mode: str = "random", return_intermediate_outs: bool = False, _timed: bool = False):
         """Args: x: 4 channel rgb+mask [N,4,R,R] (comodgan.py:437-441); z: [N,z_dim] (drawn with torch.randn when None, :438-439)."""
         assert noise_mode in ["random", "const", "none"]         # stylegan.py:280
-        if c is not None or truncation_cutoff is not None or return_intermediate_outs:
-            raise NotImplementedError("c, truncation_cutoff and return_intermediate_outs are not part of the MI355X inference path")
+        if c is not None or return_intermediate_outs:
+            raise NotImplementedError("c (class conditioning: c_dim = 0 in every published config) and return_intermediate_outs (a training-"
+                                      "loss hook) are not part of the MI355X inference path")
+        if truncation_cutoff is not None and (int(truncation_cutoff) != truncation_cutoff or truncation_cutoff < 0):
+            raise ValueError(f"truncation_cutoff must be a non-negative integer or None, got {truncation_cutoff!r}")
         r = self.img_resolution
         if x.dim() != 4 or x.shape[1] != 4 or x.shape[2] != r or x.shape[3] != r:
             raise RuntimeError(f"expected input of shape [N, 4, {r}, {r}] (mask-0.5, img*mask), got {list(x.shape)}")
@@ -226,6 +231,10 @@ class Generator(nn.Module):
         noise = None
         if noise_mode == "random":
             noise = torch.randn(n * h.noise_floats(), dtype=torch.float32, device=x.device)    # stylegan.py:284-285, all layers at once
+        cutoff = None if truncation_cutoff is None else int(truncation_cutoff)
+        if cutoff != self._cutoff:                               # (part of the workspace layout: set before sizing it)
+            h.set_truncation_cutoff(cutoff)
+            self._cutoff = cutoff
         ws = self._workspace(h, n, x.device)
         # freeze_weights(): the fp16 operand planes / demodulation statistics of the 3x3 weights at the head of the workspace
         # are prepared once and reused (the library re-prepares them by itself after a re-binding, on another workspace or

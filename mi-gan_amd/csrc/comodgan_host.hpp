@@ -90,6 +90,7 @@ struct comodgan_handle {
   std::vector<rt::event_t> events;
   int planned_batch = 0;
   size_t planned_need = 0;       // workspace bytes of planned_batch (0 = not planned)
+  int trunc_cutoff = -1;       // comodgan_set_truncation_cutoff: -1 = None (every row of ws truncated), else rows [0, cutoff)
   // comodgan_assume_static_weights: skip the per-forward weight preparation while nothing it depends on has changed
   bool static_weights = false;
   const void* prepared_ws = nullptr;
@@ -291,12 +292,13 @@ inline size_t comodgan_handle::walk(int batch, const float* x, const float* z, f
 
   // ---------------------------------------------------------------- helpers for the layers
   auto dense = [&](const std::string& layer, const float* xin, const float* xin2, int K, int K1, const std::string& wname, int O,
-                   float* out, float lr_multi, bool act, bool norm, int in_c, int out_c, const float* add, const float* lerp0) {
+                   float* out, float lr_multi, bool act, bool norm, int in_c, int out_c, const float* add, const float* lerp0,
+                   float* out_raw = nullptr) {
     // (the kernel's NHWC-bottleneck path walks channels x 16 positions of ONE input tensor)
     MIGAN_CHECK(in_c == 0 || (K == 16 * in_c && K1 == K && xin2 == nullptr), MIGAN_EINVAL, "internal: bottleneck dense layer must read one [N][16][C] tensor");
     CmDenseArgs a{};
     a.x = xin; a.x2 = xin2; a.w = dry ? nullptr : W(wname + ".weight"); a.b = dry ? nullptr : W(wname + ".bias");
-    a.add = add; a.lerp0 = lerp0; a.y = out;
+    a.add = add; a.lerp0 = lerp0; a.y = out; a.y_raw = lerp0 ? out_raw : nullptr;
     a.wgain = lr_multi / std::sqrt((float)K); a.bgain = lr_multi; a.psi = psi;
     a.N = B; a.K = K; a.K1 = K1; a.O = O; a.act = act; a.norm = norm; a.in_c = in_c; a.out_c = out_c;
     emit(layer, "migan::cm_dense_kernel", 2.0 * K * O, 0, 4.0 * ((double)K * O / B + K + O), cm_dense_kernel, a, (unsigned)cdiv(O, 8), 0);
@@ -404,6 +406,10 @@ inline size_t comodgan_handle::walk(int batch, const float* x, const float* z, f
   float* m0 = alloc((size_t)B * cfg.w_dim * 4);
   float* m1 = alloc((size_t)B * cfg.w_dim * 4);
   float* wlat = alloc((size_t)B * cfg.w_dim * 4);
+  // truncation_cutoff (stylegan.py:436-437): only ws[:, :cutoff] are pulled towards w_avg; the layers reading later rows get the raw w
+  // (the buffer is part of the workspace whenever a cutoff is set, whatever psi a forward passes: the planned size must not depend on it)
+  float* wraw = trunc_cutoff >= 0 ? alloc((size_t)B * cfg.w_dim * 4) : nullptr;
+  const bool cut = psi != 1.0f && trunc_cutoff >= 0;
   // The mapping network depends on z only and its eight launches are latency-bound (27 us each, 64 workgroups): they run on the
   // handle's own stream while the caller's stream goes on with the encoder; the affine layers (first reader of w) wait for it.
   // Ordering is by events only.  Timed / debug walks keep everything on the caller's stream.
@@ -426,7 +432,7 @@ inline size_t comodgan_handle::walk(int batch, const float* x, const float* z, f
       float* out = last ? wlat : ((i & 1) ? m1 : m0);
       dense("mapping.fc" + std::to_string(i), cur, nullptr, i == 0 ? cfg.z_dim : cfg.w_dim, i == 0 ? cfg.z_dim : cfg.w_dim,
             "mapping.fc" + std::to_string(i), cfg.w_dim, out, 0.01f, true, i == 0, 0, 0, nullptr,
-            (last && psi != 1.0f) ? (dry ? nullptr : W("mapping.w_avg")) : nullptr);
+            (last && psi != 1.0f) ? (dry ? nullptr : W("mapping.w_avg")) : nullptr, (last && cut) ? wraw : nullptr);
       cur = out;
     }
     reg_debug("mapping", wlat, {B, cfg.w_dim});
@@ -481,16 +487,18 @@ inline size_t comodgan_handle::walk(int batch, const float* x, const float* z, f
   const int wl = cfg.w_dim + cfg.w0_dim;
   size_t noise_off = 0;                     // floats per image into the caller's random-noise blob
   // every affine layer (styles = affine(cat([w, w0])), stylegan.py:282,337) in one launch, ahead of the synthesis blocks
-  struct Affine { std::string name; int c; float* styles; };
+  struct Affine { std::string name; int c; float* styles; int widx; };   // widx: the row of ws the layer reads (comodgan.py:399-405)
   std::vector<Affine> affines;
   {
-    auto add_aff = [&](const std::string& p, int c) { affines.push_back({p, c, alloc((size_t)B * c * 4)}); };
-    add_aff("synthesis.b4.conv", channels(4));
-    add_aff("synthesis.b4.torgb", channels(4));
+    auto add_aff = [&](const std::string& p, int c, int widx) { affines.push_back({p, c, alloc((size_t)B * c * 4), widx}); };
+    add_aff("synthesis.b4.conv", channels(4), 0);
+    add_aff("synthesis.b4.torgb", channels(4), 1);
+    int widx = 1;
     for (int res = 8; res <= R; res *= 2) {
-      add_aff(bname("synthesis", res) + ".conv0", channels(res / 2));
-      add_aff(bname("synthesis", res) + ".conv1", channels(res));
-      add_aff(bname("synthesis", res) + ".torgb", channels(res));
+      add_aff(bname("synthesis", res) + ".conv0", channels(res / 2), widx);
+      add_aff(bname("synthesis", res) + ".conv1", channels(res), widx + 1);
+      add_aff(bname("synthesis", res) + ".torgb", channels(res), widx + 2);
+      widx += 2;
     }
     MIGAN_CHECK((int)affines.size() <= kCmMaxAffine, MIGAN_EINVAL, "internal: too many affine layers");
     CmDenseMultiArgs a{};
@@ -500,12 +508,13 @@ inline size_t comodgan_handle::walk(int batch, const float* x, const float* z, f
       a.w[a.njobs] = dry ? nullptr : W(af.name + ".affine.weight");
       a.b[a.njobs] = dry ? nullptr : W(af.name + ".affine.bias");
       a.y[a.njobs] = af.styles; a.O[a.njobs] = af.c; a.blk0[a.njobs] = blk;
+      if (cut && af.widx >= trunc_cutoff) a.alt_mask |= 1ull << a.njobs;
       blk += cdiv(af.c, 8);
       fl += 2.0 * wl * af.c;
       ++a.njobs;
     }
     a.blk0[a.njobs] = blk;
-    a.x = wlat; a.x2 = w0; a.wgain = 1.0f / std::sqrt((float)wl); a.N = B; a.K = wl; a.K1 = cfg.w_dim;
+    a.x = wlat; a.x_alt = wraw; a.x2 = w0; a.wgain = 1.0f / std::sqrt((float)wl); a.N = B; a.K = wl; a.K1 = cfg.w_dim;
     if (side) rt_check(rt::stream_wait_event(stream, ev_map), "hipStreamWaitEvent");     // w from the mapping stream
     emit("synthesis.affine", "migan::cm_dense_multi_kernel", fl, 0, 2.0 * fl / B, cm_dense_multi_kernel, a, (unsigned)blk, 0);
   }
@@ -839,6 +848,17 @@ int comodgan_launch_info(const comodgan_handle* h, int index, const char** layer
   if (flops) *flops = L.flops;
   if (mfma_flops) *mfma_flops = L.mfma_flops;
   if (bytes) *bytes = L.bytes;
+  MIGAN_API_END
+}
+
+int comodgan_set_truncation_cutoff(comodgan_handle* h, int cutoff) {
+  MIGAN_API_BEGIN
+  MIGAN_CHECK(h, MIGAN_EINVAL, "null handle");
+  MIGAN_CHECK(cutoff >= -1, MIGAN_EINVAL, "truncation_cutoff must be >= 0, or -1 for None");
+  if (h->trunc_cutoff != cutoff) {
+    h->trunc_cutoff = cutoff;
+    h->planned_need = 0;                   // (one more [batch][w_dim] buffer in the workspace walk)
+  }
   MIGAN_API_END
 }
 

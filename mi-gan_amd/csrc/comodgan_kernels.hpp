@@ -616,6 +616,7 @@ struct CmDenseArgs {
   const float* add;    // or null
   const float* lerp0;  // w_avg [O] or null
   float* y;            // [N][O]
+  float* y_raw;        // with lerp0: also the value before the truncation lerp (the ws rows beyond truncation_cutoff), or null
   float wgain, bgain, psi;
   int N, K, K1, O;
   int act, norm, in_c, out_c;
@@ -695,6 +696,7 @@ MIGAN_DEVICE MIGAN_INLINE void cm_dense_block(const CmDenseArgs& p, int block) {
         const int oi = p.out_c ? (o & 15) * p.out_c + (o >> 4) : o;
         if (p.add) v += p.add[(size_t)n * p.O + oi];
         if (p.lerp0) {
+          if (p.y_raw) p.y_raw[(size_t)n * p.O + oi] = v;
           const float s = p.lerp0[o];
           v = (p.psi < 0.5f) ? s + p.psi * (v - s) : v - (v - s) * (1.0f - p.psi);     // torch.lerp
         }
@@ -717,6 +719,8 @@ struct CmDenseMultiArgs {
   int blk0[kCmMaxAffine + 1];     // first workgroup of each job
   const float* x;
   const float* x2;
+  const float* x_alt;             // truncation_cutoff: the un-truncated w, read by the jobs whose bit is set in alt_mask (stylegan.py:436-437)
+  unsigned long long alt_mask;
   float wgain;
   int N, K, K1, njobs;
 };
@@ -724,7 +728,7 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, 2) cm_dense_multi_kernel(const CmDens
   int j = 0;
   while (j + 1 < p.njobs && (int)blockIdx.x >= p.blk0[j + 1]) ++j;
   CmDenseArgs a{};
-  a.x = p.x; a.x2 = p.x2; a.w = p.w[j]; a.b = p.b[j]; a.y = p.y[j];
+  a.x = ((p.alt_mask >> j) & 1ull) ? p.x_alt : p.x; a.x2 = p.x2; a.w = p.w[j]; a.b = p.b[j]; a.y = p.y[j];
   a.wgain = p.wgain; a.bgain = 1.0f; a.psi = 1.0f; a.N = p.N; a.K = p.K; a.K1 = p.K1; a.O = p.O[j];
   cm_dense_block(a, (int)blockIdx.x - p.blk0[j]);
 }

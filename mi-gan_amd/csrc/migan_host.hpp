@@ -1468,6 +1468,17 @@ int migan_pipeline_scratch_bytes(int height, int width, size_t* bytes) {
   *bytes = migan::align256((size_t)(height + width) * sizeof(int)) + migan::align256((size_t)height * width);
   MIGAN_API_END
 }
+// tvF.resize(mask, (H, W), NEAREST) (:256): a mask of another size is brought to the image's size first
+int migan_pipeline_mask_resize(const void* mask_u8, int mask_height, int mask_width, void* out_u8, int height, int width, void* stream) {
+  MIGAN_API_BEGIN
+  using namespace migan;
+  MIGAN_CHECK(mask_u8 && out_u8 && mask_height > 0 && mask_width > 0 && height > 0 && width > 0 &&
+              (unsigned long long)height * width < (1ull << 30), MIGAN_EINVAL, "bad argument");
+  PipeArgs a{};
+  a.mask = (const unsigned char*)mask_u8; a.pooled = (unsigned char*)out_u8; a.H = height; a.W = width; a.y_max = mask_height; a.x_max = mask_width;
+  rt_check(rt::launch(pipe_mask_resize_kernel, a, (unsigned)cdiv(height * width, kThreads), kThreads, 0, (rt::stream_t)stream), "migan::pipe_mask_resize_kernel");
+  MIGAN_API_END
+}
 // get_masked_bbox (:132-231).  The per-row / per-column "contains a pixel below 255" flags are computed on the device, copied to
 // the host (this call synchronises `stream`), and the box arithmetic -- a dozen integer min/max, the reference's own order -- runs here.
 int migan_pipeline_bbox(const void* mask_u8, int height, int width, int resolution, int padding, void* scratch, int bbox[4], void* stream) {

@@ -56,6 +56,18 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, 2) pipe_flags_kernel(const PipeArgs p
   }
 }
 
+// MIGAN_Pipeline.forward's first line (:256): tvF.resize(mask, image size, NEAREST) = F.interpolate(mode="nearest").
+// args: mask = source [y_max][x_max] (its height / width ride in y_max / x_max), pooled = destination [H][W]
+MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, 2) pipe_mask_resize_kernel(const PipeArgs p) {
+  const int i = (int)(blockIdx.x * kThreads + threadIdx.x);
+  if (i >= p.H * p.W) return;
+  const int oy = i / p.W, ox = i % p.W, ih = p.y_max, iw = p.x_max;
+  int sy = (int)floorf((float)oy * ((float)ih / (float)p.H)), sx = (int)floorf((float)ox * ((float)iw / (float)p.W));
+  sy = sy < ih - 1 ? sy : ih - 1;
+  sx = sx < iw - 1 ? sx : iw - 1;
+  p.pooled[i] = p.mask[(size_t)sy * iw + sx];
+}
+
 // preprocess (:233-239) of the crop [y_min, y_max) x [x_min, x_max): bilinear resize of the uint8 image (rounded back to uint8 as
 // torchvision does), nearest resize of the mask, x = cat([mask / 255 - 0.5, (image * 2 / 255 - 1) * mask / 255])
 MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, 2) pipe_pre_kernel(const PipeArgs p) {

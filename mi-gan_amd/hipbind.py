@@ -67,13 +67,13 @@ EXPORTS = (
     "migan_num_launches", "migan_launch_info",
     "migan_forward_timed", "migan_set_debug", "migan_debug_tensor", "migan_sepconv_forward",
     "migan_pack_input", "migan_compose_output",
-    "migan_pipeline_scratch_bytes", "migan_pipeline_bbox", "migan_pipeline_pre", "migan_pipeline_post",
+    "migan_pipeline_mask_resize", "migan_pipeline_scratch_bytes", "migan_pipeline_bbox", "migan_pipeline_pre", "migan_pipeline_post",
     "migan_set_tuning", "migan_last_error", "migan_backend", "migan_gemm_variant", "migan_version",
     # include/comodgan_hip.h
     "comodgan_create", "comodgan_destroy", "comodgan_num_weights", "comodgan_weight_info", "comodgan_set_weight",
     "comodgan_commit", "comodgan_workspace_bytes", "comodgan_assume_static_weights", "comodgan_noise_floats", "comodgan_forward",
     "comodgan_num_launches",
-    "comodgan_launch_info", "comodgan_forward_timed", "comodgan_set_debug", "comodgan_debug_tensor",
+    "comodgan_launch_info", "comodgan_forward_timed", "comodgan_set_debug", "comodgan_debug_tensor", "comodgan_set_truncation_cutoff",
 )
 
 
@@ -116,6 +116,7 @@ class MiganLib:
         L.migan_workspace_bytes_hw.argtypes = [vp, ci, ci, ci, C.POINTER(C.c_size_t)]
         L.migan_forward_hw.argtypes = [vp, vp, vp, ci, ci, ci, vp, C.c_size_t, vp]
         L.migan_forward_u8.argtypes = [vp, vp, vp, vp, ci, vp, C.c_size_t, vp]
+        L.migan_pipeline_mask_resize.argtypes = [vp, ci, ci, vp, ci, ci, vp]
         L.migan_pipeline_scratch_bytes.argtypes = [ci, ci, C.POINTER(C.c_size_t)]
         L.migan_pipeline_bbox.argtypes = [vp, ci, ci, ci, ci, vp, C.POINTER(ci), vp]
         L.migan_pipeline_pre.argtypes = [vp, vp, ci, ci, C.POINTER(ci), ci, vp, vp]
@@ -152,6 +153,7 @@ class MiganLib:
         L.comodgan_launch_info.argtypes = [vp, ci, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.POINTER(C.c_double),
                                            C.POINTER(C.c_double), C.POINTER(C.c_double)]
         L.comodgan_set_debug.argtypes = [vp, ci]
+        L.comodgan_set_truncation_cutoff.argtypes = [vp, ci]
         L.comodgan_debug_tensor.argtypes = [vp, ci, C.c_char_p, C.POINTER(C.c_size_t), C.POINTER(C.c_int64), C.POINTER(ci)]
         L.migan_last_error.restype = C.c_char_p
         L.migan_backend.restype = C.c_char_p
@@ -196,6 +198,10 @@ class MiganLib:
                                                  C.c_void_p(out_ptr), int(batch), int(resolution), C.c_void_p(stream)))
 
     # the deployed pipeline (include/migan_hip.h, reference scripts/create_onnx_pipeline.py:118-264)
+    def pipeline_mask_resize(self, mask_ptr: int, mask_height: int, mask_width: int, out_ptr: int, height: int, width: int, stream: int = 0) -> None:
+        self.check(self.lib.migan_pipeline_mask_resize(C.c_void_p(mask_ptr), int(mask_height), int(mask_width), C.c_void_p(out_ptr),
+                                                       int(height), int(width), C.c_void_p(stream)))
+
     def pipeline_scratch_bytes(self, height: int, width: int) -> int:
         n = C.c_size_t()
         self.check(self.lib.migan_pipeline_scratch_bytes(int(height), int(width), C.byref(n)))
@@ -424,6 +430,10 @@ class CoModGANHandle:
             out.append(dict(layer=layer.value.decode(), kernel=kern.value.decode(), flops=fl.value, mfma_flops=mf.value,
                             bytes=by.value))
         return out
+
+    def set_truncation_cutoff(self, cutoff: Optional[int]) -> None:
+        """None: truncation_psi applies to every row of ws; n: to rows [0, n) only (stylegan.py:432-437)"""
+        self.lib.check(self.lib.lib.comodgan_set_truncation_cutoff(self._h, -1 if cutoff is None else int(cutoff)))
 
     def set_debug(self, keep: bool) -> None:
         self.lib.check(self.lib.lib.comodgan_set_debug(self._h, 1 if keep else 0))

@@ -52,8 +52,8 @@ class MIGAN_Pipeline(torch.nn.Module):
 
       image (1, 3, H, W) uint8, mask (1, 1, H, W) uint8 (255 = known pixel); the image is modified in place and returned.
 
-    ``model_path`` is a reference ``migan_*.pt`` state dict, or an already built ``mi-gan_amd`` Generator.  The mask must already
-    have the image's size (the reference's first line resizes it).  No CPU path."""
+    ``model_path`` is a reference ``migan_*.pt`` state dict, or an already built ``mi-gan_amd`` Generator.  A mask of another size is
+    resized to the image's size first (nearest), like the reference's first line (:256).  No CPU path."""
 
     def __init__(self, model_path, resolution: int, padding: int = 128, device="cuda"):
         super().__init__()
@@ -97,11 +97,15 @@ class MIGAN_Pipeline(torch.nn.Module):
         if image.dim() != 4 or image.shape[0] != 1 or image.shape[1] != 3 or not image.is_contiguous():
             raise RuntimeError(f"expected a contiguous image (1, 3, H, W), got {list(image.shape)}")
         h, w = int(image.shape[2]), int(image.shape[3])
-        if tuple(mask.shape) != (1, 1, h, w):
-            raise RuntimeError(f"expected mask (1, 1, {h}, {w}), got {list(mask.shape)}")
+        if mask.dim() != 4 or mask.shape[0] != 1 or mask.shape[1] != 1:
+            raise RuntimeError(f"expected mask (1, 1, h, w), got {list(mask.shape)}")
         mask = mask.contiguous()
         lib = load_library()
         stream = int(torch.cuda.current_stream(image.device).cuda_stream)
+        if tuple(mask.shape[2:]) != (h, w):                      # mask = tvF.resize(mask, image size, NEAREST) (:256)
+            resized = torch.empty((1, 1, h, w), dtype=torch.uint8, device=image.device)
+            lib.pipeline_mask_resize(mask.data_ptr(), int(mask.shape[2]), int(mask.shape[3]), resized.data_ptr(), h, w, stream)
+            mask = resized
         scratch = self._scratch_for(lib, h, w, image.device)
         bbox = lib.pipeline_bbox(mask.data_ptr(), h, w, self.res, self.padding, scratch.data_ptr(), stream)
         x = torch.empty((1, 4, self.res, self.res), dtype=torch.float32, device=image.device)

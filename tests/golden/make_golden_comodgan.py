@@ -36,7 +36,7 @@ from lib.model_zoo.comodgan import Mapping, Encoder, Synthesis, Generator  # noq
 
 torch.set_num_threads(max(1, os.cpu_count() or 1))
 
-# (tag, resolution, ch_base, ch_max, batch, seed, truncation_psi)
+# (tag, resolution, ch_base, ch_max, batch, seed, truncation_psi[, truncation_cutoff])
 CASES = [
     ("r16_c64", 16, 1024, 64, 2, 1, 1.0),
     ("r32_c128", 32, 4096, 128, 3, 2, 1.0),
@@ -45,6 +45,7 @@ CASES = [
     ("r64_std", 64, 32768, 512, 1, 5, 1.0),       # the real channel rule (512 everywhere at <= 64)
     ("r256_small", 256, 16384, 256, 1, 6, 1.0),   # the 64..256-channel range at the big resolutions
     ("r512_std", 512, 32768, 512, 1, 7, 1.0),     # comodgan-512 as scripts/demo.py:101-106 builds it (BASELINE configs[4] geometry)
+    ("r32_c128_cut3", 32, 4096, 128, 2, 8, 0.6, 3),   # truncation_cutoff: ws rows 0-2 truncated, 3-7 raw (round 3)
 ]
 
 
@@ -75,8 +76,14 @@ def schema_json():
 
 
 def main():
-    schema_json()
-    for tag, r, cb, cm, n, seed, psi in CASES:
+    only = sys.argv[sys.argv.index("--only") + 1] if "--only" in sys.argv else None      # regenerate one case, leave the others untouched
+    if only is None:
+        schema_json()
+    for case in CASES:
+        tag, r, cb, cm, n, seed, psi = case[:7]
+        cutoff = case[7] if len(case) > 7 else None
+        if only is not None and tag != only:
+            continue
         cfg = cs.Config(resolution=r, ch_base=cb, ch_max=cm, num_ws=cs.default_num_ws(r))
         sd = synth.make_comodgan_state_dict(cfg, seed)
         g = build(cfg)
@@ -93,11 +100,11 @@ def main():
                             taps[f"{name}/{j}"] = tap_summary(t)
                 hooks.append(mod.register_forward_hook(hook))
         with torch.no_grad():
-            y = g(torch.from_numpy(x), z=torch.from_numpy(z), truncation_psi=psi, noise_mode="const")
+            y = g(torch.from_numpy(x), z=torch.from_numpy(z), truncation_psi=psi, truncation_cutoff=cutoff, noise_mode="const")
         for h in hooks:
             h.remove()
         out = {"y": y.numpy().astype(np.float32), "cfg": np.asarray([r, cb, cm, n, seed], dtype=np.int64),
-               "psi": np.asarray(psi)}
+               "psi": np.asarray(psi), "cutoff": np.asarray(-1 if cutoff is None else cutoff)}
         out.update({"tap:" + k: v for k, v in taps.items()})
         np.savez_compressed(os.path.join(HERE, f"comodgan_{tag}.npz"), **out)
         print(tag, "y", y.shape, "absmax %.3f" % y.abs().max().item(), "taps", len(taps))

@@ -24,7 +24,8 @@ def load_case(tag):
     sd = pkg.synth.make_comodgan_state_dict(cfg, seed)
     x = pkg.synth.make_input(n, r, seed)
     z = pkg.synth.make_latent(n, cfg.z_dim, seed)
-    return g, cfg, sd, x, z, float(g["psi"])
+    cutoff = int(g["cutoff"]) if "cutoff" in g.files and int(g["cutoff"]) >= 0 else None      # (goldens before round 3 have no cutoff)
+    return g, cfg, sd, x, z, (float(g["psi"]), cutoff)
 
 
 def tap_summary(a):
@@ -45,9 +46,9 @@ def test_schema_matches_reference_constructors():
 
 @pytest.mark.parametrize("tag", CASES)
 def test_oracle_reproduces_reference_outputs(tag):
-    g, cfg, sd, x, z, psi = load_case(tag)
+    g, cfg, sd, x, z, (psi, cutoff) = load_case(tag)
     taps = {}
-    y = orc.generator(x, z, sd, cfg.resolution, cfg.num_ws, truncation_psi=psi, taps=taps)
+    y = orc.generator(x, z, sd, cfg.resolution, cfg.num_ws, truncation_psi=psi, truncation_cutoff=cutoff, taps=taps)
     ref = g["y"]
     scale = np.abs(ref).max()
     assert np.abs(y - ref).max() <= 3e-5 * scale, (np.abs(y - ref).max(), scale)

@@ -16,7 +16,7 @@ hb = pkg.hipbind
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 
 
-def run_emu(cfg, sd, x, z, psi=1.0, noise_mode="const", noise=None, debug=()):
+def run_emu(cfg, sd, x, z, psi=1.0, noise_mode="const", noise=None, debug=(), cutoff=None):
     lib = emu_lib()
     h = hb.CoModGANHandle(lib, cfg.resolution, cfg.num_ws, cfg.ch_base, cfg.ch_max, cfg.z_dim, cfg.w_dim, cfg.w0_dim, cfg.map_layers)
     keep = {k: aligned(v) for k, v in sd.items()}
@@ -26,6 +26,8 @@ def run_emu(cfg, sd, x, z, psi=1.0, noise_mode="const", noise=None, debug=()):
     h.commit()
     if debug:
         h.set_debug(True)
+    if cutoff is not None:
+        h.set_truncation_cutoff(cutoff)
     n = x.shape[0]
     nbytes = h.workspace_bytes(n)
     ws = np.zeros(nbytes // 4 + 64, dtype=np.float32)
@@ -92,6 +94,22 @@ def test_generator_matches_reference_golden(tag):
     assert ("migan::cm_conv_kernel<128, 32, 6, true, 2, false>" if "c128" in tag else "migan::cm_conv_kernel<64, 32, 6, true, 2, false>") in kernels
     # synthesis conv0: all four transposed-convolution phases in one launch on 64-column tiles (two waves per SIMD)
     assert "migan::cm_conv_kernel<64, 32, 6, true, 2, true>" in kernels
+
+
+def test_truncation_cutoff_matches_reference_golden():
+    """truncation_psi = 0.6 on ws[:, :3] only (stylegan.py:436-437): b4.conv / b4.torgb+b8.conv0 / b8.conv1 see the truncated w, every
+    later layer the raw one; against the reference module's own output, and cutoff >= num_ws == no cutoff"""
+    g, cfg, sd, x, z = case("r32_c128_cut3")
+    assert int(g["cutoff"]) == 3
+    y, _, _ = run_emu(cfg, sd, x, z, psi=float(g["psi"]), cutoff=3)
+    assert np.abs(y - g["y"]).max() <= 1e-3, np.abs(y - g["y"]).max()
+    y_all, _, _ = run_emu(cfg, sd, x, z, psi=float(g["psi"]))
+    assert np.abs(y_all - g["y"]).max() > 1e-2                      # the cutoff matters for this case
+    y_big, _, _ = run_emu(cfg, sd, x, z, psi=float(g["psi"]), cutoff=cfg.num_ws)
+    np.testing.assert_array_equal(y_big, y_all)
+    y_zero, _, _ = run_emu(cfg, sd, x, z, psi=float(g["psi"]), cutoff=0)
+    y_one, _, _ = run_emu(cfg, sd, x, z, psi=1.0)
+    np.testing.assert_array_equal(y_zero, y_one)                    # nothing truncated == psi 1
 
 
 def test_other_forms_of_the_transposed_convolution(monkeypatch):

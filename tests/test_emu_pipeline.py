@@ -86,6 +86,18 @@ def test_full_mask_and_no_hole(pkg):
         assert np.abs(got.astype(np.int32) - want.astype(np.int32)).max() <= 1
 
 
+def test_mask_of_another_size_is_resized_like_torchvision_nearest(pkg):
+    """MIGAN_Pipeline.forward's first line (:256): tvF.resize(mask, image size, NEAREST) -- against the oracle's torchvision restatement"""
+    lib = emu_lib()
+    rng = np.random.default_rng(8)
+    for (ih, iw), (h, w) in (((37, 53), (96, 80)), ((128, 128), (50, 70)), ((64, 48), (64, 48))):
+        m = np.ascontiguousarray((rng.random((ih, iw)) > 0.4).astype(np.uint8) * 255)
+        out = np.zeros((h, w), dtype=np.uint8)
+        lib.pipeline_mask_resize(ptr(m), ih, iw, ptr(out), h, w)
+        want = po.tv_resize(torch.from_numpy(m)[None, None], (h, w), "nearest")[0, 0].numpy()
+        np.testing.assert_array_equal(out, want)
+
+
 def test_pipeline_argument_errors(pkg):
     lib = emu_lib()
     mask = np.zeros((32, 32), dtype=np.uint8)

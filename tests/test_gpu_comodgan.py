@@ -45,8 +45,13 @@ def test_reference_golden_outputs(pkg, dev, golden_dir, tag):
     m, _ = _build(pkg, cfg, seed, dev)
     x = torch.from_numpy(pkg.synth.make_input(n, r, seed)).to(dev)
     z = torch.from_numpy(pkg.synth.make_latent(n, cfg.z_dim, seed)).to(dev)
+    cutoff = int(g["cutoff"]) if "cutoff" in g.files and int(g["cutoff"]) >= 0 else None
     with torch.no_grad():
-        y = m(x, z=z, truncation_psi=float(g["psi"]), noise_mode="const")
+        y = m(x, z=z, truncation_psi=float(g["psi"]), truncation_cutoff=cutoff, noise_mode="const")
+        if cutoff is not None:                                                 # switching the cutoff on one module re-plans the workspace
+            y_all = m(x, z=z, truncation_psi=float(g["psi"]), noise_mode="const")
+            assert float((y - y_all).abs().max()) > 1e-2
+            assert torch.equal(m(x, z=z, truncation_psi=float(g["psi"]), truncation_cutoff=cutoff, noise_mode="const"), y)
     err = float(np.abs(y.cpu().numpy() - g["y"]).max())
     assert np.isfinite(err) and err <= TOL, (tag, err, float(np.abs(g["y"]).max()))
     assert m._lib.backend() == "hip:gfx950"
@@ -115,7 +120,11 @@ def test_module_errors_on_gpu(pkg, dev):
     with pytest.raises(RuntimeError):
         m(torch.zeros(1, 4, 16, 16, device=dev), z=torch.zeros(2, 512, device=dev))
     with pytest.raises(NotImplementedError):
-        m(torch.zeros(1, 4, 16, 16, device=dev), truncation_cutoff=4)
+        m(torch.zeros(1, 4, 16, 16, device=dev), return_intermediate_outs=True)
+    with pytest.raises(NotImplementedError):
+        m(torch.zeros(1, 4, 16, 16, device=dev), c=torch.zeros(1, 0, device=dev))
+    with pytest.raises(ValueError):
+        m(torch.zeros(1, 4, 16, 16, device=dev), truncation_cutoff=-2)
 
 
 def test_in_place_weight_updates_are_seen_and_frozen_weights_are_reused(pkg, dev):

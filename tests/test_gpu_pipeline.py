@@ -86,6 +86,21 @@ def test_postprocess_alone_is_exact_against_the_oracle(pkg):
     assert diff.max() <= 1 and (diff > 0).mean() <= 1e-4, f"{diff.max()} {(diff > 0).mean():.2e}"
 
 
+def test_pipeline_resizes_a_mask_of_another_size(pkg):
+    """MIGAN_Pipeline.forward(image, mask) with a half-size mask == forward with the mask resized by torch's nearest interpolation (:256)"""
+    dev = torch.device("cuda:0")
+    g = np.load(CASES[0])
+    res, seed, padding = int(g["resolution"]), int(g["seed"]), int(g["padding"])
+    pipe = _pipeline(pkg, res, seed, padding, dev)
+    image = torch.from_numpy(np.array(g["image"], copy=True))[None].to(dev)
+    h, w = image.shape[2:]
+    small = torch.from_numpy(np.ascontiguousarray(g["mask"][:, ::2, ::2]))[None].to(dev)
+    full = po.tv_resize(small.cpu(), (h, w), "nearest").to(dev)
+    a = pipe(image.clone(), small)
+    b = pipe(image.clone(), full)
+    assert torch.equal(a, b)
+
+
 def test_pipeline_rejects_cpu_tensors(pkg):
     pipe = _pipeline(pkg, 64, 1, 8, torch.device("cuda:0"))
     with pytest.raises(RuntimeError, match="no CPU path"):
