@@ -97,6 +97,8 @@ struct Tuning {
   int small_max_wgs = 512;     // (MIGAN_GEOMETRIES_SMALL; single-image latency and the <= 16x16 layers)
   int small_kc = 64;           // K chunk of those tiles: 32 or 64 channels (batch 1: 0.85 ms with 32, 0.81 ms with 64)
   int small_up32 = 1;          // FIR-up layers: try the 32-row tile before the 64-row one
+  int small_dwfir = 1;         // dwfir_kernel: small launches walk fewer channel chunks per workgroup (more workgroups)
+  int small_ksplit = 1;        // single-image forwards: 32 x 32 tiles whose four waves split the K steps (a quarter of the weight panel per workgroup)
   int streams = 2;             // MIGAN_STREAMS=1|2: default of migan_set_streams
   int stagger = -1;            // MIGAN_STAGGER: launch index of the first half after which the second half starts (-1: plan default)
   int debug_split = 0;         // diagnostics: keep the two-sub-batch execution in keep-intermediates mode
@@ -130,7 +132,7 @@ inline bool has_small_tiles(int gemmv, int stv) { return stv == 0 ? gemmv == 2 :
 // small: the 32-row variant of a plain / pointwise layer for launches of few workgroups (MIGAN_GEOMETRIES_SMALL): 4x8-pixel tiles, or two
 // 4x4 images per tile; never wide, never with a fused ToRGB tail.
 inline Geo choose_geo(int mode, int cin, int cout, int h_in, int w_in, bool fromrgb, bool with_torgb = false, int gemmv = -1, int stv = 0,
-                      int small = 0) {   // 0 regular | 1 small | 2 (FIR-up only) the 32-row tile
+                      int small = 0) {   // 0 regular | 1 small | 2 (FIR-up only) the 32-row tile | 3 the 32 x 32 K-split tile
   Geo g;
   g.gemmv = gemmv < 0 ? tuning().gemm : gemmv;
   g.stv = stv;
@@ -182,7 +184,7 @@ inline Geo choose_geo(int mode, int cin, int cout, int h_in, int w_in, bool from
   } else {
     MIGAN_CHECK(!fromrgb, MIGAN_EINVAL, "fromrgb is only fused into plain layers");
     g.MT = 128; g.KC = 32;
-    if (small == 2) { g.MT = 32; g.NT = 128; GH = 4; GW = 8; IMGS = 1; }   // 4x8 grid of GEMM pixels, 2x6 interior
+    if (small >= 2) { g.MT = 32; g.NT = 128; GH = 4; GW = 8; IMGS = 1; }   // 4x8 grid of GEMM pixels, 2x6 interior
     else if (small) { g.MT = 64; g.NT = 128; GH = 8; GW = 8; IMGS = 1; }   // 8x8 grid, 6x6 interior
     else if (sq2 && h_in < 8) { GH = 8; GW = 8; IMGS = 2; }
     else { GH = 8; GW = 16; IMGS = 1; }
@@ -198,12 +200,16 @@ inline Geo choose_geo(int mode, int cin, int cout, int h_in, int w_in, bool from
     if (tuning().kc16 & bit) { g.KC = 16; g.MINW = tuning().kc16_minw; }
   }
   MIGAN_CHECK(IMGS * GH * GW == g.MT, MIGAN_EINVAL, "internal: tile geometry does not fill the GEMM tile");
-  const int QC = g.KC / 4;
   if (small) {
     MIGAN_CHECK(has_small_tiles(g.gemmv, stv) && cout % 128 == 0 && !fromrgb && (mode == MODE_UP || (h_in % 4 == 0 && w_in % GW == 0)), MIGAN_EINVAL,
                 "internal: no small-launch variant of this layer");
     if (tuning().small_kc == 64 && cin % 64 == 0) g.KC = 64;
+    if (small == 3) {                              // 32 x 32 tiles, the waves split the K steps of a 64-channel chunk
+      MIGAN_CHECK(g.KC == 64 && g.MT == 32 && cout % 32 == 0, MIGAN_EINVAL, "internal: no K-split tile for this layer");
+      g.NT = 32; g.nchunks = cout / 32;
+    }
   }
+  const int QC = g.KC / 4;
   const int segh = g.MT >= 128 ? 4 : 2;          // output rows per depthwise strip (the kernel's SEGH)
   const int rs = (g.MT == 32 || (g.MT == 64 && small)) ? GH / segh : (GH / 4 > 0 ? GH / 4 : 1);   // (RS * SEGH = GH)
   g.lgRS = ilog2(rs);
@@ -232,7 +238,8 @@ inline Geo choose_geo(int mode, int cin, int cout, int h_in, int w_in, bool from
   const int npl = g.gemmv == 3 ? 1 : (g.gemmv == 2 ? 2 : 3);
   const int asz = g.gemmv ? npl * g.MT * (g.KC * 2) / 4 : g.MT * AS;
   const int bsz = g.gemmv ? npl * g.NT * (g.KC * 2) / 4 : g.NT * AS;
-  const int gs = g.MT * (GS + 4);   // accumulator tile (row pitch NT+4, NT+8 with the fused ToRGB tail); the ToRGB partial sums reuse its slots
+  const int gs = g.MT * (GS + 4) * (g.NT == 32 ? 4 : 1);   // accumulator tile (row pitch NT+4, NT+8 with the fused ToRGB tail); the ToRGB partial
+                                                         // sums reuse its slots; K-split tiles: one partial tile per wave
   const size_t limit = (size_t)(160 * 1024 / g.MINW);
   if (mode == MODE_PW) {
     // A and B operands double buffered: one barrier per K chunk
@@ -489,7 +496,12 @@ inline void launch_dwfir(const DwGeo& g, DwFirArgs a, rt::stream_t stream, int s
   a.lgGH = g.lgGH; a.lgGW = g.lgGW; a.lgIMGS = g.lgIMGS;
   a.tiles_x = g.tiles_x; a.tiles_y = g.tiles_y; a.nkg = g.nkg; a.kpw = g.kpw;
   a.off_d = g.off_d; a.off_w = g.off_w;
-  rt_check(rt::launch(dwfir_fn(g.maing, stv), a, dwfir_grid(g, a.B), kThreads, g.lds_bytes, stream), dwfir_name(g, stv));
+  // small launches (single-image latency, the <= 16x16 layers): fewer 16-channel chunks per workgroup, more workgroups, as long as
+  // the launch stays within the small-launch threshold (same reasoning as MIGAN_GEOMETRIES_SMALL)
+  unsigned grid = dwfir_grid(g, a.B);
+  if (tuning().small && tuning().small_dwfir)
+    while (a.kpw > 1 && grid * 2 <= (unsigned)tuning().small_max_wgs) { a.kpw /= 2; a.nkg *= 2; grid *= 2; }
+  rt_check(rt::launch(dwfir_fn(g.maing, stv), a, grid, kThreads, g.lds_bytes, stream), dwfir_name(g, stv));
 }
 
 // 16-bit elements one tensor occupies in a weight-split buffer: header + planes, rounded to 16 bytes
@@ -749,6 +761,8 @@ inline void migan_handle::build_plan(migan::Plan& P, int H, int W) const {
     L.kernel = kernel_name(L.g);
     if (tuning().small && has_small_tiles(gemm, stv) && !fromrgb && !L.g.torgb && cout % 128 == 0 &&
         (mode == MODE_UP || (L.hin % 4 == 0 && L.win % (L.hin == 4 && L.win == 4 ? 4 : 8) == 0))) {
+      if (tuning().small_ksplit && tuning().small_kc == 64 && cin % 64 == 0)
+        L.g_small.push_back(choose_geo(mode, cin, cout, L.hin, L.win, false, false, gemm, stv, 3));
       if (mode == MODE_UP && tuning().small_up32) L.g_small.push_back(choose_geo(mode, cin, cout, L.hin, L.win, false, false, gemm, stv, 2));
       L.g_small.push_back(choose_geo(mode, cin, cout, L.hin, L.win, false, false, gemm, stv, 1));
     }
@@ -955,8 +969,12 @@ inline void migan_handle::run_range(const migan::Plan& P, const float* x, float*
       a.B = n; a.H = L.hin; a.W = L.win; a.CI = L.cin; a.CO = L.cout; a.HO = L.hout; a.WO = L.wout;
       // launches that would leave most CUs idle run the 32-row tiles: a quarter of the work per workgroup, four times the workgroups
       const Geo* Gp = &L.g;
-      for (const Geo& gs : L.g_small)
+      for (const Geo& gs : L.g_small) {
+        // K-split tiles sum K in another order than every other tile (four partial sums): single-image forwards only, so that an
+        // image of a batch of two or more is bit-identical whatever the batch size and the sub-batch grouping
+        if (gs.NT == 32 && n != 1) continue;
         if ((int)tiles_of(gs, n) <= tuning().small_max_wgs) { Gp = &gs; break; }
+      }
       const Geo& G = *Gp;
       fill_geo(a, G);
       launch_sepconv(G, a, stream);
@@ -1582,6 +1600,8 @@ int migan_set_tuning(const char* key, int value) {
   else if (k == "small_max_wgs") t.small_max_wgs = value;
   else if (k == "small_kc") t.small_kc = value;
   else if (k == "small_up32") t.small_up32 = value;
+  else if (k == "small_dwfir") t.small_dwfir = value;
+  else if (k == "small_ksplit") t.small_ksplit = value;
   else if (k == "nt256") t.nt256 = value != 0;
   else if (k == "persist_min") t.persist_min = std::max(1, value);
   else if (k == "persist_grid") t.persist_grid = std::max(8, value / 8 * 8);

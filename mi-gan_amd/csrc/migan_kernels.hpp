@@ -386,9 +386,14 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, MINW) sepconv_kernel(const SepArgs p)
   constexpr int AS = KC + 4;                       // A/B row pitch (floats): odd number of 16-B slots -> conflict-free b128
   constexpr int GS = NT + 4;                       // result tile row pitch
   constexpr int QN = NT / 4;
-  constexpr int LG_QN = (QN == 64) ? 6 : ((QN == 32) ? 5 : 4);
-  static_assert(QN == 64 || QN == 32 || QN == 16, "NT must be 256, 128 or 64");
-  constexpr int WM = (MT >= 128) ? 2 : 1, WN = 4 / WM;   // wave grid over the MT x NT tile: 2x2, or 1x4 for the 64 x 256 tile
+  constexpr int LG_QN = (QN == 64) ? 6 : ((QN == 32) ? 5 : ((QN == 16) ? 4 : 3));
+  static_assert(QN == 64 || QN == 32 || QN == 16 || QN == 8, "NT must be 256, 128, 64 or 32");
+  // KSPLIT (NT == 32; the smallest launches): all four waves own the SAME 32 x 32 output tile and split the K steps of a chunk among
+  // themselves (wave w takes 16-channel step w of the 64-channel chunk); the four partial tiles are summed through LDS before the
+  // epilogue.  A quarter of the weight panel per workgroup (the 1x1 weights are what a small launch streams), four times the workgroups.
+  constexpr bool KSPLIT = (NT == 32);
+  static_assert(!KSPLIT || (MT == 32 && KC == 64 && GEMMV >= 1 && !TORGB && !PERSIST && !FROMRGB), "K-split tiles: 32 x 32, 64-channel chunks, split GEMM variants");
+  constexpr int WM = KSPLIT ? 1 : ((MT >= 128) ? 2 : 1), WN = KSPLIT ? 1 : 4 / WM;   // wave grid over the MT x NT tile: 2x2, or 1x4 for the 64 x 256 tile
   constexpr int WROWS = MT / WM, WCOLS = NT / WN;  // per-wave tile
   constexpr int MTI = WROWS / 32, NTI = WCOLS / 32;
   static_assert(MTI >= 1 && NTI >= 1, "wave tile must be at least 32x32");
@@ -426,7 +431,7 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, MINW) sepconv_kernel(const SepArgs p)
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
-  const int wm = wave / WN, wn = wave % WN;
+  const int wm = KSPLIT ? 0 : wave / WN, wn = KSPLIT ? 0 : wave % WN;
   const int l31 = lane & 31, half = lane >> 5;
   PROF_BEGIN();
 
@@ -817,7 +822,8 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, MINW) sepconv_kernel(const SepArgs p)
       const char* ab = reinterpret_cast<const char*>(a_s + (MODE == MODE_PW ? (c & 1) * p.a_stride : 0));
       const char* bb = reinterpret_cast<const char*>(bcur);
 #pragma unroll
-      for (int ks = 0; ks < KC / 16; ++ks) {
+      for (int ks0 = 0; ks0 < (KSPLIT ? 1 : KC / 16); ++ks0) {
+        const int ks = KSPLIT ? wave : ks0;          // K-split tiles: this wave's 16-channel step of the chunk
         f4 av[MTI][NPL], bv[NTI][NPL];
 #pragma unroll
         for (int i = 0; i < MTI; ++i) {
@@ -837,7 +843,7 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, MINW) sepconv_kernel(const SepArgs p)
         for (int i = 0; i < MTI; ++i)
 #pragma unroll
           for (int j = 0; j < NTI; ++j) {
-            if (ZEROC && c == 0 && ks == 0) acc[i][j] = f16v{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // (folds into the first product's C operand)
+            if (ZEROC && c == 0 && ks0 == 0) acc[i][j] = f16v{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // (folds into the first product's C operand)
             if constexpr (X1) {
               acc[i][j] = MIGAN_MFMA_F16_32X32X16(av[i][0], bv[j][0], acc[i][j]);
             } else if constexpr (F16) {
@@ -885,7 +891,7 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, MINW) sepconv_kernel(const SepArgs p)
   int tide = tid;
   MIGAN_OPAQUE(tide);
   const int lanee = tide & 63, wavee = tide >> 6;
-  const int wme = wavee / WN, wne = wavee % WN, l31e = lanee & 31, halfe = lanee >> 5;
+  const int wme = KSPLIT ? 0 : wavee / WN, wne = KSPLIT ? 0 : wavee % WN, l31e = lanee & 31, halfe = lanee >> 5;
   __syncthreads();                       // all waves done with a_s/b_s before g_s overwrites them
   // F16: 1 / (activation scale * weight scale), a power of two written next to the weight planes by weight_absmax_kernel
   // The scale is applied where the epilogue touches each value anyway: folded into the noise add (one FMA) or,
@@ -912,16 +918,23 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, MINW) sepconv_kernel(const SepArgs p)
           const int ly = gy0 + gy, lx = gx0 + gx;
           if (ly < 0 || ly >= p.H || lx < 0 || lx >= p.W) v = 0.0f;
         }
-        g_s[row * GS + col] = v;
+        g_s[(KSPLIT ? wavee * MT * GS : 0) + row * GS + col] = v;          // K-split: one partial tile per wave
       }
   __syncthreads();
+  if constexpr (KSPLIT) {
+    // sum the four partial tiles into the first (one float4 per thread: 32 rows x 8 quads), fixed order
+    const int c4r = tide & (QN - 1), mr = tide >> LG_QN;
+    float* gp = g_s + mr * GS + c4r * 4;
+    st4(gp, (ld4(gp) + ld4(gp + MT * GS)) + (ld4(gp + 2 * MT * GS) + ld4(gp + 3 * MT * GS)));
+    __syncthreads();
+  }
   PROF_MARK(4);
 
   const bool has_noise = gnoise != nullptr;
   const float ns = has_noise ? p.noise_strength[0] : 0.0f;
   constexpr int ITEMS = MT * QN / kThreads;          // epilogue items per thread
-  constexpr int UB = 4;                              // items whose global loads are issued together
-  static_assert(ITEMS % UB == 0, "epilogue batches must divide the per-thread items");
+  constexpr int UB = ITEMS < 4 ? ITEMS : 4;          // items whose global loads are issued together
+  static_assert(ITEMS >= 1 && ITEMS % UB == 0, "epilogue batches must divide the per-thread items");
   // Items of a thread are GEMM rows m0 + k*STEP (k = 0..ITEMS-1), always the same 4 channels.  With
   // the main geometry the pixel offset of item k is a compile-time function of k, so every global
   // address is (uniform pointer advanced per item in SGPRs) + (one 32-bit lane offset computed once).

@@ -76,7 +76,10 @@ struct KernelEntry {
   MIGAN_K(2, 64, 128, 32, false, 4, 2, false, false, G, false, S),                                                                 \
   MIGAN_K(0, 32, 128, 64, false, 5, 2, false, false, G, false, S), MIGAN_K(3, 32, 128, 64, false, 2, 2, false, false, G, false, S), \
   MIGAN_K(2, 64, 128, 64, false, 7, 2, false, false, G, false, S),                                                                 \
-  MIGAN_K(2, 32, 128, 32, false, 2, 2, false, false, G, false, S), MIGAN_K(2, 32, 128, 64, false, 4, 2, false, false, G, false, S)
+  MIGAN_K(2, 32, 128, 32, false, 2, 2, false, false, G, false, S), MIGAN_K(2, 32, 128, 64, false, 4, 2, false, false, G, false, S), \
+  /* 32 x 32 K-split tiles: the four waves share one output tile and split the K steps (the smallest launches) */                  \
+  MIGAN_K(0, 32, 32, 64, false, 5, 2, false, false, G, false, S), MIGAN_K(3, 32, 32, 64, false, 2, 2, false, false, G, false, S),   \
+  MIGAN_K(2, 32, 32, 64, false, 4, 2, false, false, G, false, S)
 
 struct KernelSlice {
   const KernelEntry* entries;

@@ -23,7 +23,7 @@ def tuned(lib):
     """set process-wide tuning knobs for one test, restore the defaults afterwards"""
     changed = {}
     defaults = dict(kc16=0, kc16_minw=3, w3=3, wide=3, nt256=1, persist_min=8192, persist_grid=512, streams=2, stagger=-1,
-                    small=1, small_max_wgs=512, small_kc=64, small_up32=1)
+                    small=1, small_max_wgs=512, small_kc=64, small_up32=1, small_dwfir=1, small_ksplit=1)
 
     def set_(key, value):
         changed[key] = True
@@ -230,6 +230,14 @@ def test_generator_small_launch_tiles(pkg, lib, tuned, golden_dir, knobs, expect
     y3, _ = _forward(h, x3)
     want = orc.generator(x3, sd, r)
     np.testing.assert_allclose(y3, want, rtol=0, atol=3e-5 * max(1.0, float(np.abs(want).max())))
+    assert ", 32, 32, 64, " not in " ".join(l["kernel"] for l in h.launches())       # K-split tiles: single-image forwards only
+    # a single image: the 32 x 32 K-split tiles (four waves, four partial sums) where the knobs allow them
+    y1, _ = _forward(h, x3[:1])
+    np.testing.assert_allclose(y1, want[:1], rtol=0, atol=3e-5 * max(1.0, float(np.abs(want).max())))
+    ksplit = ", 32, 32, 64, " in " ".join(l["kernel"] for l in h.launches())
+    assert ksplit == (knobs.get("small", 1) == 1 and knobs.get("small_kc", 64) == 64 and knobs.get("small_max_wgs", 512) >= 16)
+    if not ksplit:
+        np.testing.assert_array_equal(y1[0], y3[0])                                   # same summation order: bit-identical
 
 
 # ------------------------------------------------------------------------------------------------ two sub-batches

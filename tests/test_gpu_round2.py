@@ -26,7 +26,7 @@ def tuned(pkg):
     lib = pkg.load_library()
     changed = {}
     defaults = dict(kc16=0, kc16_minw=3, w3=3, wide=3, nt256=1, persist_min=8192, persist_grid=512, streams=2, stagger=-1,
-                    small=1, small_max_wgs=512, small_kc=64, small_up32=1)
+                    small=1, small_max_wgs=512, small_kc=64, small_up32=1, small_dwfir=1, small_ksplit=1)
 
     def set_(key, value):
         changed[key] = True
@@ -183,8 +183,10 @@ def test_generator_512_with_kc16_tiles(pkg, dev, tuned):
     (dict(small_kc=32, small_up32=0), "<2, 64, 128, 32, false, 4, 2"),
     (dict(small_kc=64, small_up32=0), "<2, 64, 128, 64, false, 7, 2"),
     (dict(small_kc=32), "<2, 32, 128, 32, false, 2, 2"),
-    (dict(), "<0, 32, 128, 64, false, 5, 2"),
-], ids=["regular", "kc32", "kc64", "kc32_up32", "default"])
+    (dict(small_ksplit=0), "<0, 32, 128, 64, false, 5, 2"),
+    (dict(small_dwfir=0), "<2, 32, 32, 64, false, 4, 2"),
+    (dict(), "<0, 32, 32, 64, false, 5, 2"),
+], ids=["regular", "kc32", "kc64", "kc32_up32", "no_ksplit", "no_dwfir_split", "default"])
 def test_generator_512_batch1_small_launch_tiles(pkg, dev, tuned, knobs, expect):
     """batch 1 at 512x512 (how scripts/demo.py:122-134 calls the model): every layer from 4x4 to 64x64 runs the small-launch tiles;
     parity against the torch-CPU port within the north star's tolerance, for every tile / chunk combination"""
@@ -210,8 +212,11 @@ def test_small_launch_tiles_do_not_change_results_across_batch_sizes(pkg, dev):
         y1 = m(x[:1].contiguous()).cpu()
     ref = torc.generator(x[:3].cpu().numpy(), sd, res)
     assert float((y3 - ref).abs().max()) <= TOL
-    # different tiles sum the same K in the same order per output element: bit-identical
-    assert torch.equal(y1[0], y3[0]) and torch.equal(y3, y32[:3])
+    # batches of two or more: different tiles sum the same K in the same order per output element -> bit-identical
+    assert torch.equal(y3, y32[:3])
+    # a single-image forward also runs the K-split tiles (four partial sums per output element): the same image to fp32 rounding
+    assert float((y1[0] - y3[0]).abs().max()) <= 2e-5 * max(1.0, float(ref.abs().max()))
+    assert "<0, 32, 32, 64, " in " ".join(l["kernel"] for l in m.launch_info())
 
 
 # ------------------------------------------------------------------------------------------------ sub-batches on two streams
