@@ -210,7 +210,8 @@ def test_generator_per_handle_gemm_variant(pkg, lib, tuned, gemm):
     (dict(small_kc=32), ["<2, 32, 128, 32, false, 2, 2"]),
     (dict(), ["<0, 32, 128, 64, false, 5, 2", "<2, 32, 128, 64, false, 4, 2", "<3, 32, 128, 64, false, 2, 2"]),
     (dict(small_max_wgs=6), ["<0, 128, 128, 32, false, 9, 2, false", "<0, 32, 128, 64, false, 5, 2"]),   # per launch: only the <= 6-tile launches
-], ids=["regular", "kc32", "kc64", "kc32_up32", "default", "threshold"])
+    (dict(small_dwfir=0, small_ksplit=0), ["<0, 32, 128, 64, false, 5, 2"]),                             # four channel chunks per dwfir workgroup
+], ids=["regular", "kc32", "kc64", "kc32_up32", "default", "threshold", "no_dwfir_split"])
 def test_generator_small_launch_tiles(pkg, lib, tuned, golden_dir, knobs, expect):
     """Launches of few workgroups run 32-row (FIR-up: 32- or 64-row) tiles with 32- or 64-channel K chunks; every combination against
     the reference golden of a generator whose layers are all "small" (R = 32, 512 channels everywhere below 64x64), plus a batch
@@ -235,7 +236,8 @@ def test_generator_small_launch_tiles(pkg, lib, tuned, golden_dir, knobs, expect
     y1, _ = _forward(h, x3[:1])
     np.testing.assert_allclose(y1, want[:1], rtol=0, atol=3e-5 * max(1.0, float(np.abs(want).max())))
     ksplit = ", 32, 32, 64, " in " ".join(l["kernel"] for l in h.launches())
-    assert ksplit == (knobs.get("small", 1) == 1 and knobs.get("small_kc", 64) == 64 and knobs.get("small_max_wgs", 512) >= 16)
+    assert ksplit == (knobs.get("small", 1) == 1 and knobs.get("small_kc", 64) == 64 and knobs.get("small_max_wgs", 512) >= 16
+                      and knobs.get("small_ksplit", 1) == 1)
     if not ksplit:
         np.testing.assert_array_equal(y1[0], y3[0])                                   # same summation order: bit-identical
 
