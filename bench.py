@@ -41,6 +41,7 @@ import numpy as np
 import torch
 
 PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+T_PROCESS_START = time.perf_counter()   # (after the imports above: a fresh box spends 1-2 minutes paging torch in before this)
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 / 16x16x4_f32 peak
 PEAK_BF16_MFMA_TFLOPS = 2500.0 # MI355X_MICROARCH.md: dense bf16 / fp16 MFMA peak
 # Split GEMM variants: every fp32 product costs six bf16 MFMA products ("bf16x3") or three fp16 MFMA
@@ -236,15 +237,32 @@ def reference_migan(res, sd):
         return None
 
 
-def all_cores_cpu_rate(model, cap_s=60):
-    """the CPU port on every logical core, one image, in a child process with a time limit (on the 256-thread GPU-box host one
-    migan-512 image takes longer than that: oversubscription; the 16-thread figure is the fastest measured)"""
+def physical_cores():
+    """distinct (socket, core) pairs of /proc/cpuinfo; the logical count where that cannot be read"""
+    try:
+        pairs, phys, core = set(), None, None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("physical id"):
+                phys = line.split(":")[1].strip()
+            elif line.startswith("core id"):
+                core = line.split(":")[1].strip()
+            elif not line.strip() and phys is not None:
+                pairs.add((phys, core))
+                phys = core = None
+        return len(pairs) or (os.cpu_count() or 1)
+    except OSError:
+        return os.cpu_count() or 1
+
+
+def all_cores_cpu_rate(model, threads, cap_s=60):
+    """the CPU port on `threads` threads, one image after one warm-up image, in a child process with a time limit"""
     import subprocess
     code = ("import sys, time, os, importlib, torch; sys.path.insert(0, %r); pkg = importlib.import_module('mi-gan_amd'); "
-            "from oracle import migan_torch_cpu as torc; res = %d; torch.set_num_threads(os.cpu_count()); "
+            "from oracle import migan_torch_cpu as torc; res = %d; torch.set_num_threads(%d); "
             "sd = pkg.synth.make_state_dict(res, seed=0, regime='export'); x = pkg.synth.make_input(1, res, seed=100, kind='demo'); "
+            "torc.generator(x, sd, res); "
             "t = time.perf_counter(); torc.generator(x, sd, res); print('RATE', 1 / (time.perf_counter() - t))"
-            % (ROOT, model))
+            % (ROOT, model, threads))
     try:
         r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=cap_s)
         for line in r.stdout.splitlines():
@@ -252,7 +270,7 @@ def all_cores_cpu_rate(model, cap_s=60):
                 return round(float(line.split()[1]), 4), None
         return None, "child failed: " + r.stderr[-200:]
     except subprocess.TimeoutExpired:
-        return None, f"one image (first call, no warm-up) did not finish within the {cap_s} s cap on all {os.cpu_count()} logical cores"
+        return None, f"two images (warm-up + timed) did not finish within the {cap_s} s cap on {threads} threads"
 
 
 def build_migan(pkg, args, res, batch, dev, rank):
@@ -447,11 +465,15 @@ def run_workload(args, rank, local_rank, world, dist, dev):
         if cpu["kind"] == "reference":
             cpu["sample"] = cpu["sample"].replace(wl["cpu_desc"], "lib/model_zoo/migan_inference.py::Generator of the reference repository itself")
         if name == "migan" and cores > threads and (args.cpu_all_cores or primary_default(args)):
-            # north star: "the node's host cores (core count stated)": the all-cores figure beside the fastest setting, capped
-            rate, why = all_cores_cpu_rate(res, cap_s=600 if args.cpu_all_cores else 100)
-            cpu["value_all_cores"], cpu["all_cores"] = rate, cores
-            cpu["all_cores_note"] = why or ("one un-warmed image in a child process with torch.set_num_threads(all logical cores): slower than the "
-                                            f"{threads}-thread figure above because the port's small oneDNN ops oversubscribe; `value` is the fastest setting")
+            # north star: "the node's host cores (core count stated)": every PHYSICAL core beside the fastest setting, in a capped child
+            # process (default run: 60 s).  One thread per logical core oversubscribes the port's small oneDNN ops -- measured in round 3
+            # on the 256-thread GPU-box host: 0.014 images/s, 70 s per image -- and is what --cpu-all-cores times instead.
+            phys = cores if args.cpu_all_cores else min(cores, physical_cores())
+            rate, why = all_cores_cpu_rate(res, phys, cap_s=600 if args.cpu_all_cores else 60)
+            cpu["value_all_cores"], cpu["all_cores"] = rate, phys
+            cpu["all_cores_note"] = why or (f"one image after a warm-up image in a child process with torch.set_num_threads({phys}) "
+                                            f"({'logical' if phys == cores else 'physical'} cores of {cores} hardware threads); `value` "
+                                            f"({threads} threads) is the fastest setting measured on this class of host")
         if wl.get("post"):                                   # uint8 output: compare in uint8 steps with the composed oracle output
             parity = float((y[:n].cpu().to(torch.int16) - wl["post"](ref, n)).abs().max())
             parity32 = float((y[:n].cpu().to(torch.int16) - wl["post"](ref32, n)).abs().max())
@@ -653,7 +675,9 @@ def worker(rank, local_rank, world, args):
             dist.all_reduce(warm)
             torch.cuda.synchronize()
             flush_c_stdio()
+        t_wall = time.perf_counter()
         out = run_workload(args, rank, local_rank, world, dist, dev)
+        t_primary = time.perf_counter() - t_wall
         name, res, batch = split_model(args)
         if out is not None and world == 1 and not args.no_secondary and args.model == "migan-512" and not args.resolution \
                 and not args.batch and args.dtype == "f32" and args.gemm == "f16x2" and args.io == "f32":
@@ -668,12 +692,17 @@ def worker(rank, local_rank, world, args):
                     ex["roofline"]["whole_forward"]["alg_mfma_flop"] / (ex["ms_per_step"] * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)
                 out["exact_f32"]["note"] = ("same workload with the 1x1 convs on v_mfma_f32_32x32x2_f32 (exact fp32 products): the number "
                                             "comparable to SURVEY's 5 940 images/s fp32-MFMA ceiling")
+            t_exact = time.perf_counter() - t_wall - t_primary
             out["secondary"] = [
                 secondary_line(args, model="migan-256", dtype="bf16", steps=max(10, args.steps), cpu_images=2),
                 secondary_line(args, model="comodgan-512", steps=max(5, args.steps // 2), warmup=3, cpu_images=4),
                 # the primary workload with demo.py's pre/post-processing fused in (uint8 in, composed uint8 out)
                 secondary_line(args, io="u8", steps=max(10, args.steps // 2), warmup=3, cpu_images=2),
             ]
+            # where the wall time of this command went (the timed region itself is steps x ms_per_step)
+            out["wall_s"] = {"primary_incl_cpu_baseline_latency_rccl": round(t_primary, 1), "exact_f32": round(t_exact, 1),
+                             "secondary": round(time.perf_counter() - t_wall - t_primary - t_exact, 1),
+                             "since_process_start": round(time.perf_counter() - T_PROCESS_START, 1)}
     ok = True
     if out is not None:
         if out.get("rccl_ranks") != args.gpus or out.get("n_gpus") != args.gpus:
