@@ -229,10 +229,14 @@ int migan_compose_output(const void* y_nchw, const void* img_hwc_u8, const void*
 
 /* Process-wide tuning knobs, the run-time form of the MIGAN_* environment variables (experiments and tests):
  * "kc16" (bit mask: 16-channel K chunks for the 64-channel 512x512 layers), "kc16_minw", "w3" (the same mask: those layers on 32-channel chunks at 3 workgroups per CU), "wide", "nt256", "persist_min",
- * "persist_grid", "streams", "stagger", "stagger_pct", "single_b", "debug_split".  Applies to handles created or re-planned afterwards. */
+ * "persist_grid", "streams", "stagger", "stagger_pct", "single_b", "debug_split", "pipe" (bit mask: software-pipelined persistent kernels for
+ * 1 plain, 2 fused-FromRGB, 4 FIR-up layers), "pipe_grid", "pipe_min_tiles".  Applies to handles created or re-planned afterwards. */
 int migan_set_tuning(const char* key, int value);
 
 const char* migan_last_error(void);
+/* Symbol (as rocprofv3 prints it) of the fused-SeparableConv2d kernel the calling thread launched last, "" before the first launch:
+ * which tile form / schedule the plan picked for a layer and batch (diagnostics and tests). */
+const char* migan_last_kernel(void);
 /* "hip:gfx950" for the product library. */
 const char* migan_backend(void);
 /* The process default of how the 1x1 convolutions are multiplied (environment MIGAN_GEMM=f32|bf16x3|f16x2, read once

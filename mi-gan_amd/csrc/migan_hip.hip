@@ -2,6 +2,8 @@
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared migan_hip.hip -o libmigan_hip.so
 #include "migan_rt_hip.h"
 #include "migan_kernels.hpp"
+#include "migan_table.hpp"
+#include "migan_pipe.hpp"
 #include "comodgan_kernels.hpp"
 #include "migan_host.hpp"
 #include "comodgan_host.hpp"

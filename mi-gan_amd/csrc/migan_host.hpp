@@ -103,6 +103,10 @@ struct Tuning {
   int stagger = -1;            // MIGAN_STAGGER: launch index of the first half after which the second half starts (-1: plan default)
   int debug_split = 0;         // diagnostics: keep the two-sub-batch execution in keep-intermediates mode
   int stagger_pct = 22;        // MIGAN_STAGGER_PCT: the next sub-batch starts after this share of a forward's launches
+  int pipe = 7;                // MIGAN_PIPE bit mask: software-pipelined persistent kernels (sepconv_pipe_kernel; fp32 storage, f16x2 GEMM) for
+                               // 1 plain (+ fused ToRGB) layers, 2 the fused-FromRGB layer, 4 FIR-up layers -- wherever an instantiation exists
+  int pipe_grid = 256;         // MIGAN_PIPE_GRID: persistent workgroups of those launches (one 8-wave workgroup per CU on MI355X)
+  int pipe_min_tiles = 256;    // launches with fewer tiles keep the one-tile-per-workgroup kernels
 };
 inline Tuning& tuning() {
   static Tuning t = [] {
@@ -119,6 +123,8 @@ inline Tuning& tuning() {
     if (const char* e = std::getenv("MIGAN_W3")) v.w3 = std::atoi(e);
     if (const char* e = std::getenv("MIGAN_STREAMS")) v.streams = std::min(4, std::max(1, std::atoi(e)));
     if (const char* e = std::getenv("MIGAN_STAGGER")) v.stagger = std::atoi(e);
+    if (const char* e = std::getenv("MIGAN_PIPE")) v.pipe = std::atoi(e);
+    if (const char* e = std::getenv("MIGAN_PIPE_GRID")) v.pipe_grid = std::max(8, std::atoi(e) / 8 * 8);
     return v;
   }();
   return t;
@@ -310,6 +316,26 @@ inline const char* wide_name(const Geo& g) {
     return g.torgb ? "migan::sepconv_wide_kernel<true, 0, false, true, true>" : "migan::sepconv_wide_kernel<false, 0, false, true, true>";
   return n[wide_ball() ? 1 : 0][g.gemmv == 3 ? 1 : 0][g.torgb ? 1 : 0][g.stv];
 }
+// sepconv_pipe_kernel (migan_pipe.hpp): the software-pipelined persistent form of a layer, where an instantiation exists.  Chosen per
+// launch from the batch: every launch of two or more images of a given layer takes the same decision (tiles >= pipe_min_tiles holds
+// from batch 2 on for the layers that have an instantiation), so an image is bit-identical whatever batch >= 2 it is in.
+PipeSlice pipe_slice();
+inline bool PipeResident(const PipeEntry& e) { return (e.cin / 32) * (2 * e.NT * 64) <= 32 * 1024; }    // all weight planes of a column tile stay in LDS
+inline const PipeEntry* pick_pipe(const Geo& g, int cin, int cout, int batch, bool fused_rgb, bool u8) {
+  const int bit = g.fromrgb ? 2 : (g.mode == MODE_UP ? 4 : 1);
+  if (!(tuning().pipe & bit) || g.stv != 0 || g.gemmv != 2 || !g.maing || g.wide || g.MT != 128 || g.KC != 32 || g.lgIMGS != 0) return nullptr;
+  if (g.mode != MODE_NORMAL && g.mode != MODE_UP) return nullptr;
+  if (batch < 2 || g.tiles_x * g.tiles_y * g.nchunks * batch < tuning().pipe_min_tiles) return nullptr;
+  (void)u8;
+  const PipeSlice sl = pipe_slice();
+  for (int i = 0; i < sl.n; ++i) {
+    const PipeEntry& e = sl.entries[i];
+    if (e.mode == g.mode && e.NT == g.NT && e.cin == cin && e.fromrgb == g.fromrgb && e.torgb == fused_rgb && cout == g.NT * g.nchunks &&
+        (PipeResident(e) ? g.nchunks == 1 : true))
+      return &e;
+  }
+  return nullptr;
+}
 inline const char* kernel_name(const Geo& g);
 inline const KernelEntry& pick_kernel(const Geo& g) {
   for (const auto& e : kernel_table())
@@ -395,6 +421,10 @@ inline void prepare_kernels() {
   std::lock_guard<std::mutex> lock(mu);
   if (dev >= 0 && dev < (int)done.size() && done[dev]) return;
   for (const auto& e : kernel_table()) rt_check(rt::allow_dynamic_lds((const void*)e.fn, 96 * 1024), "hipFuncSetAttribute");
+  {
+    const PipeSlice sl = pipe_slice();
+    for (int i = 0; i < sl.n; ++i) rt_check(rt::allow_dynamic_lds((const void*)sl.entries[i].fn, 160 * 1024), "hipFuncSetAttribute");
+  }
   for (int t = 0; t < 2; ++t)
     for (int sv = 0; sv < 3; ++sv) {
       for (int ball = 0; ball < 2; ++ball) {
@@ -474,9 +504,24 @@ inline unsigned grid_of(const Geo& g, int batch, bool fused_rgb = false) {
   return use_persistent(g, batch, fused_rgb) ? (unsigned)tuning().persist_grid : tiles_of(g, batch);
 }
 
+// name of the kernel launch_sepconv runs for this geometry and batch
+inline const char* launched_kernel_name(Geo g, int cin, int cout, int batch, bool fused_rgb);
+// symbol of the fused-SeparableConv2d kernel this thread launched last (migan_last_kernel: tests ask which form ran)
+inline const char*& last_kernel_ref() {
+  thread_local const char* n = "";
+  return n;
+}
 inline void launch_sepconv(Geo g, const SepArgs& a, rt::stream_t stream) {
   prepare_kernels();
   const bool fused_rgb = a.trgb_w != nullptr;
+  if (const PipeEntry* pe = pick_pipe(g, a.CI, a.CO, a.B, fused_rgb, a.u8_img != nullptr)) {
+    MIGAN_CHECK(a.wsplit != nullptr, MIGAN_EINVAL, "internal: the pipelined kernel needs the fp16 weight planes");
+    const unsigned tiles = tiles_of(g, a.B);
+    const unsigned grid = std::min(tiles, (unsigned)tuning().pipe_grid);
+    rt_check(rt::launch(pe->fn, a, grid, (unsigned)kPipeThreads, pe->lds_bytes, stream), pe->name);
+    last_kernel_ref() = pe->name;
+    return;
+  }
   g.persist = use_persistent(g, a.B, fused_rgb);
   g.torgb = fused_rgb;
   MIGAN_CHECK(!fused_rgb || (g.mode == MODE_NORMAL && !g.fromrgb && g.nchunks == 1), MIGAN_EINVAL,
@@ -485,10 +530,19 @@ inline void launch_sepconv(Geo g, const SepArgs& a, rt::stream_t stream) {
     MIGAN_CHECK(a.wsplit != nullptr, MIGAN_EINVAL, "internal: the wide kernel needs the fp16 weight planes");
     rt_check(rt::launch(wide_fn(fused_rgb, g.stv, g.gemmv == 3, wide_ball(), wide_dma(g.stv, g.gemmv == 3)), a, tiles_of(g, a.B), kWideThreads, g.lds_bytes,
                         stream), wide_name(g));
+    last_kernel_ref() = wide_name(g);
     return;
   }
   const KernelEntry& k = pick_kernel(g);
   rt_check(rt::launch(k.fn, a, grid_of(g, a.B, fused_rgb), kThreads, g.lds_bytes, stream), k.name);
+  last_kernel_ref() = k.name;
+}
+
+inline const char* launched_kernel_name(Geo g, int cin, int cout, int batch, bool fused_rgb) {
+  if (const PipeEntry* pe = pick_pipe(g, cin, cout, batch, fused_rgb, false)) return pe->name;
+  g.persist = use_persistent(g, batch, fused_rgb);
+  g.torgb = fused_rgb;
+  return kernel_name(g);
 }
 
 inline void launch_dwfir(const DwGeo& g, DwFirArgs a, rt::stream_t stream, int stv = 0) {
@@ -978,10 +1032,7 @@ inline void migan_handle::run_range(const migan::Plan& P, const float* x, float*
       const Geo& G = *Gp;
       fill_geo(a, G);
       launch_sepconv(G, a, stream);
-      Geo gl = G;
-      gl.persist = use_persistent(gl, n, a.trgb_w != nullptr);
-      gl.torgb = a.trgb_w != nullptr;
-      L.kernel_last = kernel_name(gl);
+      L.kernel_last = launched_kernel_name(G, L.cin, L.cout, n, a.trgb_w != nullptr);
     }
     if (timed) rt_check(rt::event_record(events[2 * li + 1], stream), "hipEventRecord");
     if (!timed && (int)li == mid_after) rt_check(rt::event_record(ev_mid[part], stream), "hipEventRecord");
@@ -1610,11 +1661,15 @@ int migan_set_tuning(const char* key, int value) {
   else if (k == "single_b") t.force_single_b = value != 0;
   else if (k == "debug_split") t.debug_split = value != 0;
   else if (k == "stagger_pct") t.stagger_pct = std::min(100, std::max(0, value));
+  else if (k == "pipe") t.pipe = value;
+  else if (k == "pipe_grid") t.pipe_grid = std::max(8, value / 8 * 8);
+  else if (k == "pipe_min_tiles") t.pipe_min_tiles = std::max(1, value);
   else throw Error(MIGAN_EINVAL, "unknown tuning key: " + k);
   MIGAN_API_END
 }
 
 const char* migan_last_error(void) { return migan::last_error_ref().c_str(); }
+const char* migan_last_kernel(void) { return migan::last_kernel_ref(); }
 const char* migan_backend(void) { return rt::backend_name(); }
 const char* migan_gemm_variant(void) {
   const int g = migan::tuning().gemm;

@@ -1171,7 +1171,7 @@ constexpr int kWideThreads = 512;
 // the register path (profiles/r03_wide_phase_profile.txt) has 60 % of a chunk in "registers -> LDS + wait for the loads".  The
 // image is a buffer descriptor, so pixels outside it (conv zero padding) are lane offsets beyond its range and arrive as zeros;
 // the XOR swizzle of the weight planes is applied to the SOURCE address (the LDS destination of a DMA is linear in the lane).
-// hipcc waits for outstanding DMAs (vmcnt(0)) at every __syncthreads(), which is exactly where the loop needs them.
+// Every wave waits for its own DMAs (explicit s_waitcnt vmcnt(0)) ahead of the barrier that publishes them.
 template <bool TORGB, int STV = 0, bool X1 = false, bool BALL = false, bool DMA = false>
 MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(kWideThreads, 2) sepconv_wide_kernel(const SepArgs p) {
   static_assert(!DMA || (STV == 0 && BALL), "the LDS-DMA staging is built for fp32 storage on the dedicated-MFMA-wave form");
@@ -1485,6 +1485,9 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(kWideThreads, 2) sepconv_wide_kernel(const
       load_taps(KC);
       store_taps(1);
     }
+    // every wave waits for ITS OWN DMAs before the barrier that publishes them: gfx950 barriers do not drain the VM counter, and
+    // the wait hipcc 7.2 happens to place there is not a guarantee (a workgroup-scope release only needs lgkmcnt)
+    MIGAN_WAIT_VMCNT(0);
     __syncthreads();
     if (groupA) depthwise(0, 0);
     __syncthreads();
@@ -1529,7 +1532,7 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(kWideThreads, 2) sepconv_wide_kernel(const
         PROF_MARK(pslot + 1);
         if (c + 1 < nkc && !MIGAN_ABL(4)) depthwise((c + 1) & 1, (c + 1) & 1);
         PROF_MARK(pslot + 2);
-        if constexpr (DMA) { if (c + 2 < nkc) store_taps(c & 1); }
+        if constexpr (DMA) { if (c + 2 < nkc) store_taps(c & 1); MIGAN_WAIT_VMCNT(0); }
         __syncthreads();
         PROF_MARK(pslot + 3);
       }
@@ -1540,7 +1543,7 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(kWideThreads, 2) sepconv_wide_kernel(const
         PROF_MARK(pslot + 1);
         if (!MIGAN_ABL(8)) mfma_chunk(c & 1);
         PROF_MARK(pslot + 2);
-        if constexpr (DMA) { if (c + 2 < nkc) store_taps(c & 1); }
+        if constexpr (DMA) { if (c + 2 < nkc) store_taps(c & 1); MIGAN_WAIT_VMCNT(0); }
         __syncthreads();
         PROF_MARK(pslot + 3);
       }

@@ -72,6 +72,17 @@ __device__ __forceinline__ MIGAN_BUF migan_make_buf(const void* p, unsigned byte
 #define MIGAN_LDS_DMA16(buf, voff, soff, ldsp) \
   __builtin_amdgcn_raw_ptr_buffer_load_lds((buf), (__attribute__((address_space(3))) void*)(ldsp), 16, (int)(voff), (int)(soff), 0, 0)
 
+// ---- hand-placed synchronisation of the LDS-DMA pipelines (sepconv_pipe_kernel, sepconv_wide_kernel<..., DMA>) --------------------
+// s_waitcnt vmcnt(n): at most n of this wave's vector-memory operations (LDS-DMAs, loads, stores: issue order) still outstanding.
+// Inline asm on purpose: the compiler's own waitcnt pass neither sees nor removes it (MI355X_MICROARCH.md, "Compiler hazard").
+#define MIGAN_WAIT_VMCNT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
+// workgroup barrier that publishes this wave's LDS writes but leaves its vector-memory operations in flight: __syncthreads() would drain
+// them (an LDS-DMA is a pending LDS write on the VM counter; a store tail would be waited for as well)
+#define MIGAN_BARRIER_LDS() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+// the lanes of one wave exchange data through LDS: in-order LDS + lockstep execution need no instruction, only a fence the scheduler
+// will not move LDS accesses across (the CPU emulator, whose lanes are independent fibers, synchronises the wave here)
+#define MIGAN_WAVE_SYNC() __builtin_amdgcn_wave_barrier()
+
 namespace rt {
 typedef hipStream_t stream_t;
 typedef hipEvent_t event_t;

@@ -86,4 +86,18 @@ struct KernelSlice {
   int n;
 };
 
+// sepconv_pipe_kernel instantiations (migan_pipe.hpp; translation unit migan_pipe.hip)
+struct PipeEntry {
+  int mode, NT, cin;
+  bool fromrgb, torgb;
+  int ring;
+  SepKernelFn fn;
+  const char* name;     // the symbol as rocprofv3 prints it
+  size_t lds_bytes;
+};
+struct PipeSlice {
+  const PipeEntry* entries;
+  int n;
+};
+
 }  // namespace migan

@@ -68,7 +68,7 @@ EXPORTS = (
     "migan_forward_timed", "migan_set_debug", "migan_debug_tensor", "migan_sepconv_forward",
     "migan_pack_input", "migan_compose_output",
     "migan_pipeline_mask_resize", "migan_pipeline_scratch_bytes", "migan_pipeline_bbox", "migan_pipeline_pre", "migan_pipeline_post",
-    "migan_set_tuning", "migan_last_error", "migan_backend", "migan_gemm_variant", "migan_version",
+    "migan_set_tuning", "migan_last_error", "migan_last_kernel", "migan_backend", "migan_gemm_variant", "migan_version",
     # include/comodgan_hip.h
     "comodgan_create", "comodgan_destroy", "comodgan_num_weights", "comodgan_weight_info", "comodgan_set_weight",
     "comodgan_commit", "comodgan_workspace_bytes", "comodgan_assume_static_weights", "comodgan_noise_floats", "comodgan_forward",
@@ -156,6 +156,7 @@ class MiganLib:
         L.comodgan_set_truncation_cutoff.argtypes = [vp, ci]
         L.comodgan_debug_tensor.argtypes = [vp, ci, C.c_char_p, C.POINTER(C.c_size_t), C.POINTER(C.c_int64), C.POINTER(ci)]
         L.migan_last_error.restype = C.c_char_p
+        L.migan_last_kernel.restype = C.c_char_p
         L.migan_backend.restype = C.c_char_p
         L.migan_gemm_variant.restype = C.c_char_p
         L.migan_backend.restype = C.c_char_p
@@ -163,7 +164,7 @@ class MiganLib:
             raise MiganError(f"{self.path} reports backend {L.migan_backend().decode()!r}, not {PRODUCT_BACKEND!r}: only the gfx950 HIP "
                              f"library is a product backend (the CPU emulator build is test infrastructure)")
         for name in EXPORTS:
-            if name not in ("migan_last_error", "migan_backend", "migan_gemm_variant"):
+            if name not in ("migan_last_error", "migan_last_kernel", "migan_backend", "migan_gemm_variant"):
                 getattr(L, name).restype = ci
 
     # -- error mapping: EINVAL -> ValueError-like, like the reference's constructor / load_state_dict
@@ -184,6 +185,10 @@ class MiganLib:
 
     def gemm_variant(self) -> str:
         return self.lib.migan_gemm_variant().decode()
+
+    def last_kernel(self) -> str:
+        """symbol of the fused-SeparableConv2d kernel this thread launched last"""
+        return (self.lib.migan_last_kernel() or b"").decode()
 
     def set_tuning(self, key: str, value: int) -> None:
         self.check(self.lib.migan_set_tuning(key.encode(), int(value)))

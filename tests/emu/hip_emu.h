@@ -34,10 +34,18 @@ struct Dim3 {
   unsigned x = 1, y = 1, z = 1;
 };
 
+// one LDS-DMA (buffer_load ... lds) of one lane: 16 bytes that land in LDS when the lane WAITS for them (MIGAN_WAIT_VMCNT), not when
+// the instruction is issued -- a reader that is only ordered by a barrier, without the issuing wave's vmcnt wait, sees stale LDS
+struct DmaOp {
+  char* dst;
+  unsigned char data[16];
+};
+
 struct Lane {
   Dim3 tid;
   void* sp = nullptr;
   bool done = false;
+  std::vector<DmaOp> dma;      // outstanding LDS-DMAs, oldest first
 };
 
 constexpr int kMaxLanes = 512;
@@ -267,8 +275,9 @@ inline emu_f16v hipemu_mfma_16b_32x32x16(emu_f4 a, emu_f4 bv, emu_f16v c, bool f
 #define MIGAN_MFMA_F16_32X32X16(a, b, c) hipemu_mfma_16b_32x32x16((a), (b), (c), true)
 
 
-// ---- LDS-DMA staging: buffer descriptor with the hardware's range check, and the direct global -> LDS copy (executed at once:
-// the emulator has no asynchronous memory; the product relies on the vmcnt(0) hipcc places before every barrier)
+// ---- LDS-DMA staging: buffer descriptor with the hardware's range check, and the direct global -> LDS copy.  The copy is DEFERRED:
+// the bytes are captured at issue and written to LDS by MIGAN_WAIT_VMCNT(n) (all but the n newest of the lane's outstanding DMAs), so a
+// missing or mis-counted wait leaves NaN-poisoned / stale LDS behind and fails the parity tests.  __syncthreads() does not drain them.
 #define MIGAN_UNIFORM(x) (x)
 struct MIGAN_BUF {
   const char* p;
@@ -276,12 +285,27 @@ struct MIGAN_BUF {
 };
 #define MIGAN_MAKE_BUF(ptr, bytes) (MIGAN_BUF{reinterpret_cast<const char*>(ptr), (unsigned)(bytes)})
 inline void hipemu_lds_dma16(MIGAN_BUF b, unsigned voff, unsigned soff, float* wave_base) {
-  const int lane = hipemu::tl_blk->cur & 63;
-  char* dst = reinterpret_cast<char*>(wave_base) + 16 * lane;
-  if ((unsigned long long)voff + 16ull > (unsigned long long)b.n) std::memset(dst, 0, 16);      // range check on the lane offset
-  else std::memcpy(dst, b.p + voff + soff, 16);
+  hipemu::Block* blk = hipemu::tl_blk;
+  const int lane = blk->cur & 63;
+  hipemu::DmaOp op;
+  op.dst = reinterpret_cast<char*>(wave_base) + 16 * lane;
+  if ((unsigned long long)voff + 16ull > (unsigned long long)b.n) std::memset(op.data, 0, 16);      // range check on the lane offset
+  else std::memcpy(op.data, b.p + voff + soff, 16);
+  blk->lanes[blk->cur].dma.push_back(op);
 }
 #define MIGAN_LDS_DMA16(buf, voff, soff, ldsp) hipemu_lds_dma16((buf), (voff), (soff), (ldsp))
+inline void hipemu_wait_vmcnt(int n) {
+  hipemu::Block* blk = hipemu::tl_blk;
+  std::vector<hipemu::DmaOp>& q = blk->lanes[blk->cur].dma;
+  const size_t keep = (size_t)(n < 0 ? 0 : n);
+  if (q.size() <= keep) return;
+  const size_t done = q.size() - keep;
+  for (size_t i = 0; i < done; ++i) std::memcpy(q[i].dst, q[i].data, 16);
+  q.erase(q.begin(), q.begin() + (long)done);
+}
+#define MIGAN_WAIT_VMCNT(n) hipemu_wait_vmcnt(n)
+#define MIGAN_BARRIER_LDS() hipemu::block_barrier()
+#define MIGAN_WAVE_SYNC() hipemu::wave_barrier()
 
 // ---- the runtime surface the host code uses ----------------------------------------------------------
 namespace rt {

@@ -5,6 +5,8 @@
 #include "../../mi-gan_amd/csrc/migan_kernels.hpp"
 #include "../../mi-gan_amd/csrc/comodgan_kernels.hpp"
 #include "../../mi-gan_amd/csrc/migan_table.hpp"
+#include "../../mi-gan_amd/csrc/migan_pipe.hpp"
+#include "../../mi-gan_amd/csrc/migan_pipe_table.inc"
 // every slice of the sepconv_kernel table (the product compiles one translation unit per slice)
 #define MIGAN_SLICE_G 0
 #define MIGAN_SLICE_S 0
@@ -133,6 +135,7 @@ static void run_block(Worker& wk, void (*invoke)(const void*), const void* arg, 
     Lane& l = b->lanes[i];
     l.tid = Dim3{(unsigned)i, 0, 0};
     l.done = false;
+    l.dma.clear();
     b->wave_alive[i >> 6]++;
     uintptr_t top = reinterpret_cast<uintptr_t>(wk.stacks + (size_t)(i + 1) * kStackBytes) & ~(uintptr_t)15;
     void** slot = reinterpret_cast<void**>(top - 16);   // return address: entry sees rsp % 16 == 8

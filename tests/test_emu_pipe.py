@@ -1,0 +1,72 @@
+"""The software-pipelined persistent SeparableConv2d kernels (mi-gan_amd/csrc/migan_pipe.hpp) on the CPU fiber emulator, against the
+numpy oracle, through the C ABI entry migan_sepconv_forward.  The emulator defers every LDS-DMA until the issuing lane's
+MIGAN_WAIT_VMCNT, so a missing or mis-counted wait of the DMA ring leaves NaN-poisoned LDS behind and fails these cases; its
+lanes run to the next collective one after the other, so a missing barrier between the wave groups gives a wrong result too."""
+import importlib
+
+import pytest
+
+from tests.emu_util import emu_lib
+from tests.sepconv_case import HostMem, run_sepconv_case
+
+
+@pytest.fixture(scope="module")
+def lib():
+    return emu_lib()
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    return importlib.import_module("mi-gan_amd")
+
+
+@pytest.fixture(autouse=True)
+def small_grids(lib):
+    # the emulator cases have a few dozen tiles: let them take the pipelined kernels, a few tiles per workgroup
+    lib.set_tuning("pipe_min_tiles", 1)
+    lib.set_tuning("pipe_grid", 8)
+    yield
+    lib.set_tuning("pipe_min_tiles", 256)
+    lib.set_tuning("pipe_grid", 256)
+    lib.set_tuning("pipe", 7)
+
+
+PIPE = "migan::sepconv_pipe_kernel<"
+
+
+# (h, w, batch): 8x16 tiles; with 8 workgroups some walk 1 tile, some 2, some 3 (steady state, first and last tile)
+@pytest.mark.parametrize("h,w,batch", [(16, 32, 2), (16, 32, 5), (8, 16, 2), (24, 48, 2)])
+@pytest.mark.parametrize("noise", [False, True])
+def test_plain_64_to_64(lib, pkg, h, w, batch, noise):
+    run_sepconv_case(lib, pkg, HostMem(), cin=64, cout=64, h=h, w=w, batch=batch, noise=noise, seed=3)
+    assert lib.last_kernel().startswith(PIPE + "0, 64, 64, false, false"), lib.last_kernel()
+
+
+@pytest.mark.parametrize("h,w,batch,prev", [(16, 32, 3, True), (16, 16, 2, False), (32, 32, 2, True)])
+def test_plain_with_fused_torgb(lib, pkg, h, w, batch, prev):
+    run_sepconv_case(lib, pkg, HostMem(), cin=64, cout=64, h=h, w=w, batch=batch, noise=True, torgb=True, with_prev=prev, seed=5)
+    assert lib.last_kernel().startswith(PIPE + "0, 64, 64, false, true"), lib.last_kernel()
+
+
+@pytest.mark.parametrize("h,w,batch", [(16, 32, 3), (8, 16, 2), (32, 16, 2)])
+def test_plain_with_fused_fromrgb(lib, pkg, h, w, batch):
+    run_sepconv_case(lib, pkg, HostMem(), cin=64, cout=64, h=h, w=w, batch=batch, fromrgb=True, seed=7)
+    assert lib.last_kernel().startswith(PIPE + "0, 64, 64, true, false"), lib.last_kernel()
+
+
+@pytest.mark.parametrize("h,w,batch", [(8, 16, 2), (16, 32, 2), (12, 20, 3), (6, 14, 2)])
+@pytest.mark.parametrize("noise,skip", [(True, True), (False, False)])
+def test_fir_up_128_to_64(lib, pkg, h, w, batch, noise, skip):
+    run_sepconv_case(lib, pkg, HostMem(), cin=128, cout=64, h=h, w=w, batch=batch, up=2, noise=noise, skip=skip, seed=9)
+    assert lib.last_kernel().startswith(PIPE + "2, 64, 128, false, false"), lib.last_kernel()
+
+
+def test_pipe_off_takes_the_one_tile_kernels(lib, pkg):
+    lib.set_tuning("pipe", 0)
+    run_sepconv_case(lib, pkg, HostMem(), cin=64, cout=64, h=16, w=32, batch=2, noise=True, seed=3)
+    assert lib.last_kernel().startswith("migan::sepconv_kernel<"), lib.last_kernel()
+
+
+def test_single_image_keeps_the_latency_tiles(lib, pkg):
+    run_sepconv_case(lib, pkg, HostMem(), cin=64, cout=64, h=16, w=32, batch=1, noise=True, seed=3)
+    assert lib.last_kernel().startswith("migan::sepconv_kernel<"), lib.last_kernel()
