@@ -103,9 +103,13 @@ struct Tuning {
   int stagger = -1;            // MIGAN_STAGGER: launch index of the first half after which the second half starts (-1: plan default)
   int debug_split = 0;         // diagnostics: keep the two-sub-batch execution in keep-intermediates mode
   int stagger_pct = 22;        // MIGAN_STAGGER_PCT: the next sub-batch starts after this share of a forward's launches
-  int pipe = 7;                // MIGAN_PIPE bit mask: software-pipelined persistent kernels (sepconv_pipe_kernel; fp32 storage, f16x2 GEMM) for
-                               // 1 plain (+ fused ToRGB) layers, 2 the fused-FromRGB layer, 4 FIR-up layers -- wherever an instantiation exists
-  int pipe_grid = 256;         // MIGAN_PIPE_GRID: persistent workgroups of those launches (one 8-wave workgroup per CU on MI355X)
+  int pipe = 5;                // MIGAN_PIPE bit mask: software-pipelined persistent kernels (sepconv_pipe_kernel; fp32 storage, f16x2 GEMM) for
+                               // 1 plain (+ fused ToRGB) layers, 2 the fused-FromRGB layer, 4 FIR-up layers -- wherever an instantiation exists.
+                               // Default 5: synthesis.b512.conv1 -11 %, synthesis.b512.conv2 -6 %; the fused-FromRGB form (encoder.b512.conv1)
+                               // is instruction-issue bound by the tile build and only ties the one-tile kernel (profiles/r04_pipe_*)
+  int pipe_grid = 256;         // MIGAN_PIPE_GRID: persistent workgroups of those launches (one 12- or 16-wave workgroup per CU on MI355X)
+  int pipe_na = 4;             // waves of the depthwise group of those workgroups (4 or 8), for the layers in pipe_na8 the other value
+  int pipe_na8 = 0;            // bit mask like `pipe`: layers that take 8 depthwise waves
   int pipe_min_tiles = 256;    // launches with fewer tiles keep the one-tile-per-workgroup kernels
 };
 inline Tuning& tuning() {
@@ -330,7 +334,8 @@ inline const PipeEntry* pick_pipe(const Geo& g, int cin, int cout, int batch, bo
   const PipeSlice sl = pipe_slice();
   for (int i = 0; i < sl.n; ++i) {
     const PipeEntry& e = sl.entries[i];
-    if (e.mode == g.mode && e.NT == g.NT && e.cin == cin && e.fromrgb == g.fromrgb && e.torgb == fused_rgb && cout == g.NT * g.nchunks &&
+    const int na = (tuning().pipe_na8 & bit) ? 8 : tuning().pipe_na;
+    if (e.mode == g.mode && e.NT == g.NT && e.cin == cin && e.fromrgb == g.fromrgb && e.torgb == fused_rgb && e.na == na && cout == g.NT * g.nchunks &&
         (PipeResident(e) ? g.nchunks == 1 : true))
       return &e;
   }
@@ -518,7 +523,7 @@ inline void launch_sepconv(Geo g, const SepArgs& a, rt::stream_t stream) {
     MIGAN_CHECK(a.wsplit != nullptr, MIGAN_EINVAL, "internal: the pipelined kernel needs the fp16 weight planes");
     const unsigned tiles = tiles_of(g, a.B);
     const unsigned grid = std::min(tiles, (unsigned)tuning().pipe_grid);
-    rt_check(rt::launch(pe->fn, a, grid, (unsigned)kPipeThreads, pe->lds_bytes, stream), pe->name);
+    rt_check(rt::launch(pe->fn, a, grid, (unsigned)pipe_threads(pe->na), pe->lds_bytes, stream), pe->name);
     last_kernel_ref() = pe->name;
     return;
   }
@@ -1663,6 +1668,8 @@ int migan_set_tuning(const char* key, int value) {
   else if (k == "stagger_pct") t.stagger_pct = std::min(100, std::max(0, value));
   else if (k == "pipe") t.pipe = value;
   else if (k == "pipe_grid") t.pipe_grid = std::max(8, value / 8 * 8);
+  else if (k == "pipe_na") t.pipe_na = value == 8 ? 8 : 4;
+  else if (k == "pipe_na8") t.pipe_na8 = value;
   else if (k == "pipe_min_tiles") t.pipe_min_tiles = std::max(1, value);
   else throw Error(MIGAN_EINVAL, "unknown tuning key: " + k);
   MIGAN_API_END

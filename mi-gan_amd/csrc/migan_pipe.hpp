@@ -3,34 +3,37 @@
 // Same arithmetic as sepconv_kernel (reference lib/model_zoo/migan_inference.py:154-170: depthwise 3x3 + bias -> lrelu_agc -> 1x1 conv
 // -> [2x FIR upsample] -> noise -> lrelu_agc -> [+ skip] -> [ToRGB]), other schedule.  The stage ablation of the round-3 kernels
 // (profiles/r03_ablation_batch32.txt) shows their phases ADD UP: a workgroup loads, computes, then stores, and the 15 GB of output
-// stores of a forward are fully exposed (27 % of the time).  Here one persistent 8-wave workgroup per CU is a four-stage pipeline over
-// its tiles, every stage on its own hardware queue:
+// stores of a forward are fully exposed (27 % of the time).  Here ONE persistent workgroup per CU (12 or 16 waves) is a four-stage
+// pipeline over its tiles, every stage on its own hardware queue:
 //
 //   DMA    buffer_load ... lds: input tile of K-chunk s+R-1 (and 1x1 weight planes) HBM/L2 -> LDS ring, no registers, issued by group A,
 //          R-1 chunks (24-48 KB per CU) in flight across the barriers (counted s_waitcnt vmcnt, raw s_barrier)
-//   A      waves 0-3: depthwise 3x3 + bias + act + fp16 hi/lo split of chunk s+1 -> A-operand planes (VALU + LDS)
-//   B      waves 4-7: v_mfma_f32_32x32x16_f16 x 3 of chunk s (matrix pipe) ...
+//   A      NA waves: depthwise 3x3 + bias + act + fp16 hi/lo split of chunk s+1 -> A-operand planes (VALU + LDS)
+//   B      8 waves (4 row blocks x 2 column halves of the 128 x NT tile): v_mfma_f32_32x32x16_f16 x 3 of chunk s (matrix pipe) ...
 //   store  ... and, between their MFMA groups, the EPILOGUE OF THE PREVIOUS TILE: its accumulators wait in a second register set
 //          (plain layers: transposed through a wave-private LDS patch, no barrier) or in a dedicated LDS result tile (FIR-up layers),
 //          and a slice of its noise / activation / skip / ToRGB work and of its global stores is issued in every K step of the next
 //          tile.  The stores of tile t therefore drain while tile t+1 is loaded and computed; B never waits for them (it issues no
-//          DMA, and its own loads are requested one slice ahead of the stores that precede their use).
+//          DMA, and everything it loads is requested ahead of the stores that precede its use: vmcnt retires in issue order).
 //
 // One workgroup barrier per K chunk.  The 1x1 weight planes and the depthwise taps of ALL chunks stay in LDS for the life of the
 // workgroup where they fit (Cin x Cout <= 128 x 64: the 512x512 layers), otherwise the planes stream through a two-slot ring.
+// Why 12-16 waves: each stage is a dependent instruction stream (one wave issues a VALU instruction every ~5 cycles, an LDS round
+// trip is > 100); the first form of this kernel (4 + 4 waves) was bound by the lone epilogue wave per SIMD
+// (profiles/r04_pipe_phase_profile.txt), so the stages are spread over three to four waves per SIMD.
 // fp32 activation storage, f16x2 GEMM (the default of that storage format); everything else keeps sepconv_kernel.
 #pragma once
 
 namespace migan {
 
-constexpr int kPipeThreads = 512;
+constexpr int kPipeBWaves = 8;
+constexpr int pipe_threads(int na) { return (na + kPipeBWaves) * 64; }
 
-// LDS carve of one instantiation (bytes), shared with the host plan (pipe_lds_bytes)
+// LDS carve of one instantiation (bytes), shared with the host plan
 template <int MODE, int NT, int CIN, bool FROMRGB, int R>
 struct PipeLds {
   static constexpr int NKC = CIN / 32;
-  static constexpr int DNI = 6;                                     // input-tile DMAs per group-A thread and chunk (1440 of 1536 units used)
-  static constexpr int IN_SLOT = DNI * 256 * 16;                    // ring slot: [180 pixels][32 channels] fp32 + padding
+  static constexpr int IN_SLOT = 1536 * 16;                         // ring slot: [180 pixels][32 channels] fp32 + padding (1440 of 1536 16-byte units)
   static constexpr int A_BUF = 2 * 128 * 64;                        // hi + lo plane of the A operand, [128 rows][32 k] fp16 each
   static constexpr int B_CHUNK = 2 * NT * 64;                       // hi + lo plane of one K chunk of the weights, [NT rows][32 k] fp16
   static constexpr bool WRES = NKC * B_CHUNK <= 32 * 1024;          // all chunks resident
@@ -42,31 +45,51 @@ struct PipeLds {
   static constexpr int OFF_F = OFF_W + NKC * 1280;                  // FROMRGB: fromrgb weights per chunk input-major [4][32] + bias [32]
   static constexpr int OFF_RGB = OFF_F + (FROMRGB ? NKC * 640 : 0); // FROMRGB: raw network input of the halo tile, two tiles
   static constexpr int OFF_T = OFF_RGB + (FROMRGB ? 2 * 180 * 16 : 0);
-  static constexpr int T_SZ = MODE == MODE_UP ? 128 * (NT + 4) * 4 : 4 * 32 * 36 * 4;   // FIR-up: shared result tile; plain: one transpose patch per B wave
-  static constexpr int TOTAL = OFF_T + T_SZ;
+  static constexpr int T_SZ = MODE == MODE_UP ? 128 * (NT + 4) * 4 : kPipeBWaves * 32 * 32 * 4;   // FIR-up: shared result tile; plain: one transpose patch per B wave
+  static constexpr int OFF_P = OFF_T + T_SZ;                       // plain + ToRGB: per-pixel partial sums of the waves of column half 1, [128 pixels][4]
+  static constexpr int TOTAL = OFF_P + (MODE == MODE_UP ? 0 : 128 * 16);
   static_assert(TOTAL <= 160 * 1024, "LDS budget");
 };
 
-template <int MODE, int NT, int CIN, bool FROMRGB, bool TORGB, int R>
-MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(kPipeThreads, 2) sepconv_pipe_kernel(const SepArgs p) {
+// phase profile of this kernel (-DMIGAN_PHASE_PROF builds): 16 accumulators; group A -> slots 0..3 [DMA issue + offsets / tile build,
+// depthwise, vmcnt wait, barrier], group B -> 4 MFMAs, 5 first use of the prefetched noise / taps, 6 barrier, 7 hand-over + rest, 9 block
+// epilogue (transpose, activation, stores), 10 ToRGB partial sums, 11 ToRGB tail, 12 prefetch requests; slot 8 counts workgroups
+#ifdef MIGAN_PHASE_PROF
+#define PPROF_BEGIN() long long pprof_t = (long long)MIGAN_CLOCK(); long long pprof_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
+#define PPROF_MARK(i) do { const long long n_ = (long long)MIGAN_CLOCK(); pprof_acc[i] += n_ - pprof_t; pprof_t = n_; } while (0)
+#define PPROF_END(AT_) do { if (p.prof && (tid == 0 || tid == (AT_))) { for (int i_ = 0; i_ < 16; ++i_) if (i_ != 8) MIGAN_ATOMIC_ADD_U64(p.prof + i_, (unsigned long long)pprof_acc[i_]); if (tid == 0) MIGAN_ATOMIC_ADD_U64(p.prof + 8, 1ull); } } while (0)
+#else
+#define PPROF_BEGIN() do {} while (0)
+#define PPROF_MARK(i) do {} while (0)
+#define PPROF_END(AT_) do {} while (0)
+#endif
+
+template <int MODE, int NT, int CIN, bool FROMRGB, bool TORGB, int R, int NA>
+MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(pipe_threads(NA), (NA + kPipeBWaves) / 4) sepconv_pipe_kernel(const SepArgs p) {
   static_assert(MODE == MODE_NORMAL || MODE == MODE_UP, "plain and FIR-up layers");
   static_assert(!FROMRGB || MODE == MODE_NORMAL, "FromRGB is fused into the first plain layer");
   static_assert(!TORGB || MODE == MODE_NORMAL, "ToRGB is fused into plain layers");
   static_assert(R == 2 || R == 3, "ring depth");
+  static_assert(NA == 4 || NA == 8, "4 or 8 waves in group A");
   typedef PipeLds<MODE, NT, CIN, FROMRGB, R> L;
   constexpr int MT = 128, KC = 32, QC = 8, LG_QC = 3, GH = 8, GW = 16, lgGW = 4, IGW = GW + 2, NPIX = (GH + 2) * IGW, NITEMS = NPIX * QC;
-  constexpr int NKC = L::NKC, DNI = L::DNI, PB = 64, NSLOT = 4, NPL = 2;
+  constexpr int NKC = L::NKC, PB = 64, NSLOT = 4, NPL = 2;
+  constexpr int AT = NA * 64;                                       // threads of group A
+  constexpr int DNI = 1536 / AT;                                    // input-tile DMAs (or built items) per group-A thread and chunk
   constexpr bool WRES = L::WRES;
-  constexpr int DNB = NPL * NT * NSLOT / 256;                       // weight-plane DMAs per group-A thread and chunk
-  constexpr int NTI = NT / 32;                                      // 32-column blocks of a B wave (it owns 32 rows x NT)
+  constexpr int DNB = NPL * NT * NSLOT / AT;                        // weight-plane DMAs per group-A thread and chunk
+  static_assert(DNB >= 1, "weight planes must split over group A");
+  constexpr int NTIW = NT / 64;                                     // 32-column blocks of a B wave (it owns 32 rows x NT/2 columns)
+  constexpr int SEGH = MT * QC / AT;                                // rows of a depthwise strip: 4 (NA 4) or 2 (NA 8)
   static_assert(NKC >= 2 && NKC % 2 == 0, "an even number of K chunks (the A-operand buffer of a step is then a compile-time choice)");
+  static_assert(NTIW + (TORGB ? 1 : 0) <= NKC, "the epilogue slices of a tile must fit the K steps of the next one");
   MIGAN_DYN_SMEM(smem);
   char* const lds = reinterpret_cast<char*>(smem);
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave_u = MIGAN_UNIFORM(tid >> 6);
-  const bool groupA = tid < 256;
+  const bool groupA = tid < AT;
 
   // ---- tile schedule: the XCD-contiguous ranges of sepconv_kernel, walked by the persistent workgroups of each XCD ----------------
   const int ntiles = p.tiles_x * p.tiles_y * p.nchunks * p.B;
@@ -79,6 +102,9 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(kPipeThreads, 2) sepconv_pipe_kernel(const
   const int T = tl0 < tcnt ? (tcnt - tl0 + tstep - 1) / tstep : 0;   // my tiles
   if (T == 0) return;                                                 // (uniform: the whole workgroup leaves)
   const int G = T * NKC;                                              // my K steps
+  // phase profile (-DMIGAN_PHASE_PROF builds): group A -> slots 0..3 [DMA issue + offsets / tile build, depthwise, vmcnt wait, barrier],
+  // group B -> slots 4..7 [MFMAs, epilogue slice, barrier, rest]
+  PPROF_BEGIN();
   auto decode = [&](int k, int& n0_, int& b0_, int& gy0_, int& gx0_) {
     int t = tbase + tl0 + k * tstep;
     const int nch = t % p.nchunks; t /= p.nchunks;
@@ -90,12 +116,69 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(kPipeThreads, 2) sepconv_pipe_kernel(const
     gx0_ = tx * p.sx - p.off;
   };
 
+  // ---- FROMRGB: the input tile is act(fromrgb(network input)) (reference :194-195), BUILT instead of copied -- by every thread of the
+  // workgroup (item i = tid + j NBT of the [180 pixels][8 channel quads] tile; a thread's items all have channel quad tid & 7, so its
+  // 4 x 4 weights + bias are read once per chunk).  Each group keeps its own cursor over the K steps.
+  constexpr int NBT = pipe_threads(NA), BNI = (NITEMS + NBT - 1) / NBT;
+  struct BuildCursor {
+    int is, ic, ik, slot, gy0, gx0, b0;
+    unsigned mask;                                       // bit j = item j of this thread is a pixel inside the image
+  };
+  auto build_mask = [&](BuildCursor& bc) {
+    bc.mask = 0;
+#pragma unroll
+    for (int j = 0; j < BNI; ++j) {
+      const int i = tid + j * NBT;
+      if (i < NITEMS) {
+        const int pix = i >> LG_QC;
+        const int ix = pix % IGW, iy = pix / IGW;
+        const int yy = bc.gy0 - 1 + iy, xx = bc.gx0 - 1 + ix;
+        if (yy >= 0 && yy < p.H && xx >= 0 && xx < p.W) bc.mask |= 1u << j;
+      }
+    }
+  };
+  auto build_begin = [&](BuildCursor& bc) {
+    bc.is = bc.ic = bc.ik = bc.slot = 0;
+    int n0_;
+    decode(0, n0_, bc.b0, bc.gy0, bc.gx0);
+    build_mask(bc);
+  };
+  // build this thread's share of step bc.is into its ring slot, then move the cursor on; returns true when that was the last chunk of a tile
+  auto build_step = [&](BuildCursor& bc) -> bool {
+    if (bc.is >= G) return false;
+    if (!MIGAN_ABL(16)) {
+      float* in_s = reinterpret_cast<float*>(lds + L::OFF_IN + bc.slot * L::IN_SLOT);
+      const float* rgb_s = reinterpret_cast<const float*>(lds + L::OFF_RGB + (bc.ik & 1) * NPIX * 16);
+      const float* wr = reinterpret_cast<const float*>(lds + L::OFF_F) + bc.ic * 160 + (tid & (QC - 1)) * 4;
+      const f4 w0 = ld4(wr), w1 = ld4(wr + 32), w2 = ld4(wr + 64), w3 = ld4(wr + 96), bb = ld4(wr + 128);
+#pragma unroll
+      for (int j = 0; j < BNI; ++j) {
+        const int i = tid + j * NBT;
+        if (i < NITEMS) {
+          f4 v = {0.f, 0.f, 0.f, 0.f};
+          if (bc.mask & (1u << j)) v = act4(fromrgb_quad(ld4(rgb_s + (i >> LG_QC) * 4), w0, w1, w2, w3, bb));
+          st4(in_s + i * 4, v);
+        }
+      }
+    }
+    ++bc.is;
+    bc.slot = bc.slot + 1 == R ? 0 : bc.slot + 1;
+    if (++bc.ic < NKC) return false;
+    bc.ic = 0;
+    if (++bc.ik < T) {
+      int n0_;
+      decode(bc.ik, n0_, bc.b0, bc.gy0, bc.gx0);
+      build_mask(bc);
+    }
+    return true;
+  };
+
   if (groupA) {
     // =============================================== group A: DMA issue + depthwise stage ===========================================
     const int lt = tid;
     float* const w_s = reinterpret_cast<float*>(lds + L::OFF_W);
     // depthwise taps + bias of every chunk, once per workgroup: conv1.weight [CIN][9] -> per chunk tap-major [9][32], then bias [32]
-    for (int i = lt; i < CIN * 9 / 4; i += 256) {
+    for (int i = lt; i < CIN * 9 / 4; i += AT) {
       const f4 v = ld4(p.wdw + i * 4);
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -103,16 +186,16 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(kPipeThreads, 2) sepconv_pipe_kernel(const
         w_s[(ch >> 5) * 320 + tap * 32 + (ch & 31)] = v[e];
       }
     }
-    for (int i = lt; i < CIN / 4; i += 256) st4(w_s + ((i * 4) >> 5) * 320 + 288 + ((i * 4) & 31), ld4(p.bdw + i * 4));
+    for (int i = lt; i < CIN / 4; i += AT) st4(w_s + ((i * 4) >> 5) * 320 + 288 + ((i * 4) & 31), ld4(p.bdw + i * 4));
     if constexpr (FROMRGB) {
       // fromrgb.weight [CIN][4] -> per chunk input-major [4][32], then bias [32] (reference :186)
       float* const f_s = reinterpret_cast<float*>(lds + L::OFF_F);
-      for (int i = lt; i < CIN; i += 256) {
+      for (int i = lt; i < CIN; i += AT) {
         const f4 v = ld4(p.frgb_w + i * 4);
 #pragma unroll
         for (int e = 0; e < 4; ++e) f_s[(i >> 5) * 160 + e * 32 + (i & 31)] = v[e];
       }
-      for (int i = lt; i < CIN / 4; i += 256) st4(f_s + ((i * 4) >> 5) * 160 + 128 + ((i * 4) & 31), ld4(p.frgb_b + i * 4));
+      for (int i = lt; i < CIN / 4; i += AT) st4(f_s + ((i * 4) >> 5) * 160 + 128 + ((i * 4) & 31), ld4(p.frgb_b + i * 4));
     }
 
     // ---- 1x1 weight planes (split_weights_kernel: chunk-major [plane][CIN/32][CO][32] fp16) -> LDS, XOR swizzle on the SOURCE side ----
@@ -120,7 +203,7 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(kPipeThreads, 2) sepconv_pipe_kernel(const
     unsigned dboff[DNB];
 #pragma unroll
     for (int j = 0; j < DNB; ++j) {
-      const int i = lt + j * 256;                        // 16-byte unit of the LDS image [plane][NT rows][4 slots]
+      const int i = lt + j * AT;                         // 16-byte unit of the LDS image [plane][NT rows][4 slots]
       const int plane = i / (NT * NSLOT), rem = i % (NT * NSLOT);
       const int n = rem / NSLOT, sp = rem % NSLOT;       // LDS row n, stored slot sp holds source slot sp ^ swizzle(n)
       dboff[j] = (unsigned)(plane * p.CO * CIN + n * KC + ((sp ^ ((n >> 2) & (NSLOT - 1))) * 8)) * 2u;
@@ -129,7 +212,7 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(kPipeThreads, 2) sepconv_pipe_kernel(const
       float* bb = reinterpret_cast<float*>(lds + L::OFF_B + buf * L::B_CHUNK);
       const unsigned soff = (unsigned)(chunk * KC * p.CO + n0_ * KC) * 2u;
 #pragma unroll
-      for (int j = 0; j < DNB; ++j) MIGAN_LDS_DMA16(wbuf, dboff[j], soff, bb + (j * 256 + wave_u * 64) * 4);
+      for (int j = 0; j < DNB; ++j) MIGAN_LDS_DMA16(wbuf, dboff[j], soff, bb + (j * AT + wave_u * 64) * 4);
     };
 
     // ---- input tile of one K chunk -> ring slot.  The image is a buffer descriptor: a halo pixel outside it (the conv's zero padding,
@@ -138,7 +221,7 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(kPipeThreads, 2) sepconv_pipe_kernel(const
     auto make_dgoff = [&](int gy0_, int gx0_) {
 #pragma unroll
       for (int j = 0; j < DNI; ++j) {
-        const int i = lt + j * 256;
+        const int i = lt + j * AT;
         unsigned g = 0xfffff000u;
         if (i < NITEMS) {
           const int c4 = i & (QC - 1), pix = i >> LG_QC;
@@ -151,13 +234,14 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(kPipeThreads, 2) sepconv_pipe_kernel(const
     };
     const unsigned img_bytes = (unsigned)(p.H * p.W * CIN) * 4u;
     auto dma_in = [&](int b0_, int chunk, int slot) {
+      if (MIGAN_ABL(16)) return;
       float* in_s = reinterpret_cast<float*>(lds + L::OFF_IN + slot * L::IN_SLOT);
       const MIGAN_BUF xbuf = MIGAN_MAKE_BUF(reinterpret_cast<const char*>(p.x) + (size_t)b0_ * img_bytes, img_bytes);
 #pragma unroll
-      for (int j = 0; j < DNI; ++j) MIGAN_LDS_DMA16(xbuf, dgoff[j], (unsigned)(chunk * KC) * 4u, in_s + (j * 256 + wave_u * 64) * 4);
+      for (int j = 0; j < DNI; ++j) MIGAN_LDS_DMA16(xbuf, dgoff[j], (unsigned)(chunk * KC) * 4u, in_s + (j * AT + wave_u * 64) * 4);
     };
 
-    // ---- FROMRGB: the input tile is act(fromrgb(network input)) (reference :194-195), built by this group instead of copied ----------
+    // ---- FROMRGB: the raw 4-channel network input of the halo tile, one tile ahead, through registers into LDS (this group) ----------
     f4 rraw = {0.f, 0.f, 0.f, 0.f};
     auto load_raw = [&](int b0_, int gy0_, int gx0_) {
       f4 v = {0.f, 0.f, 0.f, 0.f};
@@ -179,36 +263,15 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(kPipeThreads, 2) sepconv_pipe_kernel(const
     auto store_raw = [&](int buf) {
       if (lt < NPIX) st4(reinterpret_cast<float*>(lds + L::OFF_RGB + buf * NPIX * 16) + lt * 4, rraw);
     };
-    auto build_in = [&](int gy0_, int gx0_, int chunk, int slot, int rbuf) {
-      float* in_s = reinterpret_cast<float*>(lds + L::OFF_IN + slot * L::IN_SLOT);
-      const float* rgb_s = reinterpret_cast<const float*>(lds + L::OFF_RGB + rbuf * NPIX * 16);
-      const float* f_s = reinterpret_cast<const float*>(lds + L::OFF_F) + chunk * 160;
-#pragma unroll
-      for (int j = 0; j < DNI; ++j) {
-        const int i = lt + j * 256;
-        if (i < NITEMS) {
-          const int c4 = i & (QC - 1), pix = i >> LG_QC;
-          const int ix = pix % IGW, iy = pix / IGW;
-          const int yy = gy0_ - 1 + iy, xx = gx0_ - 1 + ix;
-          f4 v = {0.f, 0.f, 0.f, 0.f};
-          if (yy >= 0 && yy < p.H && xx >= 0 && xx < p.W) {
-            const f4 raw = ld4(rgb_s + pix * 4);
-            const float* wr = f_s + c4 * 4;
-            v = act4(fromrgb_quad(raw, ld4(wr), ld4(wr + 32), ld4(wr + 64), ld4(wr + 96), ld4(f_s + 128 + c4 * 4)));
-          }
-          st4(in_s + i * 4, v);
-        }
-      }
-    };
-
-    // ---- depthwise 3x3 + bias + act (x 2^7) + fp16 hi/lo split of one chunk: one 4-row strip x 4 channels per thread ------------------
+    // ---- depthwise 3x3 + bias + act (x 2^7) + fp16 hi/lo split of one chunk: one SEGH-row strip x 4 channels per thread --------------
     auto depthwise = [&](int slot, int chunk, int abuf) {
+      if (MIGAN_ABL(4)) return;
       const float* in_s = reinterpret_cast<const float*>(lds + L::OFF_IN + slot * L::IN_SLOT);
       const float* wc = w_s + chunk * 320;
       char* a_b = lds + L::OFF_A + abuf * L::A_BUF;
       const int c4 = lt & (QC - 1);
       const int gx = (lt >> LG_QC) & (GW - 1);
-      const int r0 = (lt >> (LG_QC + lgGW)) * 4;
+      const int r0 = (lt >> (LG_QC + lgGW)) * SEGH;
       f4 w[9];
 #pragma unroll
       for (int tap = 0; tap < 9; ++tap) w[tap] = ld4(wc + tap * KC + c4 * 4);
@@ -223,10 +286,10 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(kPipeThreads, 2) sepconv_pipe_kernel(const
       nxt[0] = ld4(ip); nxt[1] = ld4(ip + KC); nxt[2] = ld4(ip + 2 * KC);
       ip += IGW * KC;
 #pragma unroll
-      for (int o = 0; o < 4; ++o) {
+      for (int o = 0; o < SEGH; ++o) {
         const int nr = (o + 2) % 3;
         win[nr][0] = nxt[0]; win[nr][1] = nxt[1]; win[nr][2] = nxt[2];
-        if (o + 1 < 4) {
+        if (o + 1 < SEGH) {
           nxt[0] = ld4(ip); nxt[1] = ld4(ip + KC); nxt[2] = ld4(ip + 2 * KC);
           ip += IGW * KC;
         }
@@ -245,7 +308,7 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(kPipeThreads, 2) sepconv_pipe_kernel(const
       }
     };
 
-    // ---- cursors: the step whose input is issued next (is), the step whose weights are issued next (bs: streamed planes only) ------
+    // ---- cursors: the step whose input is issued / built next (is), the step whose weights are issued next (bs: streamed planes only) --
     int is = 0, ic = 0, ik = 0, islot = 0, ib0 = 0, in0 = 0, igy0 = 0, igx0 = 0;
     decode(0, in0, ib0, igy0, igx0);
     if constexpr (!FROMRGB) make_dgoff(igy0, igx0);
@@ -277,12 +340,12 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(kPipeThreads, 2) sepconv_pipe_kernel(const
         }
       }
     };
-    // the depthwise cursor: step ds (chunk dc, ring slot dslot, tile coordinates only matter to FROMRGB)
-    int dslot = 0;
+    int dslot = 0;                                       // ring slot of the step the depthwise stage works on next
 
     if constexpr (FROMRGB) {
-      // ---- prologue: raw(tile 0) -> LDS, steps 0 and 1 built (NKC == 2: tile 0 complete), raw(tile 1) in registers -----------------
-      static_assert(!FROMRGB || (NKC == 2 && R == 3), "the fused-FromRGB form is built for Cin = 64 (two chunks) and a three-slot ring");
+      // ---- two-slot ring filled by this group itself: interval g runs the depthwise stage of step g+1 (slot (g+1) & 1) and builds the
+      // input tile of step g+2 into slot g & 1, which the depthwise stage of step g finished reading before the last barrier ----
+      static_assert(!FROMRGB || (NKC == 2 && R == 2 && WRES), "the fused-FromRGB form is built for Cin = 64 (two chunks, resident planes) and a two-slot ring");
 #pragma unroll
       for (int c = 0; c < NKC; ++c) dma_b(in0, c, c);          // the resident weight planes: the only DMAs of this form
       load_raw(ib0, igy0, igx0);
@@ -290,35 +353,33 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(kPipeThreads, 2) sepconv_pipe_kernel(const
       MIGAN_WAIT_VMCNT(0);
       int rk = 1, rn0 = 0, rb0 = 0, rgy0 = 0, rgx0 = 0;         // tile whose raw pixels are in registers
       if (rk < T) { decode(rk, rn0, rb0, rgy0, rgx0); load_raw(rb0, rgy0, rgx0); }
-      MIGAN_BARRIER_LDS();                                     // P1: taps, fromrgb weights, raw(0) visible (B waits here too)
-      // produce(step s): build its input tile; after the last chunk of a tile, hand the next tile's raw pixels over
+      BuildCursor bcur;
+      build_begin(bcur);
+      MIGAN_BARRIER_LDS();                                     // P1: taps, fromrgb weights, weight planes, raw(0) visible (B waits here too)
+      // produce(step s): build this group's share of its input tile; after the last chunk of a tile, hand the next tile's raw pixels over
       auto produce = [&]() {
-        if (is < G) {
-          build_in(igy0, igx0, ic, islot, ik & 1);
-          const bool last = ic == NKC - 1;
-          advance_issue();
-          if (last && ik < T) {
-            store_raw(ik & 1);                                  // raw(tile ik), last read (as buffer ik & 1) two tiles ago
-            ++rk;
-            if (rk < T) { decode(rk, rn0, rb0, rgy0, rgx0); load_raw(rb0, rgy0, rgx0); }
-          }
+        if (build_step(bcur) && bcur.ik < T) {
+          store_raw(bcur.ik & 1);                               // raw(tile ik): that buffer was last read two tiles ago
+          ++rk;
+          if (rk < T) { decode(rk, rn0, rb0, rgy0, rgx0); load_raw(rb0, rgy0, rgx0); }
         }
       };
       produce();                                               // step 0 -> slot 0
       produce();                                               // step 1 -> slot 1 (+ raw(1) -> LDS)
       MIGAN_BARRIER_LDS();                                     // P2
       depthwise(0, 0, 0);
-      produce();                                               // step 2 -> slot 2
       MIGAN_BARRIER_LDS();                                     // barrier 0
       dslot = 1;
       int dc = 1;
       for (int g = 0; g < G; ++g) {
-        // interval g: B runs the MFMAs of step g; here: depthwise of step g+1, input tile of step g+3
         if (g + 1 < G) depthwise(dslot, dc, (g + 1) & 1);
-        produce();                                             // step g+3 -> slot g % 3 (read by the depthwise stage of step g, one interval ago)
-        dslot = dslot + 1 == R ? 0 : dslot + 1;
+        PPROF_MARK(1);
+        produce();                                             // step g+2 -> slot g & 1
+        PPROF_MARK(0);
+        dslot ^= 1;
         dc = dc + 1 == NKC ? 0 : dc + 1;
         MIGAN_BARRIER_LDS();
+        PPROF_MARK(3);
       }
     } else {
       // ---- prologue: resident weight planes, the first R input chunks in flight -----------------------------------------------------
@@ -347,56 +408,68 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(kPipeThreads, 2) sepconv_pipe_kernel(const
         // MFMAs of step g-1) are free: refill them first, then the depthwise stage of step g+1
         if constexpr (!WRES) { if (g >= 1) issue_b(); }        // step g+1 (steps 0 and 1 were issued by the prologue)
         issue_in();                                            // step g+R
+        PPROF_MARK(0);
         if (g + 1 < G) depthwise(dslot, dc, (g + 1) & 1);
+        PPROF_MARK(1);
         dslot = dslot + 1 == R ? 0 : dslot + 1;
         dc = dc + 1 == NKC ? 0 : dc + 1;
         // before the barrier that starts interval g+1: input of step g+2 and weights of step g+1 landed.  Everything issued before the
         // newest input chunk is then complete, and that chunk (step g+R, R = 3) stays in flight
         if (R == 3 && g + 3 < G) MIGAN_WAIT_VMCNT(DNI); else MIGAN_WAIT_VMCNT(0);
+        PPROF_MARK(2);
         MIGAN_BARRIER_LDS();
+        PPROF_MARK(3);
       }
     }
-    if constexpr (MODE == MODE_UP) {
-      MIGAN_BARRIER_LDS();                                     // the last tile's result tile is published by group B
+    if constexpr (MODE == MODE_UP || TORGB) {
+      MIGAN_BARRIER_LDS();                                     // the last tile: group B publishes its result tile / ToRGB partial sums
     }
+    PPROF_END(AT);
     return;
   }
 
   // ================================================= group B: MFMAs + the previous tile's epilogue ====================================
-  const int tb = tid - 256, wb = wave_u - 4;                    // wave wb owns GEMM rows 32 wb .. 32 wb + 31 (image rows 2 wb, 2 wb + 1 of the tile)
+  const int tb = tid - AT, wb = wave_u - NA;                    // wave wb: GEMM rows 32 rb .. 32 rb + 31, columns cbk NT/2 .. (cbk + 1) NT/2 - 1
+  const int rb = wb >> 1, cbk = wb & 1;
   const int l31 = lane & 31, half = lane >> 5;
-  f16v acc[NTI], accp[NTI];
+  (void)tb;
+  f16v acc[NTIW], accp[NTIW];
 #pragma unroll
-  for (int j = 0; j < NTI; ++j)
+  for (int j = 0; j < NTIW; ++j)
 #pragma unroll
     for (int r = 0; r < 16; ++r) { acc[j][r] = 0.0f; accp[j][r] = 0.0f; }
 
-  auto mfma_chunk = [&](int abuf, int bbuf) {
+  // first: the first product of a tile reads the constant 0 as C (no accumulator clearing at the hand-over)
+  auto mfma_chunk = [&](int abuf, int bbuf, bool first) {
+    if (MIGAN_ABL(8)) return;
     const char* ab = lds + L::OFF_A + abuf * L::A_BUF;
     const char* bb = lds + L::OFF_B + bbuf * L::B_CHUNK;
 #pragma unroll
     for (int ks = 0; ks < KC / 16; ++ks) {
-      f4 av[NPL], bv[NTI][NPL];
+      f4 av[NPL], bv[NTIW][NPL];
       {
-        const int row = wb * 32 + l31;
+        const int row = rb * 32 + l31;
         const char* q = ab + row * PB + (((2 * ks + half) ^ ((row >> 2) & (NSLOT - 1))) << 4);
 #pragma unroll
         for (int pl = 0; pl < NPL; ++pl) av[pl] = ld4(reinterpret_cast<const float*>(q + pl * MT * PB));
       }
 #pragma unroll
-      for (int j = 0; j < NTI; ++j) {
-        const int row = j * 32 + l31;
+      for (int j = 0; j < NTIW; ++j) {
+        const int row = cbk * (NT / 2) + j * 32 + l31;
         const char* q = bb + row * PB + (((2 * ks + half) ^ ((row >> 2) & (NSLOT - 1))) << 4);
 #pragma unroll
         for (int pl = 0; pl < NPL; ++pl) bv[j][pl] = ld4(reinterpret_cast<const float*>(q + pl * NT * PB));
       }
-      // smallest products first; consecutive MFMAs go to different accumulators
+      // smallest products first
 #pragma unroll
-      for (int j = 0; j < NTI; ++j) acc[j] = MIGAN_MFMA_F16_32X32X16(av[1], bv[j][0], acc[j]);
+      for (int j = 0; j < NTIW; ++j) {
+        if (first && ks == 0) acc[j] = f16v{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        acc[j] = MIGAN_MFMA_F16_32X32X16(av[1], bv[j][0], acc[j]);
+      }
 #pragma unroll
-      for (int j = 0; j < NTI; ++j) acc[j] = MIGAN_MFMA_F16_32X32X16(av[0], bv[j][1], acc[j]);
+      for (int j = 0; j < NTIW; ++j) acc[j] = MIGAN_MFMA_F16_32X32X16(av[0], bv[j][1], acc[j]);
 #pragma unroll
-      for (int j = 0; j < NTI; ++j) acc[j] = MIGAN_MFMA_F16_32X32X16(av[0], bv[j][0], acc[j]);
+      for (int j = 0; j < NTIW; ++j) acc[j] = MIGAN_MFMA_F16_32X32X16(av[0], bv[j][0], acc[j]);
     }
   };
 
@@ -408,152 +481,255 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(kPipeThreads, 2) sepconv_pipe_kernel(const
   // coordinates of the tile whose accumulators are in `accp` (pn0 etc.) and of the tile being accumulated (cn0 etc.)
   int ck = 0, cn0 = 0, cb0 = 0, cgy0 = 0, cgx0 = 0, pn0 = 0, pb0 = 0, pgy0 = 0, pgx0 = 0;
   decode(0, cn0, cb0, cgy0, cgx0);
-  bool have_prev = false;
+  auto hand_over = [&]() {
+#pragma unroll
+    for (int j = 0; j < NTIW; ++j) accp[j] = acc[j];
+    pn0 = cn0; pb0 = cb0; pgy0 = cgy0; pgx0 = cgx0;
+    if (++ck < T) decode(ck, cn0, cb0, cgy0, cgx0);
+  };
 
+  BuildCursor bcur;
+  if constexpr (FROMRGB) build_begin(bcur);
   MIGAN_BARRIER_LDS();                                          // P1
+  if constexpr (FROMRGB) {                                      // this group's share of the input tiles of steps 0 and 1
+    build_step(bcur);
+    build_step(bcur);
+  }
   MIGAN_BARRIER_LDS();                                          // P2
   MIGAN_BARRIER_LDS();                                          // barrier 0: A planes of step 0 (and the weight planes) are in LDS
 
   if constexpr (MODE == MODE_NORMAL) {
-    // ---- plain layers: the epilogue runs on the wave's own 32 x NT accumulators, one 32 x 32 block at a time through a wave-private
+    // ---- plain layers: the epilogue runs on the wave's own 32 x NT/2 accumulators, one 32 x 32 block at a time through a wave-private
     // LDS patch (C layout: lane = column, 16 rows per lane -> rows of 32 channels = one 128-byte line per 8 lanes) ----
-    float* const t_s = reinterpret_cast<float*>(lds + L::OFF_T) + wb * (32 * 36);
+    // The patch is [32 pixel rows][32 channels] fp32 with its 16-byte slots XOR-swizzled by (row >> 1) & 7: the column writes
+    // (ds_write_b32, one row per instruction) and the row reads (ds_read_b128) are both conflict-free without padding.
+    float* const t_s = reinterpret_cast<float*>(lds + L::OFF_T) + wb * (32 * 32);
     const int q4 = lane & 7, prow = lane >> 3;                 // this lane's channel quad of a block, its pixel row inside a group of 8
-    float nz[4] = {0.f, 0.f, 0.f, 0.f};                         // noise_const of this lane's 4 pixels (rows 8q + prow) of the tile in `accp`
+    // write side: element r of the fragment is row (r & 3) + 8 (r >> 2) + 4 half, column l31 -> slot (l31 >> 2) ^ ((row >> 1) & 7);
+    // (row >> 1) & 7 = 2 half + s_r with s_r = ((r >> 1) & 1) + 4 ((r >> 2) & 1) in {0, 1, 4, 5}: four lane addresses + constant row offsets
+    int twr[4];
+    {
+      const int u = (l31 >> 2) ^ (2 * half);
+#pragma unroll
+      for (int v = 0; v < 4; ++v) twr[v] = (4 * half) * 32 + ((u ^ ((v & 1) + 4 * (v >> 1))) << 2) + (l31 & 3);
+    }
+    // read side: row 8 q + prow, slot q4 ^ ((prow >> 1) + 4 (q & 1))
+    const int trd0 = prow * 32 + ((q4 ^ (prow >> 1)) << 2), trd1 = prow * 32 + ((q4 ^ (prow >> 1) ^ 4) << 2);
+    float nz[4] = {0.f, 0.f, 0.f, 0.f};                         // noise_const of this lane's 4 pixels (rows 8q + prow) of the tile being finished
     float nzn[4] = {0.f, 0.f, 0.f, 0.f};                        // ... of the tile being accumulated (requested one K step before the hand-over)
-    float rs[4][3];                                             // ToRGB partial sums of those pixels
+    float rs[4][3];                                             // ToRGB partial sums of those pixels over this wave's columns
     unsigned pix0 = 0;                                          // output pixel index of row prow of the wave's first image row
-    f4 tw[NTI][3];
+    f4 tw[NTIW][3];
+    float tbias[3] = {0.f, 0.f, 0.f};                           // (read once: a load inside the tile loop would wait for every store before it)
     if constexpr (TORGB) {
 #pragma unroll
-      for (int j = 0; j < NTI; ++j)
+      for (int ch = 0; ch < 3; ++ch) tbias[ch] = p.trgb_b[ch];
 #pragma unroll
-        for (int ch = 0; ch < 3; ++ch) tw[j][ch] = ld4(p.trgb_w + ch * p.CO + j * 32 + q4 * 4);
+      for (int j = 0; j < NTIW; ++j)
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) tw[j][ch] = ld4(p.trgb_w + ch * p.CO + cbk * (NT / 2) + j * 32 + q4 * 4);
     }
-    // pixel of (q, lane): GEMM row m = 32 wb + 8 q + prow -> tile row 2 wb + (q >> 1), column 8 (q & 1) + prow.
-    // The noise values of the NEXT tile are loaded before the last store slice of the previous one is issued, and only used a K step
-    // later: the wait in front of their first use then leaves those stores in flight (vmcnt retires in issue order).
-    auto request_noise = [&]() {
-      if (has_noise) {
-        const unsigned px = (unsigned)((cgy0 + 2 * wb) * p.WO + cgx0 + prow);
+    // ToRGB tail (reference :308-313), run by the waves of column half 0: lane q4 < 4 of each 8-lane pixel group finishes pixel q = q4 of
+    // the group: own sums + the other half's (through LDS) + bias + the 2x-upsampled previous image, whose 2x2 taps per colour it holds in pv
+    float pv[3][4], pvn[3][4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) nzn[q] = p.noise[px + (unsigned)((q >> 1) * p.WO + (q & 1) * 8)];
+    for (int ch = 0; ch < 3; ++ch)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) pv[ch][e] = pvn[ch][e] = 0.0f;
+    float* const part_s = reinterpret_cast<float*>(lds + L::OFF_P) + rb * (32 * 4);
+    // pixel of (q, lane): GEMM row m = 32 rb + 8 q + prow -> tile row 2 rb + (q >> 1), column 8 (q & 1) + prow.
+    // Everything the next epilogue loads (noise values, previous-image taps) is requested before the last store slice of the previous
+    // tile is issued, and only used a K step later: the wait in front of the first use then leaves those stores in flight.
+    // (uniform base pointer + 32-bit lane byte offset: the saddr + voffset form, no 64-bit address arithmetic)
+    auto request_next = [&]() {
+      if (has_noise) {
+        const unsigned px = (unsigned)((cgy0 + 2 * rb) * p.WO + cgx0 + prow) * 4u;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) nzn[q] = *at_bytes(p.noise + ((q >> 1) * p.WO + (q & 1) * 8), px);
+      }
+      if constexpr (TORGB) {
+        if (p.img_prev && cbk == 0 && q4 < 4) {
+          // 2x2 taps of Upsample2d under output pixel (oy, ox): clamped coordinates, combined by up_combine (zero outside)
+          const int oy = cgy0 + 2 * rb + (q4 >> 1), ox = cgx0 + (q4 & 1) * 8 + prow;
+          const int hp = p.HO >> 1, wp = p.WO >> 1;
+          const int y0 = (oy & 1) ? (oy >> 1) : (oy >> 1) - 1, x0 = (ox & 1) ? (ox >> 1) : (ox >> 1) - 1;
+          const int cy0 = y0 >= 0 ? y0 : 0, cy1 = y0 + 1 < hp ? y0 + 1 : hp - 1, cx0 = x0 >= 0 ? x0 : 0, cx1 = x0 + 1 < wp ? x0 + 1 : wp - 1;
+          const unsigned o00 = (unsigned)(cy0 * wp + cx0) * 4u, o01 = (unsigned)(cy0 * wp + cx1) * 4u;
+          const unsigned o10 = (unsigned)(cy1 * wp + cx0) * 4u, o11 = (unsigned)(cy1 * wp + cx1) * 4u;
+          const size_t plane4 = (size_t)hp * wp;
+#pragma unroll
+          for (int ch = 0; ch < 3; ++ch) {
+            const float* pl = p.img_prev + ((size_t)cb0 * 3 + ch) * plane4;
+            pvn[ch][0] = *at_bytes(pl, o00); pvn[ch][1] = *at_bytes(pl, o01);
+            pvn[ch][2] = *at_bytes(pl, o10); pvn[ch][3] = *at_bytes(pl, o11);
+          }
+        }
       }
     };
     auto begin_tile_epilogue = [&]() {
-      pix0 = (unsigned)((pgy0 + 2 * wb) * p.WO + pgx0 + prow);
+      pix0 = (unsigned)((pgy0 + 2 * rb) * p.WO + pgx0 + prow);
 #pragma unroll
       for (int q = 0; q < 4; ++q) nz[q] = nzn[q];
       if constexpr (TORGB) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) rs[q][0] = rs[q][1] = rs[q][2] = 0.0f;
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) pv[ch][e] = pvn[ch][e];
       }
     };
-    auto epi_block = [&](const f16v& a, int j) {
-      // accumulator fragment -> patch: lane holds column l31, rows (r & 3) + 8 (r >> 2) + 4 half
+    // A block of accumulators goes through the patch in three moves that sit in DIFFERENT places of the K step, so that no LDS round
+    // trip is waited for: stage (16 ds_write_b32, at the hand-over or right after the previous block's rows were consumed), fetch
+    // (4 ds_read_b128, issued before the step's MFMAs) and finish (noise, activation, store, ToRGB share -- after the MFMAs).
+    auto stage_block = [&](const f16v& a) {
+      if (MIGAN_ABL(2)) return;
+      MIGAN_WAVE_SYNC();                                        // (rows of the previous block were read by other lanes of this wave)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) t_s[((r & 3) + 8 * (r >> 2) + 4 * half) * 36 + l31] = a[r];
+      for (int r = 0; r < 16; ++r) t_s[twr[((r >> 1) & 1) + 2 * ((r >> 2) & 1)] + ((r & 3) + 8 * (r >> 2)) * 32] = a[r];
       MIGAN_WAVE_SYNC();
+    };
+    f4 tv[4];
+    auto fetch_block = [&]() {
+      if (MIGAN_ABL(2)) return;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) tv[q] = ld4(t_s + ((q & 1) ? trd1 : trd0) + q * 8 * 32);
+    };
+    auto finish_block = [&](int j) {
+      if (MIGAN_ABL(2)) return;
       char* yb = reinterpret_cast<char*>(p.y) + (size_t)pb0 * img_out_bytes;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        f4 v = ld4(t_s + (8 * q + prow) * 36 + q4 * 4);
-        v = v * acc_scale + MIGAN_FMUL_RN(nz[q], ns);               // product rounded first, reference :166
+        f4 v = tv[q] * acc_scale + MIGAN_FMUL_RN(nz[q], ns);        // product rounded first, reference :166
         v = act4(v);
         const unsigned pix = pix0 + (unsigned)((q >> 1) * p.WO + (q & 1) * 8);
-        Io<0>::st(yb, (pix * (unsigned)p.CO + (unsigned)(pn0 + j * 32 + q4 * 4)) * 4u, v);
+        if (!MIGAN_ABL(1)) Io<0>::st(yb, (pix * (unsigned)p.CO + (unsigned)(pn0 + cbk * (NT / 2) + j * 32 + q4 * 4)) * 4u, v);
         if constexpr (TORGB) {
           float r0, r1, r2;
           torgb_partial(v, tw[j][0], tw[j][1], tw[j][2], r0, r1, r2);
           rs[q][0] += r0; rs[q][1] += r1; rs[q][2] += r2;
         }
       }
-      MIGAN_WAVE_SYNC();                                        // the patch is rewritten by the next block
     };
-    auto end_tile_epilogue = [&]() {
-      if constexpr (TORGB) {
-        // sum the 8 lanes of a pixel (butterfly inside groups of 8), then lane q4 == 0 adds bias + the 2x-upsampled previous image
-        // (reference :308-313) and writes the three planes
+    // after a wave's last block: its per-pixel partial sums (8 lanes per pixel); column half 1 hands them to the wave of half 0 that
+    // owns the same rows
+    float mine[3] = {0.f, 0.f, 0.f};
+    auto rgb_partials = [&]() {
+      if (MIGAN_ABL(2)) return;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float s0 = MIGAN_SUM8(rs[q][0]), s1 = MIGAN_SUM8(rs[q][1]), s2 = MIGAN_SUM8(rs[q][2]);
+        if (q4 == q) { mine[0] = s0; mine[1] = s1; mine[2] = s2; }
+      }
+      if (cbk == 1 && q4 < 4) st4(part_s + (8 * q4 + prow) * 4, f4{mine[0], mine[1], mine[2], 0.0f});
+    };
+    auto rgb_finish = [&]() {                                   // (one barrier after rgb_partials)
+      if (MIGAN_ABL(2)) return;
+      if (cbk == 0 && q4 < 4) {
+        const f4 other = ld4(part_s + (8 * q4 + prow) * 4);
         const size_t plane = (size_t)p.HO * p.WO;
+        const int oy = pgy0 + 2 * rb + (q4 >> 1), ox = pgx0 + (q4 & 1) * 8 + prow;
+        // (scalar adds kept apart: the packed form of these sums is the op_sel hazard of DESIGN 5.7, refused by the ISA lint)
+        float o3[3] = {mine[0] + other.x, mine[1] + other.y, mine[2] + other.z};
+        MIGAN_OPAQUE_F(o3[0]); MIGAN_OPAQUE_F(o3[1]); MIGAN_OPAQUE_F(o3[2]);
+        o3[0] += tbias[0]; MIGAN_OPAQUE_F(o3[0]);
+        o3[1] += tbias[1]; MIGAN_OPAQUE_F(o3[1]);
+        o3[2] += tbias[2]; MIGAN_OPAQUE_F(o3[2]);
+        if (p.img_prev) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          float s0 = rs[q][0], s1 = rs[q][1], s2 = rs[q][2];
-          s0 += MIGAN_SWIZZLE_XOR(s0, 1); s1 += MIGAN_SWIZZLE_XOR(s1, 1); s2 += MIGAN_SWIZZLE_XOR(s2, 1);
-          s0 += MIGAN_SWIZZLE_XOR(s0, 2); s1 += MIGAN_SWIZZLE_XOR(s1, 2); s2 += MIGAN_SWIZZLE_XOR(s2, 2);
-          s0 += MIGAN_SWIZZLE_XOR(s0, 4); s1 += MIGAN_SWIZZLE_XOR(s1, 4); s2 += MIGAN_SWIZZLE_XOR(s2, 4);
-          if (q4 == 0) {
-            const int oy = pgy0 + 2 * wb + (q >> 1), ox = pgx0 + (q & 1) * 8 + prow;
-            float o3[3] = {s0 + p.trgb_b[0], s1 + p.trgb_b[1], s2 + p.trgb_b[2]};
-            if (p.img_prev) {
-              const size_t plane4 = plane >> 2;
+          for (int ch = 0; ch < 3; ++ch) o3[ch] = up_combine(pv[ch], oy, ox, p.HO >> 1, p.WO >> 1) + o3[ch];
+        }
+        if (p.u8_out) {
+          compose_pixel(p.u8_img, p.u8_mask, p.u8_out, (size_t)pb0 * plane + (size_t)oy * p.WO + ox, o3[0], o3[1], o3[2]);
+        } else {
+          const unsigned po = (unsigned)(oy * p.WO + ox) * 4u;
 #pragma unroll
-              for (int ch = 0; ch < 3; ++ch) {
-                float pv[4];
-                up_taps(p.img_prev + ((size_t)pb0 * 3 + ch) * plane4, p.HO >> 1, p.WO >> 1, oy, ox, pv);
-                o3[ch] = up_combine(pv, oy, ox, p.HO >> 1, p.WO >> 1) + o3[ch];
-              }
-            }
-            if (p.u8_out) {
-              compose_pixel(p.u8_img, p.u8_mask, p.u8_out, (size_t)pb0 * plane + (size_t)oy * p.WO + ox, o3[0], o3[1], o3[2]);
-            } else {
-#pragma unroll
-              for (int ch = 0; ch < 3; ++ch) p.img_out[((size_t)pb0 * 3 + ch) * plane + (size_t)oy * p.WO + ox] = o3[ch];
-            }
-          }
+          for (int ch = 0; ch < 3; ++ch) *at_bytes(p.img_out + ((size_t)pb0 * 3 + ch) * plane, po) = o3[ch];
         }
       }
     };
-    // slice c of a tile's epilogue = the blocks j with j * NKC / NTI == c (NTI <= NKC: at most one block per step)
-    for (int t = 0; t < T; ++t) {
+    // slice c of a tile's epilogue: block c (c < NTIW); the partial ToRGB sums after the last block; the ToRGB tail one step later.
+    // The first tile is peeled off (nothing to finish under it): inside the steady-state loop every load -> use pair then sits on ONE
+    // control path, so the compiler's waitcnt pass can count the stores issued in between instead of falling back to vmcnt(0) (a
+    // "previous tile exists" branch around the uses made it drain every store of the wave once per tile: 2.9k cycles, measured).
+#pragma unroll
+    for (int c = 0; c < NKC; ++c) {
+      mfma_chunk(c & 1, WRES ? c : (c & 1), c == 0);
+      if (c == NKC - 1) {
+        request_next();
+        hand_over();
+        stage_block(accp[0]);
+      }
+      if constexpr (FROMRGB) build_step(bcur);                  // this group's share of the input tile two steps ahead
+      MIGAN_BARRIER_LDS();
+    }
+    for (int t = 1; t < T; ++t) {
 #pragma unroll
       for (int c = 0; c < NKC; ++c) {
-        mfma_chunk(c & 1, WRES ? c : (c & 1));
-        if (c == NKC - 1) request_noise();
-        if (have_prev) {
-#pragma unroll
-          for (int j = 0; j < NTI; ++j)
-            if ((NTI >= NKC ? j / (NTI / NKC) : j * (NKC / NTI)) == c) epi_block(accp[j], j);
-          if (c == NKC - 1) end_tile_epilogue();
+        PPROF_MARK(7);
+        if (c < NTIW) fetch_block();                            // rows of block c: on their way while the MFMAs run
+        mfma_chunk(c & 1, WRES ? c : (c & 1), c == 0);
+        PPROF_MARK(4);
+        if (c == NKC - 1) request_next();
+        PPROF_MARK(12);
+        if (c == 0) begin_tile_epilogue();                      // (first use of what request_next asked for a K step ago)
+        PPROF_MARK(5);
+        if (c < NTIW) {
+          finish_block(c);
+          if (c + 1 < NTIW) stage_block(accp[c + 1 < NTIW ? c + 1 : 0]);
+        }
+        PPROF_MARK(9);
+        if constexpr (TORGB) {
+          if (c == NTIW - 1) rgb_partials();
+          PPROF_MARK(10);
+          if (c == NTIW) rgb_finish();
+          PPROF_MARK(11);
         }
         if (c == NKC - 1) {
-#pragma unroll
-          for (int j = 0; j < NTI; ++j) {
-            accp[j] = acc[j];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
-          }
-          pn0 = cn0; pb0 = cb0; pgy0 = cgy0; pgx0 = cgx0;
-          have_prev = true;
-          if (++ck < T) decode(ck, cn0, cb0, cgy0, cgx0);
-          begin_tile_epilogue();                               // its noise values are requested a whole K step before their first use
+          hand_over();
+          stage_block(accp[0]);
         }
+        PPROF_MARK(7);
+        if constexpr (FROMRGB) build_step(bcur);
+        PPROF_MARK(13);
         MIGAN_BARRIER_LDS();
+        PPROF_MARK(6);
       }
     }
     // the last tile: nothing left to hide it under
+    begin_tile_epilogue();
 #pragma unroll
-    for (int j = 0; j < NTI; ++j) epi_block(accp[j], j);
-    end_tile_epilogue();
+    for (int j = 0; j < NTIW; ++j) {
+      fetch_block();
+      finish_block(j);
+      if (j + 1 < NTIW) stage_block(accp[j + 1 < NTIW ? j + 1 : 0]);
+    }
+    if constexpr (TORGB) {
+      rgb_partials();
+      MIGAN_BARRIER_LDS();                                      // (group A joins this one)
+      rgb_finish();
+    }
   } else {
     // ---- FIR-up layers (reference Upsample2d :79-103 after the 1x1): the 2x polyphase FIR needs the 3x3 neighbourhood of the GEMM
     // result, so the accumulators of a finished tile go to a dedicated LDS result tile during the first K step of the next tile
     // (published by that step's barrier) and the 6 x 14 interior pixels x NT/4 channel quads are worked off in the steps after it ----
     constexpr int GS = NT + 4, QN = NT / 4, LG_QN = (QN == 16) ? 4 : 5;
     static_assert(QN == 16 || QN == 32, "FIR-up tiles: 64 or 128 output channels");
-    constexpr int STEP = 256 >> LG_QN;                          // GEMM rows between the items of a thread
-    constexpr int ITEMS = MT * QN / 256;
+    constexpr int BT = kPipeBWaves * 64;
+    constexpr int STEP = BT >> LG_QN;                           // GEMM rows between the items of a thread
+    constexpr int ITEMS = MT * QN / BT;
     float* const g_s = reinterpret_cast<float*>(lds + L::OFF_T);
     auto acc_to_lds = [&]() {
 #pragma unroll
-      for (int j = 0; j < NTI; ++j)
+      for (int j = 0; j < NTIW; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const int row = wb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+          const int row = rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
           // halo pixels outside the low-resolution image contribute zeros to the FIR (reference pads with zeros :101)
           const int ly = pgy0 + (row >> lgGW), lx = pgx0 + (row & (GW - 1));
           float v = accp[j][r];
           if (ly < 0 || ly >= p.H || lx < 0 || lx >= p.W) v = 0.0f;
-          g_s[row * GS + j * 32 + l31] = v;
+          g_s[row * GS + cbk * (NT / 2) + j * 32 + l31] = v;
         }
     };
     const int c4 = tb & (QN - 1), m0 = tb >> LG_QN;
@@ -589,6 +765,7 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(kPipeThreads, 2) sepconv_pipe_kernel(const
         }
     };
     auto item_finish = [&](int k, const ItemIo& io) {
+      if (MIGAN_ABL(2)) return;
       int m;
       unsigned lpix, loff;
       if (!item_geo(k, m, lpix, loff)) return;
@@ -613,58 +790,59 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(kPipeThreads, 2) sepconv_pipe_kernel(const
           f4 v = out[a][bb] * acc_scale + MIGAN_FMUL_RN(io.nzv[a][bb], ns);    // product rounded first, reference :166
           v = act4(v);
           v += io.sk[a][bb];
-          Io<0>::st(yb, loff + (unsigned)(a * p.WO + bb) * (unsigned)p.CO * 4u, v);
+          if (!MIGAN_ABL(1)) Io<0>::st(yb, loff + (unsigned)(a * p.WO + bb) * (unsigned)p.CO * 4u, v);
         }
     };
-    // items of slice c (c = 1 .. NKC-1): an even share of the items that can be interior rows of the 8 x 16 grid (tile rows 1..6)
-    constexpr int SL = NKC - 1, K0 = GW / STEP, K1 = ITEMS - K0;
-    auto slice_of = [](int k) { return 1 + (k - K0) * SL / (K1 - K0); };
+    // items of slice c (c = 1 .. NKC-1): an even share of the thread's ITEMS rows
+    constexpr int SL = NKC - 1;
+    auto slice_of = [](int k) { return 1 + k * SL / ITEMS; };
     ItemIo io[2];
-    for (int t = 0; t < T; ++t) {
+    // (first tile peeled off, for the reason given in the plain form)
+#pragma unroll
+    for (int c = 0; c < NKC; ++c) {
+      mfma_chunk(c & 1, WRES ? c : (c & 1), c == 0);
+      if (c == NKC - 1) hand_over();
+      MIGAN_BARRIER_LDS();
+    }
+    for (int t = 1; t < T; ++t) {
 #pragma unroll
       for (int c = 0; c < NKC; ++c) {
         // (the first item of this step's slice asks for its noise / skip values before the MFMAs)
-        if (have_prev && c >= 1) {
+        if (c >= 1) {
 #pragma unroll
-          for (int k = K0; k < K1; ++k)
-            if (slice_of(k) == c && (k == K0 || slice_of(k - 1) != c)) item_load(k, io[k & 1]);
+          for (int k = 0; k < ITEMS; ++k)
+            if (slice_of(k) == c && (k == 0 || slice_of(k - 1) != c)) item_load(k, io[k & 1]);
         }
-        mfma_chunk(c & 1, WRES ? c : (c & 1));
-        if (have_prev) {
-          if (c == 0) {
-            acc_to_lds();                                       // (the previous result tile was consumed before the last barrier)
-          } else {
+        PPROF_MARK(7);
+        mfma_chunk(c & 1, WRES ? c : (c & 1), c == 0);
+        PPROF_MARK(4);
+        if (c == 0) {
+          acc_to_lds();                                         // (the previous result tile was consumed before the last barrier)
+        } else {
 #pragma unroll
-            for (int k = K0; k < K1; ++k)
-              if (slice_of(k) == c) {
-                if (k + 1 < K1 && slice_of(k + 1) == c) item_load(k + 1, io[(k + 1) & 1]);
-                item_finish(k, io[k & 1]);
-              }
-          }
+          for (int k = 0; k < ITEMS; ++k)
+            if (slice_of(k) == c) {
+              if (k + 1 < ITEMS && slice_of(k + 1) == c) item_load(k + 1, io[(k + 1) & 1]);
+              item_finish(k, io[k & 1]);
+            }
         }
-        if (c == NKC - 1) {
-#pragma unroll
-          for (int j = 0; j < NTI; ++j) {
-            accp[j] = acc[j];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
-          }
-          pn0 = cn0; pb0 = cb0; pgy0 = cgy0; pgx0 = cgx0;
-          have_prev = true;
-          if (++ck < T) decode(ck, cn0, cb0, cgy0, cgx0);
-        }
+        if (c == NKC - 1) hand_over();
+        PPROF_MARK(5);
         MIGAN_BARRIER_LDS();
+        PPROF_MARK(6);
       }
     }
     acc_to_lds();
     MIGAN_BARRIER_LDS();                                        // (group A joins this one)
-    item_load(K0, io[K0 & 1]);
+    item_load(0, io[0]);
 #pragma unroll
-    for (int k = K0; k < K1; ++k) {
-      if (k + 1 < K1) item_load(k + 1, io[(k + 1) & 1]);
+    for (int k = 0; k < ITEMS; ++k) {
+      if (k + 1 < ITEMS) item_load(k + 1, io[(k + 1) & 1]);
       item_finish(k, io[k & 1]);
     }
   }
+  PPROF_MARK(5);
+  PPROF_END(AT);
 }
 
 }  // namespace migan

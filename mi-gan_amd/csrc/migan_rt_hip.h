@@ -45,6 +45,19 @@ __device__ __forceinline__ float migan_swizzle_xor(float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), ((M << 10) | 0x1f)));
 }
 #define MIGAN_SWIZZLE_XOR(v, m) migan_swizzle_xor<(m)>(v)
+// sum over aligned groups of 8 lanes, result in every lane of the group: three v_add_f32_dpp (quad_perm [1,0,3,2], quad_perm [2,3,0,1],
+// row_half_mirror) -- VALU only, no LDS crossbar; same summation tree as an xor-1/2/4 butterfly
+template <int CTRL>
+__device__ __forceinline__ float migan_dpp_get(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float migan_sum8(float v) {
+  v += migan_dpp_get<0xB1>(v);
+  v += migan_dpp_get<0x4E>(v);
+  v += migan_dpp_get<0x141>(v);
+  return v;
+}
+#define MIGAN_SUM8(v) migan_sum8(v)
 #define MIGAN_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 // instruction-class pipeline hints for the machine scheduler: the next `n` instructions of class `mask` (0x8 MFMA, 0x20 VMEM
 // read, 0x100 DS read, 0x200 DS write) form one group; groups are laid out in the order these calls appear

@@ -90,7 +90,7 @@ struct KernelSlice {
 struct PipeEntry {
   int mode, NT, cin;
   bool fromrgb, torgb;
-  int ring;
+  int ring, na;         // LDS ring depth; waves of the depthwise group (the workgroup has na + 8 waves)
   SepKernelFn fn;
   const char* name;     // the symbol as rocprofv3 prints it
   size_t lds_bytes;

@@ -4,7 +4,7 @@
 // (mi-gan_amd/csrc/migan_kernels.hpp) and the same host plan / C ABI (migan_host.hpp) without a GPU,
 // to check tile indexing, LDS carving, barrier placement and the MFMA fragment mapping.
 //
-// Model: one workgroup = 64..512 lanes (whole waves), each lane a user-level fiber (hand-rolled x86-64 context switch)
+// Model: one workgroup = 64..1024 lanes (whole waves), each lane a user-level fiber (hand-rolled x86-64 context switch)
 // on ONE OS thread; lanes run to the next collective (__syncthreads, MFMA, shuffle) and then yield
 // round-robin.  Lane 0 therefore runs arbitrarily far ahead of lane 255 between barriers, which is
 // the most adversarial legal schedule: a missing barrier shows up as a wrong result.  LDS is filled
@@ -48,7 +48,7 @@ struct Lane {
   std::vector<DmaOp> dma;      // outstanding LDS-DMAs, oldest first
 };
 
-constexpr int kMaxLanes = 512;
+constexpr int kMaxLanes = 1024;
 constexpr int kMaxWaves = kMaxLanes / 64;
 constexpr size_t kStackBytes = 96 * 1024;
 
@@ -136,6 +136,13 @@ void run_grid(void (*invoke)(const void*), const void* arg, unsigned grid, unsig
 inline float __shfl_xor(float v, int mask);
 #define MIGAN_CLAMP(v, lo, hi) fminf(fmaxf((v), (lo)), (hi))
 #define MIGAN_SWIZZLE_XOR(v, m) __shfl_xor((v), (m))
+inline float hipemu_sum8(float v) {
+  v += __shfl_xor(v, 1);
+  v += __shfl_xor(v, 2);
+  v += __shfl_xor(v, 4);
+  return v;
+}
+#define MIGAN_SUM8(v) hipemu_sum8(v)
 #define MIGAN_SCHED_FENCE() do {} while (0)
 #define MIGAN_SCHED_GROUP(mask, n) do { (void)(mask); (void)(n); } while (0)
 #define MIGAN_STORE_NT(ptr, v) (*(ptr) = (v))

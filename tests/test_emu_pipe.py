@@ -20,15 +20,19 @@ def pkg():
     return importlib.import_module("mi-gan_amd")
 
 
-@pytest.fixture(autouse=True)
-def small_grids(lib):
+# both workgroup shapes: 4 or 8 waves in the depthwise group (12- / 16-wave workgroups)
+@pytest.fixture(autouse=True, params=[4, 8])
+def small_grids(request, lib):
     # the emulator cases have a few dozen tiles: let them take the pipelined kernels, a few tiles per workgroup
     lib.set_tuning("pipe_min_tiles", 1)
     lib.set_tuning("pipe_grid", 8)
+    lib.set_tuning("pipe_na", request.param)
+    lib.set_tuning("pipe", 7)          # every form, also the ones the default plan leaves to the one-tile kernels
     yield
     lib.set_tuning("pipe_min_tiles", 256)
     lib.set_tuning("pipe_grid", 256)
-    lib.set_tuning("pipe", 7)
+    lib.set_tuning("pipe", 5)
+    lib.set_tuning("pipe_na", 4)
 
 
 PIPE = "migan::sepconv_pipe_kernel<"
