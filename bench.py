@@ -72,6 +72,14 @@ def parse(argv=None):
                          "last kernels, migan_forward_u8); the all-gather then moves uint8 shards (4x fewer bytes)")
     ap.add_argument("--cpu-images", type=int, default=4, help="sample size of the CPU baseline (0 = skip)")
     ap.add_argument("--no-gather", action="store_true", help="N>1: skip the output all-gather")
+    ap.add_argument("--gather-dtype", type=str, default="auto", choices=["auto", "f32", "f16", "u8"],
+                    help="N>1: what the ranks exchange.  auto = the forward's own output (fp32 [n,3,R,R], 100.7 MB per rank and step at "
+                         "migan-512 x 32; uint8 [n,R,R,3], 25.2 MB, with --io u8); f16 = the fp32 output rounded to fp16 before the gather "
+                         "(half the bytes; |y| ~ 30, so ~1e-2 absolute: not for parity runs); u8 requires --io u8")
+    ap.add_argument("--reserve-cus", type=int, default=0, metavar="K",
+                    help="N>1: run the forward on a HIP stream whose CU mask leaves K CUs (a multiple of 8: K/8 per XCD) to the RCCL "
+                         "kernels of the overlapped all-gather, instead of letting them queue behind 256-CU-wide layers "
+                         "(hipExtStreamCreateWithCUMask; implies --streams 1, the library's own side streams are not masked)")
     ap.add_argument("--force-pg", action="store_true",
                     help="N=1: also create a one-rank NCCL (= RCCL) process group and time the same steps through the pipelined output "
                          "gather (rccl_world1 on the line): the collective path on the hardware without a second GPU")
@@ -90,7 +98,12 @@ def parse(argv=None):
     ap.add_argument("--dry", action="store_true",
                     help="exercise rank spawning, the process group, the output gather and the JSON line without a GPU: the forward\n"
                          "is replaced by a copy (tests only; the line says so and carries no throughput claim)")
-    return ap.parse_args(argv)
+    a = ap.parse_args(argv)
+    if a.reserve_cus:
+        if a.reserve_cus % 8 or not (0 < a.reserve_cus < 256):
+            ap.error("--reserve-cus must be a multiple of 8 between 8 and 248")
+        a.streams = 1                                        # the library's own side streams carry no CU mask
+    return a
 
 
 def split_model(args):
@@ -380,12 +393,21 @@ def run_workload(args, rank, local_rank, world, dist, dev):
     gather = world > 1 and not args.no_gather
     # N > 1: every step's output shards are all-gathered (RCCL) into one of two buffers; the gather of step i runs on
     # RCCL's stream while step i+1 computes, and every gather completes inside the timed region (fence()).
-    pipe = pkg.distributed.OutputGather(wl["out_shape"], wl.get("out_dtype", torch.float32), dev) if gather else None
+    gdt = gather_dtype_of(args, wl.get("out_dtype", torch.float32))
+    pipe = pkg.distributed.OutputGather(wl["out_shape"], gdt, dev) if gather else None
+    # --reserve-cus K: the forward runs on a CU-masked stream so that the RCCL kernels of the overlapped gather find free CUs
+    masked = pkg.distributed.cu_masked_stream(dev, args.reserve_cus) if (args.reserve_cus and not args.dry) else None
 
     def step():
-        y = wl["step"]()
+        if masked is not None:
+            masked.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(masked):
+                y = wl["step"]()
+            torch.cuda.current_stream(dev).wait_stream(masked)
+        else:
+            y = wl["step"]()
         if gather:
-            pipe.submit(y)
+            pipe.submit(y if y.dtype == gdt else y.to(gdt))
         return y
 
     def fence():
@@ -536,7 +558,10 @@ def run_workload(args, rank, local_rank, world, dist, dev):
         out[wl["alt"]["key"]] = alt
     if gather:
         out["compute_only_ms_per_step"] = round(compute_only, 4)
-        out["gather_mb_per_rank_per_step"] = round(float(np.prod(wl["out_shape"])) * (1 if wl.get("out_dtype") == torch.uint8 else 4) / 1e6, 1)
+        out["gather_mb_per_rank_per_step"] = round(float(np.prod(wl["out_shape"])) * torch.empty(0, dtype=gdt).element_size() / 1e6, 1)
+        out["gather_dtype"] = str(gdt).replace("torch.", "")
+    if args.reserve_cus:
+        out["reserved_cus"] = args.reserve_cus
     return out
 
 
@@ -615,6 +640,19 @@ def secondary_line(base_args, **over):
     return out
 
 
+def gather_dtype_of(args, out_dtype):
+    """what the ranks exchange (--gather-dtype)"""
+    if args.gather_dtype == "auto":
+        return out_dtype
+    if args.gather_dtype == "u8":
+        if args.io != "u8":
+            raise SystemExit("--gather-dtype u8 needs --io u8 (the composed uint8 image is what migan_forward_u8 writes)")
+        return torch.uint8
+    if args.io == "u8":
+        raise SystemExit("--io u8 exchanges uint8 shards; --gather-dtype f32 / f16 apply to the fp32 output")
+    return torch.float16 if args.gather_dtype == "f16" else torch.float32
+
+
 def dry_run(args, rank, world, dist):
     """--dry: the launch / rendezvous / gather / JSON plumbing on any backend, without the HIP library"""
     pkg = importlib.import_module("mi-gan_amd")
@@ -624,11 +662,12 @@ def dry_run(args, rank, world, dist):
     shape = (batch, 8, 8, 3) if u8 else (batch, 3, 8, 8)
     y = torch.full(shape, rank, dtype=torch.uint8 if u8 else torch.float32)
     gather = world > 1 and not args.no_gather
-    pipe = pkg.distributed.OutputGather(shape, y.dtype, dev) if gather else None
+    gdt = gather_dtype_of(args, y.dtype)
+    pipe = pkg.distributed.OutputGather(shape, gdt, dev) if gather else None
     t0 = time.perf_counter()
     for _ in range(args.steps):
         if gather:
-            slot = pipe.submit(y)
+            slot = pipe.submit(y.to(gdt))
     if gather:
         pipe.drain()
         full = pipe.result(slot)
@@ -647,7 +686,8 @@ def dry_run(args, rank, world, dist):
             "warmup": args.warmup, "ms_per_step": round(el / max(1, args.steps) * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.dtype, "data": "none (--dry: launch plumbing only, no forward was run)",
             "config": {"workload": "dry run", "global_batch": world * batch, "parallelism": f"batch-shard x{world}"},
-            "dry": True, "rccl_ranks": ranks_seen, "backend": args.backend, "gather_dtype": str(y.dtype).replace("torch.", "")}
+            "dry": True, "rccl_ranks": ranks_seen, "backend": args.backend, "gather_dtype": str(gdt).replace("torch.", ""),
+            "gather_mb_per_rank_per_step": round(float(np.prod(shape)) * torch.empty(0, dtype=gdt).element_size() / 1e6, 6)}
 
 
 def worker(rank, local_rank, world, args):

@@ -237,6 +237,10 @@ const char* migan_last_error(void);
 /* Symbol (as rocprofv3 prints it) of the fused-SeparableConv2d kernel the calling thread launched last, "" before the first launch:
  * which tile form / schedule the plan picked for a layer and batch (diagnostics and tests). */
 const char* migan_last_kernel(void);
+/* What the clamp of lrelu_agc (reference :21-23) does with a NaN in THIS build of the library: "clamp" (default build: v_med3_f32 maps it to
+ * -256, like the reference's CUDA plugin bias_act.cu:139) or "propagate" (libmigan_hip_strictnan.so, built with -DMIGAN_STRICT_NAN: a NaN stays
+ * a NaN, like Tensor.clamp in the reference module). */
+const char* migan_nan_policy(void);
 /* "hip:gfx950" for the product library. */
 const char* migan_backend(void);
 /* The process default of how the 1x1 convolutions are multiplied (environment MIGAN_GEMM=f32|bf16x3|f16x2, read once

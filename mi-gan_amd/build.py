@@ -112,6 +112,55 @@ def build(force: bool = False, verbose: bool = False, extra: Sequence[str] = (),
     return OUT
 
 
+STRICT_NAN_OUT = os.path.join(CSRC, "libmigan_hip_strictnan.so")
+
+
+def build_variant(name: str, extra: Sequence[str], force: bool = False, verbose: bool = False) -> str:
+    """another build of the same library under libmigan_hip_<name>.so (objects in csrc/_obj_<name>/): the NaN-propagating variant
+    (-DMIGAN_STRICT_NAN) and the measurement builds (scripts/build_variant.py)"""
+    out = os.path.join(CSRC, f"libmigan_hip_{name}.so")
+    stamp = out + ".flags"
+    if (not force and os.path.exists(out) and os.path.exists(stamp) and open(stamp).read().strip() == flags_digest(extra)
+            and os.path.getmtime(out) >= max(os.path.getmtime(s) for s in SOURCES)):
+        return out
+    obj = os.path.join(CSRC, f"_obj_{name}")
+    os.makedirs(obj, exist_ok=True)
+    us = []
+    for o, cmd in units(extra):
+        o2 = os.path.join(obj, os.path.basename(o))
+        us.append((o2, cmd[:-1] + [o2]))
+
+    def run(u):
+        if verbose:
+            print(" ".join(u[1]), flush=True)
+        r = subprocess.run(u[1], cwd=CSRC, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"hipcc failed ({r.returncode}) on {os.path.basename(u[0])}:\n{r.stderr[-4000:]}")
+        return u[0]
+
+    with ThreadPoolExecutor(max_workers=min(len(us), os.cpu_count() or 1)) as ex:
+        objs = list(ex.map(run, us))
+    r = subprocess.run([hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC", *objs, "-o", out], cwd=CSRC, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"link failed ({r.returncode}):\n{r.stderr[-4000:]}")
+    with open(stamp, "w") as f:
+        f.write(flags_digest(extra) + "\n")
+    return out
+
+
+def build_strict_nan(force: bool = False, verbose: bool = False) -> str:
+    """libmigan_hip_strictnan.so: the same library with Tensor.clamp's NaN propagation (Generator(nan_policy="propagate"))"""
+    out = build_variant("strictnan", ["-DMIGAN_STRICT_NAN"], force=force, verbose=verbose)
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("migan_isa_lint", os.path.join(HERE, "isa_lint.py"))
+    isa_lint = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(isa_lint)
+    if isa_lint.available():
+        isa_lint.check(out)
+    return out
+
+
 if __name__ == "__main__":
     import sys
     print(build(force="--force" in sys.argv, verbose=True,

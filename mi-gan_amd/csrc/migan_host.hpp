@@ -103,13 +103,12 @@ struct Tuning {
   int stagger = -1;            // MIGAN_STAGGER: launch index of the first half after which the second half starts (-1: plan default)
   int debug_split = 0;         // diagnostics: keep the two-sub-batch execution in keep-intermediates mode
   int stagger_pct = 22;        // MIGAN_STAGGER_PCT: the next sub-batch starts after this share of a forward's launches
-  int pipe = 5;                // MIGAN_PIPE bit mask: software-pipelined persistent kernels (sepconv_pipe_kernel; fp32 storage, f16x2 GEMM) for
-                               // 1 plain (+ fused ToRGB) layers, 2 the fused-FromRGB layer, 4 FIR-up layers -- wherever an instantiation exists.
-                               // Default 5: synthesis.b512.conv1 -11 %, synthesis.b512.conv2 -6 %; the fused-FromRGB form (encoder.b512.conv1)
-                               // is instruction-issue bound by the tile build and only ties the one-tile kernel (profiles/r04_pipe_*)
+  int pipe = 7;                // MIGAN_PIPE bit mask: software-pipelined persistent kernels (sepconv_pipe_kernel; fp32 storage, f16x2 GEMM) for
+                               // 1 plain (+ fused ToRGB) layers, 2 the fused-FromRGB layer, 4 FIR-up layers -- wherever an instantiation exists
+                               // (the 512 x 512 layers of migan-512: -5 / -10 / -9 % per layer, profiles/r04_pipe_layers.txt)
   int pipe_grid = 256;         // MIGAN_PIPE_GRID: persistent workgroups of those launches (one 12- or 16-wave workgroup per CU on MI355X)
   int pipe_na = 4;             // waves of the depthwise group of those workgroups (4 or 8), for the layers in pipe_na8 the other value
-  int pipe_na8 = 0;            // bit mask like `pipe`: layers that take 8 depthwise waves
+  int pipe_na8 = 3;            // bit mask like `pipe`: layers that take the other count (default: plain and fused-FromRGB layers run 8 + 8 waves, FIR-up 4 + 8)
   int pipe_min_tiles = 256;    // launches with fewer tiles keep the one-tile-per-workgroup kernels
 };
 inline Tuning& tuning() {
@@ -731,7 +730,7 @@ struct migan_handle {
   }
   void ensure_aux();
   void run_range(const migan::Plan& P, const float* x, float* y, int n, char* sub_ws, char* shared, rt::stream_t stream,
-                 bool timed, int mid_after, int part, const migan_io_u8* u8);
+                 bool timed, int mid_after, int part, const migan_io_u8* u8, int n_geo = 0);
   void forward(migan::Plan& P, const float* x, float* y, int batch, void* ws, size_t ws_bytes, rt::stream_t stream, float* ms,
                int n_ms, const migan_io_u8* u8 = nullptr);
 };
@@ -984,7 +983,7 @@ inline void migan_handle::ensure_aux() {
 
 // launches of one sub-batch of n images on `stream`
 inline void migan_handle::run_range(const migan::Plan& P, const float* x, float* y, int n, char* sub_ws, char* shared,
-                                    rt::stream_t stream, bool timed, int mid_after, int part, const migan_io_u8* u8) {
+                                    rt::stream_t stream, bool timed, int mid_after, int part, const migan_io_u8* u8, int n_geo) {
   using namespace migan;
   std::vector<size_t> offs(P.bufs.size());
   for (size_t i = 0; i < P.bufs.size(); ++i) offs[i] = sub_offset(P, (int)i, n);
@@ -1031,8 +1030,11 @@ inline void migan_handle::run_range(const migan::Plan& P, const float* x, float*
       for (const Geo& gs : L.g_small) {
         // K-split tiles sum K in another order than every other tile (four partial sums): single-image forwards only, so that an
         // image of a batch of two or more is bit-identical whatever the batch size and the sub-batch grouping
-        if (gs.NT == 32 && n != 1) continue;
-        if ((int)tiles_of(gs, n) <= tuning().small_max_wgs) { Gp = &gs; break; }
+        // (n_geo: the sub-batch size the production forward launches with -- the per-launch timing run covers the whole batch in one
+        // launch but must time the kernels the throughput run uses)
+        const int ng = n_geo > 0 ? n_geo : n;
+        if (gs.NT == 32 && ng != 1) continue;
+        if ((int)tiles_of(gs, ng) <= tuning().small_max_wgs) { Gp = &gs; break; }
       }
       const Geo& G = *Gp;
       fill_geo(a, G);
@@ -1100,6 +1102,7 @@ inline void migan_handle::forward(migan::Plan& P, const float* x, float* y, int 
   }
   int nsub[kMaxStreams];
   int parts = split(batch, nsub);
+  const int n_production = nsub[0];              // what a launch of the throughput path covers
   if (timed) { nsub[0] = batch; parts = 1; }     // per-launch durations: one stream, whole-batch launches (the split workspace always fits them)
   const size_t in_img = (size_t)4 * P.H * P.W, out_img = (size_t)3 * P.H * P.W;
   if (parts > 1) {
@@ -1126,7 +1129,7 @@ inline void migan_handle::forward(migan::Plan& P, const float* x, float* y, int 
     }
     for (int k = 1; k < parts; ++k) rt_check(rt::stream_wait_event(stream, ev_join[k - 1]), "hipStreamWaitEvent");
   } else {
-    run_range(P, x, y, nsub[0], sub0, shared, stream, timed, -1, 0, u8);
+    run_range(P, x, y, nsub[0], sub0, shared, stream, timed, -1, 0, u8, timed ? n_production : 0);
   }
   if (timed) {
     rt_check(rt::stream_sync(stream), "hipStreamSynchronize");
@@ -1677,6 +1680,13 @@ int migan_set_tuning(const char* key, int value) {
 
 const char* migan_last_error(void) { return migan::last_error_ref().c_str(); }
 const char* migan_last_kernel(void) { return migan::last_kernel_ref(); }
+const char* migan_nan_policy(void) {
+#ifdef MIGAN_STRICT_NAN
+  return "propagate";
+#else
+  return "clamp";
+#endif
+}
 const char* migan_backend(void) { return rt::backend_name(); }
 const char* migan_gemm_variant(void) {
   const int g = migan::tuning().gemm;

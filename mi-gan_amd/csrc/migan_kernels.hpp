@@ -1281,7 +1281,7 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(kWideThreads, 2) sepconv_wide_kernel(const
     }
   }
   const MIGAN_BUF xbuf = MIGAN_MAKE_BUF(xb, (unsigned)(p.H * p.W * p.CI) * OE);
-  const MIGAN_BUF wbuf = MIGAN_MAKE_BUF(p.wsplit, 0x7ffffff0u);
+  const MIGAN_BUF wbuf = MIGAN_MAKE_BUF(p.wsplit, (unsigned)(NPL * p.CO * p.CI) * 2u);     // the planes' real extent: a wrong lane offset reads zeros, not memory
   auto load_taps = [&](int k0) {
     if (tid < KC * 9 / 4) rw = ld4(p.wdw + (size_t)k0 * 9 + (unsigned)(tid * 4));
     else if (tid < NW4) rw = ld4(p.bdw + k0 + (unsigned)((tid - KC * 9 / 4) * 4));

@@ -105,15 +105,37 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(pipe_threads(NA), (NA + kPipeBWaves) / 4) 
   // phase profile (-DMIGAN_PHASE_PROF builds): group A -> slots 0..3 [DMA issue + offsets / tile build, depthwise, vmcnt wait, barrier],
   // group B -> slots 4..7 [MFMAs, epilogue slice, barrier, rest]
   PPROF_BEGIN();
-  auto decode = [&](int k, int& n0_, int& b0_, int& gy0_, int& gx0_) {
-    int t = tbase + tl0 + k * tstep;
-    const int nch = t % p.nchunks; t /= p.nchunks;
-    const int tx = t % p.tiles_x;  t /= p.tiles_x;
-    const int ty = t % p.tiles_y;
-    n0_ = nch * NT;
-    b0_ = t / p.tiles_y;
-    gy0_ = ty * p.sy - p.off;
-    gx0_ = tx * p.sx - p.off;
+  // A workgroup's tiles are tstep apart in the logical order (column chunk fastest, then x, y, image): every cursor below walks them with
+  // a mixed-radix add of tstep (computed once; scalar ALU only) instead of dividing a tile number by run-time extents once per tile.
+  struct TileCur {
+    int n, x, y, b;
+  };
+  const int st_n = tstep % p.nchunks, st_r1 = tstep / p.nchunks;
+  const int st_x = st_r1 % p.tiles_x, st_r2 = st_r1 / p.tiles_x;
+  const int st_y = st_r2 % p.tiles_y, st_b = st_r2 / p.tiles_y;
+  TileCur tile0;
+  {
+    int t = tbase + tl0;
+    tile0.n = t % p.nchunks; t /= p.nchunks;
+    tile0.x = t % p.tiles_x; t /= p.tiles_x;
+    tile0.y = t % p.tiles_y;
+    tile0.b = t / p.tiles_y;
+  }
+  auto tile_next = [&](TileCur& c) {
+    int carry = 0;
+    c.n += st_n;
+    if (c.n >= p.nchunks) { c.n -= p.nchunks; carry = 1; }
+    c.x += st_x + carry; carry = 0;
+    if (c.x >= p.tiles_x) { c.x -= p.tiles_x; carry = 1; }
+    c.y += st_y + carry; carry = 0;
+    if (c.y >= p.tiles_y) { c.y -= p.tiles_y; carry = 1; }
+    c.b += st_b + carry;
+  };
+  auto tile_coords = [&](const TileCur& c, int& n0_, int& b0_, int& gy0_, int& gx0_) {
+    n0_ = c.n * NT;
+    b0_ = c.b;
+    gy0_ = c.y * p.sy - p.off;
+    gx0_ = c.x * p.sx - p.off;
   };
 
   // ---- FROMRGB: the input tile is act(fromrgb(network input)) (reference :194-195), BUILT instead of copied -- by every thread of the
@@ -123,6 +145,7 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(pipe_threads(NA), (NA + kPipeBWaves) / 4) 
   struct BuildCursor {
     int is, ic, ik, slot, gy0, gx0, b0;
     unsigned mask;                                       // bit j = item j of this thread is a pixel inside the image
+    TileCur tc;
   };
   auto build_mask = [&](BuildCursor& bc) {
     bc.mask = 0;
@@ -139,8 +162,9 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(pipe_threads(NA), (NA + kPipeBWaves) / 4) 
   };
   auto build_begin = [&](BuildCursor& bc) {
     bc.is = bc.ic = bc.ik = bc.slot = 0;
+    bc.tc = tile0;
     int n0_;
-    decode(0, n0_, bc.b0, bc.gy0, bc.gx0);
+    tile_coords(bc.tc, n0_, bc.b0, bc.gy0, bc.gx0);
     build_mask(bc);
   };
   // build this thread's share of step bc.is into its ring slot, then move the cursor on; returns true when that was the last chunk of a tile
@@ -167,7 +191,8 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(pipe_threads(NA), (NA + kPipeBWaves) / 4) 
     bc.ic = 0;
     if (++bc.ik < T) {
       int n0_;
-      decode(bc.ik, n0_, bc.b0, bc.gy0, bc.gx0);
+      tile_next(bc.tc);
+      tile_coords(bc.tc, n0_, bc.b0, bc.gy0, bc.gx0);
       build_mask(bc);
     }
     return true;
@@ -217,8 +242,27 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(pipe_threads(NA), (NA + kPipeBWaves) / 4) 
 
     // ---- input tile of one K chunk -> ring slot.  The image is a buffer descriptor: a halo pixel outside it (the conv's zero padding,
     // reference :126) is a lane offset beyond its range and arrives as zeros; so do the padding units of the slot ----
-    unsigned dgoff[DNI];
+    // Interior tiles (the whole 10 x 18 halo window inside the image: 9 of 10 tiles at 512 x 512) use offsets relative to the window's
+    // first pixel, computed once per workgroup; the window's position rides in the scalar offset of the DMA.  Border tiles compute
+    // absolute offsets with the out-of-range marker on padding pixels.
+    unsigned dgoff[DNI], drel[DNI], tile_soff = 0;
+#pragma unroll
+    for (int j = 0; j < DNI; ++j) {
+      const int i = lt + j * AT;
+      drel[j] = 0xfffff000u;
+      if (i < NITEMS) {
+        const int c4 = i & (QC - 1), pix = i >> LG_QC;
+        drel[j] = (unsigned)(((pix / IGW) * p.W + (pix % IGW)) * CIN + c4 * 4) * 4u;
+      }
+    }
     auto make_dgoff = [&](int gy0_, int gx0_) {
+      if (gy0_ >= 1 && gy0_ + GH + 1 <= p.H && gx0_ >= 1 && gx0_ + GW + 1 <= p.W) {
+#pragma unroll
+        for (int j = 0; j < DNI; ++j) dgoff[j] = drel[j];
+        tile_soff = (unsigned)(((gy0_ - 1) * p.W + (gx0_ - 1)) * CIN) * 4u;
+        return;
+      }
+      tile_soff = 0;
 #pragma unroll
       for (int j = 0; j < DNI; ++j) {
         const int i = lt + j * AT;
@@ -238,7 +282,7 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(pipe_threads(NA), (NA + kPipeBWaves) / 4) 
       float* in_s = reinterpret_cast<float*>(lds + L::OFF_IN + slot * L::IN_SLOT);
       const MIGAN_BUF xbuf = MIGAN_MAKE_BUF(reinterpret_cast<const char*>(p.x) + (size_t)b0_ * img_bytes, img_bytes);
 #pragma unroll
-      for (int j = 0; j < DNI; ++j) MIGAN_LDS_DMA16(xbuf, dgoff[j], (unsigned)(chunk * KC) * 4u, in_s + (j * AT + wave_u * 64) * 4);
+      for (int j = 0; j < DNI; ++j) MIGAN_LDS_DMA16(xbuf, dgoff[j], tile_soff + (unsigned)(chunk * KC) * 4u, in_s + (j * AT + wave_u * 64) * 4);
     };
 
     // ---- FROMRGB: the raw 4-channel network input of the halo tile, one tile ahead, through registers into LDS (this group) ----------
@@ -310,7 +354,8 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(pipe_threads(NA), (NA + kPipeBWaves) / 4) 
 
     // ---- cursors: the step whose input is issued / built next (is), the step whose weights are issued next (bs: streamed planes only) --
     int is = 0, ic = 0, ik = 0, islot = 0, ib0 = 0, in0 = 0, igy0 = 0, igx0 = 0;
-    decode(0, in0, ib0, igy0, igx0);
+    TileCur itc = tile0;
+    tile_coords(itc, in0, ib0, igy0, igx0);
     if constexpr (!FROMRGB) make_dgoff(igy0, igx0);
     auto advance_issue = [&]() {
       ++is;
@@ -318,7 +363,8 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(pipe_threads(NA), (NA + kPipeBWaves) / 4) 
       if (++ic == NKC) {
         ic = 0;
         if (++ik < T) {
-          decode(ik, in0, ib0, igy0, igx0);
+          tile_next(itc);
+          tile_coords(itc, in0, ib0, igy0, igx0);
           if constexpr (!FROMRGB) make_dgoff(igy0, igx0);
         }
       }
@@ -330,13 +376,14 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(pipe_threads(NA), (NA + kPipeBWaves) / 4) 
       }
     };
     int bs = 0, bc = 0, bk = 0, bn0 = in0;
+    TileCur btc = tile0;
     auto issue_b = [&]() {                               // streamed weight planes of step bs -> slot bs & 1
       if (bs < G) {
         dma_b(bn0, bc, bs & 1);
         ++bs;
         if (++bc == NKC) {
           bc = 0;
-          if (++bk < T) { int b_, y_, x_; decode(bk, bn0, b_, y_, x_); }
+          if (++bk < T) { tile_next(btc); bn0 = btc.n * NT; }
         }
       }
     };
@@ -352,7 +399,8 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(pipe_threads(NA), (NA + kPipeBWaves) / 4) 
       store_raw(0);
       MIGAN_WAIT_VMCNT(0);
       int rk = 1, rn0 = 0, rb0 = 0, rgy0 = 0, rgx0 = 0;         // tile whose raw pixels are in registers
-      if (rk < T) { decode(rk, rn0, rb0, rgy0, rgx0); load_raw(rb0, rgy0, rgx0); }
+      TileCur rtc = tile0;
+      if (rk < T) { tile_next(rtc); tile_coords(rtc, rn0, rb0, rgy0, rgx0); load_raw(rb0, rgy0, rgx0); }
       BuildCursor bcur;
       build_begin(bcur);
       MIGAN_BARRIER_LDS();                                     // P1: taps, fromrgb weights, weight planes, raw(0) visible (B waits here too)
@@ -361,7 +409,7 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(pipe_threads(NA), (NA + kPipeBWaves) / 4) 
         if (build_step(bcur) && bcur.ik < T) {
           store_raw(bcur.ik & 1);                               // raw(tile ik): that buffer was last read two tiles ago
           ++rk;
-          if (rk < T) { decode(rk, rn0, rb0, rgy0, rgx0); load_raw(rb0, rgy0, rgx0); }
+          if (rk < T) { tile_next(rtc); tile_coords(rtc, rn0, rb0, rgy0, rgx0); load_raw(rb0, rgy0, rgx0); }
         }
       };
       produce();                                               // step 0 -> slot 0
@@ -429,8 +477,10 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(pipe_threads(NA), (NA + kPipeBWaves) / 4) 
   }
 
   // ================================================= group B: MFMAs + the previous tile's epilogue ====================================
-  const int tb = tid - AT, wb = wave_u - NA;                    // wave wb: GEMM rows 32 rb .. 32 rb + 31, columns cbk NT/2 .. (cbk + 1) NT/2 - 1
-  const int rb = wb >> 1, cbk = wb & 1;
+  const int tb = tid - AT, wb = wave_u - NA;                    // wave wb = 4 cbk + rb: GEMM rows 32 rb .. 32 rb + 31, columns cbk NT/2 .. (cbk + 1) NT/2 - 1
+  // (waves go to SIMDs round-robin: rb = wb & 3 puts one wave of each column half on every SIMD, so the ToRGB tail -- run by half 0 -- and
+  // the hand-off writes of half 1 are spread over all four)
+  const int rb = wb & 3, cbk = wb >> 2;
   const int l31 = lane & 31, half = lane >> 5;
   (void)tb;
   f16v acc[NTIW], accp[NTIW];
@@ -480,12 +530,13 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(pipe_threads(NA), (NA + kPipeBWaves) / 4) 
 
   // coordinates of the tile whose accumulators are in `accp` (pn0 etc.) and of the tile being accumulated (cn0 etc.)
   int ck = 0, cn0 = 0, cb0 = 0, cgy0 = 0, cgx0 = 0, pn0 = 0, pb0 = 0, pgy0 = 0, pgx0 = 0;
-  decode(0, cn0, cb0, cgy0, cgx0);
+  TileCur ctc = tile0;
+  tile_coords(ctc, cn0, cb0, cgy0, cgx0);
   auto hand_over = [&]() {
 #pragma unroll
-    for (int j = 0; j < NTIW; ++j) accp[j] = acc[j];
+    for (int j = (MODE == MODE_NORMAL ? 1 : 0); j < NTIW; ++j) accp[j] = acc[j];      // (plain layers stage block 0 straight from `acc`)
     pn0 = cn0; pb0 = cb0; pgy0 = cgy0; pgx0 = cgx0;
-    if (++ck < T) decode(ck, cn0, cb0, cgy0, cgx0);
+    if (++ck < T) { tile_next(ctc); tile_coords(ctc, cn0, cb0, cgy0, cgx0); }
   };
 
   BuildCursor bcur;
@@ -657,8 +708,8 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(pipe_threads(NA), (NA + kPipeBWaves) / 4) 
       mfma_chunk(c & 1, WRES ? c : (c & 1), c == 0);
       if (c == NKC - 1) {
         request_next();
+        stage_block(acc[0]);
         hand_over();
-        stage_block(accp[0]);
       }
       if constexpr (FROMRGB) build_step(bcur);                  // this group's share of the input tile two steps ahead
       MIGAN_BARRIER_LDS();
@@ -686,8 +737,8 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(pipe_threads(NA), (NA + kPipeBWaves) / 4) 
           PPROF_MARK(11);
         }
         if (c == NKC - 1) {
+          stage_block(acc[0]);
           hand_over();
-          stage_block(accp[0]);
         }
         PPROF_MARK(7);
         if constexpr (FROMRGB) build_step(bcur);

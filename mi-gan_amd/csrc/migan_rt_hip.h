@@ -36,7 +36,18 @@ __device__ __forceinline__ float migan_f16hi_f32(unsigned pk) { return (float)__
 #define MIGAN_F16HI_F32(pk) migan_f16hi_f32(pk)
 #define MIGAN_MFMA_F16_32X32X16(a, b, c) \
   __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(migan_f16x8, (a)), __builtin_bit_cast(migan_f16x8, (b)), (c), 0, 0, 0)
+// The clamp of lrelu_agc (reference :21-23).  Default: v_med3_f32, which returns lo for a NaN (what the reference's CUDA plugin does,
+// bias_act.cu:139).  -DMIGAN_STRICT_NAN (libmigan_hip_strictnan.so, Generator(nan_policy="propagate")): Tensor.clamp's behaviour, a NaN stays
+// a NaN -- one v_cmp_u_f32 + v_cndmask_b32 per value on top.
+#ifdef MIGAN_STRICT_NAN
+__device__ __forceinline__ float migan_clamp_nan(float v, float lo, float hi) {
+  const float c = __builtin_amdgcn_fmed3f(v, lo, hi);
+  return v != v ? v : c;
+}
+#define MIGAN_CLAMP(v, lo, hi) migan_clamp_nan((v), (lo), (hi))
+#else
 #define MIGAN_CLAMP(v, lo, hi) __builtin_amdgcn_fmed3f((v), (lo), (hi))     // v_med3_f32
+#endif
 // ds_swizzle bit mode: lane' = ((lane & and_mask) | or_mask) ^ xor_mask inside groups of 32 lanes
 // (a function, not a macro body: __builtin_bit_cast applied directly to a vector element lvalue such as `v.y`
 // reads element 0 with this compiler; passing the float by value is safe)

@@ -106,3 +106,27 @@ class OutputGather:
     def drain(self) -> None:
         for slot in range(len(self.bufs)):
             self.result(slot)
+
+
+def cu_masked_stream(device, reserve_cus: int, total_cus: int = 256, xcds: int = 8):
+    """A HIP stream restricted to total_cus - reserve_cus compute units (hipExtStreamCreateWithCUMask), wrapped as a
+    torch.cuda.ExternalStream: kernels launched on it leave ``reserve_cus`` CUs (reserve_cus / xcds on every XCD) to whatever else
+    is running -- here the RCCL kernels of the overlapped output all-gather, which otherwise queue behind layers that fill all
+    256 CUs of an MI355X.  CU i of the mask is bit i (logical CU numbering: XCD = i % xcds, as workgroups are dealt)."""
+    import ctypes
+    if reserve_cus <= 0 or reserve_cus % xcds or reserve_cus >= total_cus:
+        raise ValueError(f"reserve_cus must be a positive multiple of {xcds} below {total_cus}")
+    device = torch.device(device)
+    per_xcd = reserve_cus // xcds
+    words = [0] * ((total_cus + 31) // 32)
+    for cu in range(total_cus):
+        if cu // xcds >= per_xcd:                      # the first per_xcd CUs of every XCD stay free
+            words[cu // 32] |= 1 << (cu % 32)
+    hip = ctypes.CDLL("libamdhip64.so")
+    stream = ctypes.c_void_p()
+    mask = (ctypes.c_uint32 * len(words))(*words)
+    with torch.cuda.device(device):
+        rc = hip.hipExtStreamCreateWithCUMask(ctypes.byref(stream), ctypes.c_uint32(len(words)), mask)
+    if rc != 0:
+        raise RuntimeError(f"hipExtStreamCreateWithCUMask failed with {rc}")
+    return torch.cuda.ExternalStream(stream.value, device=device)

@@ -68,7 +68,7 @@ EXPORTS = (
     "migan_forward_timed", "migan_set_debug", "migan_debug_tensor", "migan_sepconv_forward",
     "migan_pack_input", "migan_compose_output",
     "migan_pipeline_mask_resize", "migan_pipeline_scratch_bytes", "migan_pipeline_bbox", "migan_pipeline_pre", "migan_pipeline_post",
-    "migan_set_tuning", "migan_last_error", "migan_last_kernel", "migan_backend", "migan_gemm_variant", "migan_version",
+    "migan_set_tuning", "migan_last_error", "migan_last_kernel", "migan_nan_policy", "migan_backend", "migan_gemm_variant", "migan_version",
     # include/comodgan_hip.h
     "comodgan_create", "comodgan_destroy", "comodgan_num_weights", "comodgan_weight_info", "comodgan_set_weight",
     "comodgan_commit", "comodgan_workspace_bytes", "comodgan_assume_static_weights", "comodgan_noise_floats", "comodgan_forward",
@@ -98,6 +98,15 @@ class MiganLib:
                 f"{self.path} not found: the MI355X HIP extension is not built. "
                 f"Run `python -c 'import __graft_entry__ as g; g.build()'` (hipcc --offload-arch=gfx950). "
                 f"There is no CPU/PyTorch fallback for this path.")
+        # the in-tree product library must be the product build: build.py stamps it with a digest of its compile flags, and a measurement
+        # build (-DMIGAN_ABLATE / -DMIGAN_PHASE_PROF) left under this name would otherwise be picked up silently
+        if os.path.abspath(self.path) == os.path.abspath(os.path.join(_HERE, "csrc", _LIBNAME)):
+            stamp = self.path + ".flags"
+            if os.path.exists(stamp):
+                from . import build as _build
+                if open(stamp).read().strip() != _build.flags_digest(()):
+                    raise MiganError(f"{self.path} was not built with the product flags (stamp {stamp} differs): rebuild with "
+                                     f"`python -c 'import __graft_entry__ as g; g.build()'`; measurement builds go under another name")
         try:
             self.lib = C.CDLL(self.path)
         except OSError as e:  # pragma: no cover - depends on the machine
@@ -157,6 +166,7 @@ class MiganLib:
         L.comodgan_debug_tensor.argtypes = [vp, ci, C.c_char_p, C.POINTER(C.c_size_t), C.POINTER(C.c_int64), C.POINTER(ci)]
         L.migan_last_error.restype = C.c_char_p
         L.migan_last_kernel.restype = C.c_char_p
+        L.migan_nan_policy.restype = C.c_char_p
         L.migan_backend.restype = C.c_char_p
         L.migan_gemm_variant.restype = C.c_char_p
         L.migan_backend.restype = C.c_char_p
@@ -164,7 +174,7 @@ class MiganLib:
             raise MiganError(f"{self.path} reports backend {L.migan_backend().decode()!r}, not {PRODUCT_BACKEND!r}: only the gfx950 HIP "
                              f"library is a product backend (the CPU emulator build is test infrastructure)")
         for name in EXPORTS:
-            if name not in ("migan_last_error", "migan_last_kernel", "migan_backend", "migan_gemm_variant"):
+            if name not in ("migan_last_error", "migan_last_kernel", "migan_nan_policy", "migan_backend", "migan_gemm_variant"):
                 getattr(L, name).restype = ci
 
     # -- error mapping: EINVAL -> ValueError-like, like the reference's constructor / load_state_dict
@@ -185,6 +195,10 @@ class MiganLib:
 
     def gemm_variant(self) -> str:
         return self.lib.migan_gemm_variant().decode()
+
+    def nan_policy(self) -> str:
+        """"clamp" (default build) or "propagate" (libmigan_hip_strictnan.so): what lrelu_agc's clamp does with a NaN"""
+        return self.lib.migan_nan_policy().decode()
 
     def last_kernel(self) -> str:
         """symbol of the fused-SeparableConv2d kernel this thread launched last"""
@@ -454,11 +468,23 @@ class CoModGANHandle:
 _LIB: Optional[MiganLib] = None
 
 
-def load_library(path: Optional[str] = None) -> MiganLib:
-    """Process-wide libmigan_hip.so (raises MiganError when it is not built)."""
-    global _LIB
+_STRICT_LIB: Optional["MiganLib"] = None
+
+
+def load_library(path: Optional[str] = None, nan_policy: str = "clamp") -> MiganLib:
+    """Process-wide libmigan_hip.so (raises MiganError when it is not built).  nan_policy="propagate": the build of the same library
+    whose clamp keeps a NaN a NaN, like Tensor.clamp in the reference module (libmigan_hip_strictnan.so, -DMIGAN_STRICT_NAN)."""
+    global _LIB, _STRICT_LIB
+    if nan_policy not in ("clamp", "propagate"):
+        raise ValueError(f"nan_policy must be 'clamp' or 'propagate', got {nan_policy!r}")
     if path is not None:
         return MiganLib(path)
+    if nan_policy == "propagate":
+        if _STRICT_LIB is None:
+            _STRICT_LIB = MiganLib(os.path.join(_HERE, "csrc", "libmigan_hip_strictnan.so"))
+            if _STRICT_LIB.nan_policy() != "propagate":
+                raise MiganError("libmigan_hip_strictnan.so was not built with -DMIGAN_STRICT_NAN")
+        return _STRICT_LIB
     if _LIB is None:
         _LIB = MiganLib()
     return _LIB

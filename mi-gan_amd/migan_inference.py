@@ -217,11 +217,17 @@ def _init_tensor(e: schema.Entry) -> torch.Tensor:
 class Generator(nn.Module):
     """MI-GAN inference generator (reference migan_inference.py:355-369) on MI355X."""
 
-    def __init__(self, resolution: int = 256, activation_dtype="f32"):
+    def __init__(self, resolution: int = 256, activation_dtype="f32", nan_policy: str = "clamp"):
         """resolution: as the reference (:356).  activation_dtype (extension): storage format of the feature maps between
         layers on the GPU -- "f32" (the reference's precision, <= 1e-3 parity), "bf16" (BASELINE configs[1]) or "f16";
-        parameters, input, output and all arithmetic stay float32 (include/migan_hip.h, MIGAN_DTYPE_*)."""
+        parameters, input, output and all arithmetic stay float32 (include/migan_hip.h, MIGAN_DTYPE_*).
+        nan_policy (extension): "clamp" (default) -- a NaN activation leaves lrelu_agc's clamp as -256, as in the reference's CUDA
+        plugin; "propagate" -- it stays a NaN, as Tensor.clamp does in the reference module (:21-23); runs the -DMIGAN_STRICT_NAN
+        build of the library (a few per cent slower: two more VALU instructions per activation)."""
         super().__init__()
+        if nan_policy not in ("clamp", "propagate"):
+            raise ValueError(f"nan_policy must be 'clamp' or 'propagate', got {nan_policy!r}")
+        self._nan_policy = nan_policy
         schema.check_resolution(resolution)                    # ValueError like reference :215-216
         if resolution > schema.MAX_RESOLUTION:
             raise NotImplementedError(
@@ -340,7 +346,7 @@ class Generator(nn.Module):
     def _engine(self, x: torch.Tensor) -> MiganHandle:
         dev = self._require_device(x)
         if self._lib is None:
-            self._lib = load_library()                         # raises MiganError when not built
+            self._lib = load_library(nan_policy=self._nan_policy)      # raises MiganError when not built
         if self._handle is None or self._handle_device != dev:
             if self._handle is not None:
                 self._handle.close()
@@ -442,6 +448,6 @@ class Generator(nn.Module):
     def launch_info(self):
         """Per-launch layer / kernel names and algorithmic flops and bytes per image."""
         if self._lib is None:
-            self._lib = load_library()
+            self._lib = load_library(nan_policy=self._nan_policy)
         h = self._handle or MiganHandle(self._lib, self.resolution, 0, dtype=self._act_dtype)
         return h.launches()        # kernel names reflect the variants used by the last forward on this handle

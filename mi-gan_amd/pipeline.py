@@ -75,18 +75,36 @@ class MIGAN_Pipeline(torch.nn.Module):
         self._scratch = None
 
     def _scratch_for(self, lib, h: int, w: int, device) -> torch.Tensor:
+        """scratch of the bbox / post kernels, one buffer per (device, stream): two streams running the pipeline never share it"""
         need = lib.pipeline_scratch_bytes(h, w)
-        if self._scratch is None or self._scratch.numel() < need or self._scratch.device != device:
-            self._scratch = torch.empty(need, dtype=torch.uint8, device=device)
-        return self._scratch
+        key = (device.index if device.index is not None else torch.cuda.current_device(), int(torch.cuda.current_stream(device).cuda_stream))
+        if self._scratch is None:
+            self._scratch = {}
+        buf = self._scratch.get(key)
+        if buf is None or buf.numel() < need:
+            buf = torch.empty(need, dtype=torch.uint8, device=device)
+            self._scratch[key] = buf
+        return buf
+
+    @staticmethod
+    def _check_mask(mask: torch.Tensor) -> torch.Tensor:
+        if not mask.is_cuda:
+            raise RuntimeError("mi-gan_amd.pipeline needs tensors on an MI355X (HIP) device; there is no CPU path")
+        if mask.dtype != torch.uint8:
+            raise RuntimeError("mask must be uint8 (reference create_onnx_pipeline.py:254-255)")
+        if mask.dim() != 4 or mask.shape[0] != 1 or mask.shape[1] != 1:
+            raise RuntimeError(f"expected mask (1, 1, h, w), got {list(mask.shape)}")
+        return mask.contiguous()
 
     def get_masked_bbox(self, mask: torch.Tensor):
         """(:132-231) -> x_min, x_max, y_min, y_max"""
+        mask = self._check_mask(mask)
         lib = load_library()
         h, w = int(mask.shape[-2]), int(mask.shape[-1])
-        scratch = self._scratch_for(lib, h, w, mask.device)
-        return lib.pipeline_bbox(mask.data_ptr(), h, w, self.res, self.padding, scratch.data_ptr(),
-                                 int(torch.cuda.current_stream(mask.device).cuda_stream))
+        with torch.cuda.device(mask.device):                      # the handle-free entry points launch on the CURRENT device
+            scratch = self._scratch_for(lib, h, w, mask.device)
+            return lib.pipeline_bbox(mask.data_ptr(), h, w, self.res, self.padding, scratch.data_ptr(),
+                                     int(torch.cuda.current_stream(mask.device).cuda_stream))
 
     @torch.no_grad()
     def forward(self, image: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
@@ -97,9 +115,13 @@ class MIGAN_Pipeline(torch.nn.Module):
         if image.dim() != 4 or image.shape[0] != 1 or image.shape[1] != 3 or not image.is_contiguous():
             raise RuntimeError(f"expected a contiguous image (1, 3, H, W), got {list(image.shape)}")
         h, w = int(image.shape[2]), int(image.shape[3])
-        if mask.dim() != 4 or mask.shape[0] != 1 or mask.shape[1] != 1:
-            raise RuntimeError(f"expected mask (1, 1, h, w), got {list(mask.shape)}")
-        mask = mask.contiguous()
+        mask = self._check_mask(mask)
+        if mask.device != image.device:
+            raise RuntimeError("image and mask must be on the same device")
+        with torch.cuda.device(image.device):                     # the handle-free entry points launch on the CURRENT device
+            return self._forward_on_device(image, mask, h, w)
+
+    def _forward_on_device(self, image: torch.Tensor, mask: torch.Tensor, h: int, w: int) -> torch.Tensor:
         lib = load_library()
         stream = int(torch.cuda.current_stream(image.device).cuda_stream)
         if tuple(mask.shape[2:]) != (h, w):                      # mask = tvF.resize(mask, image size, NEAREST) (:256)

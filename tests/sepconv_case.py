@@ -66,7 +66,7 @@ def weights(pkg, cin, cout, seed, res_out, noise, wscale=1.0):
 
 
 def run_sepconv_case(lib, pkg, mem, *, cin, cout, h, w=None, batch, down=1, up=1, noise=False, skip=False, seed=1, storage="f32",
-                     gemm=-1, fromrgb=False, torgb=False, with_prev=False, wscale=1.0):
+                     gemm=-1, fromrgb=False, torgb=False, with_prev=False, wscale=1.0, nan_at=None):
     w = w or h
     ho, wo = (h // 2, w // 2) if down == 2 else ((h * 2, w * 2) if up == 2 else (h, w))
     sd = weights(pkg, cin, cout, seed, (ho, wo), noise, wscale)
@@ -92,6 +92,8 @@ def run_sepconv_case(lib, pkg, mem, *, cin, cout, h, w=None, batch, down=1, up=1
         kw.update(fromrgb_weight=mem.ptr(dev(fw)), fromrgb_bias=mem.ptr(dev(fb)))
     else:
         x = orc.round_storage((pkg.synth.normal((batch, cin, h, w), seed, "x") * 1.5).astype(np.float32), storage)
+        if nan_at is not None:
+            x[nan_at] = np.nan                       # NaN-propagating builds only (Generator(nan_policy="propagate")): the mask must follow the oracle
         xin = dev(to_storage(nhwc(x), storage))
     gemm16 = storage != "f32" and gemm != 2          # 16-bit storage: GEMM variant "f16" unless f16x2 (2) is asked for
     want = orc.separable_conv(x.copy(), osd, "m", gemm16)
@@ -126,6 +128,11 @@ def run_sepconv_case(lib, pkg, mem, *, cin, cout, h, w=None, batch, down=1, up=1
                         wsplit=mem.ptr(wsp), wsplit_bytes=wsp_n * 4, dtype=pkg.hipbind.dtype_code(storage), gemm=gemm, **kw)
     mem.sync()
     got = nchw(from_storage(mem.get(y), storage))
+    if nan_at is not None:
+        assert np.array_equal(np.isnan(got), np.isnan(want)), "NaN mask differs from the oracle's"
+        assert np.isnan(want).any() and not np.isnan(want).all()
+        got = np.where(np.isnan(want), 0.0, got).astype(np.float32)
+        want = np.where(np.isnan(want), 0.0, want).astype(np.float32)
     assert np.isfinite(got).all(), "kernel left NaNs (unwritten output or read of unwritten LDS)"
     # "f16" GEMM variant: an fp16 operand that rounded the other way (the two sides differ in the last place before rounding)
     # moves the fp32 sum by 2^-11 of one product

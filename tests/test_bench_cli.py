@@ -49,6 +49,27 @@ def test_uint8_io_gathers_uint8_shards():
     assert out["rccl_ranks"] == 2 and out["gather_dtype"] == "uint8"
 
 
+def test_world_8_dry_run_is_one_line_with_eight_ranks_and_no_single_gpu_legs():
+    """the shape of the driver's scaling run, on CPU: eight ranks rendezvous and gather, rank 0 prints exactly one JSON line, and the legs
+    that only make sense at N = 1 (secondary workloads, CPU baseline, batch-1 latency) are not there"""
+    r, out = _run("--gpus", "8", "--backend", "gloo", "--dry", "--steps", "2")
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert len([l for l in r.stdout.splitlines() if l.startswith("{")]) == 1
+    assert out["n_gpus"] == 8 and out["rccl_ranks"] == 8 and out["config"]["global_batch"] == 256 and out["scaling"] == "weak"
+    for key in ("secondary", "cpu_baseline", "latency_b1_ms", "value_exact_f32", "rccl_world1"):
+        assert key not in out
+    assert out["gather_dtype"] == "float32"
+
+
+def test_gather_dtype_choices():
+    r, out = _run("--gpus", "2", "--backend", "gloo", "--dry", "--steps", "2", "--gather-dtype", "f16")
+    assert r.returncode == 0 and out["gather_dtype"] == "float16"
+    r32, out32 = _run("--gpus", "2", "--backend", "gloo", "--dry", "--steps", "2")
+    assert out["gather_mb_per_rank_per_step"] * 2 == out32["gather_mb_per_rank_per_step"]
+    r, out = _run("--gpus", "2", "--backend", "gloo", "--dry", "--steps", "1", "--gather-dtype", "u8")
+    assert r.returncode != 0                                     # uint8 shards exist only with --io u8
+
+
 def test_uint8_source_of_the_synthetic_input_matches_it():
     import importlib
     import numpy as np

@@ -108,7 +108,7 @@ def test_real_demo_script_end_to_end_on_the_emulated_kernels(pkg, workdir, patch
     G = pkg.Generator
     monkeypatch.setattr(G, "_require_device", lambda self, x: 0)
     monkeypatch.setattr(G, "_stream", lambda self, x: 0)
-    monkeypatch.setattr(pkg.migan_inference, "load_library", lambda: lib)
+    monkeypatch.setattr(pkg.migan_inference, "load_library", lambda **kw: lib)
     demo = _load_demo("ref_demo_ours2")
     assert demo.MIGAN is G
     _run_demo(demo, tmp, ckpt, tmp / "out_ours")

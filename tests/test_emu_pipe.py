@@ -27,12 +27,13 @@ def small_grids(request, lib):
     lib.set_tuning("pipe_min_tiles", 1)
     lib.set_tuning("pipe_grid", 8)
     lib.set_tuning("pipe_na", request.param)
-    lib.set_tuning("pipe", 7)          # every form, also the ones the default plan leaves to the one-tile kernels
+    lib.set_tuning("pipe_na8", 0)      # (this wave count for every form)
     yield
     lib.set_tuning("pipe_min_tiles", 256)
     lib.set_tuning("pipe_grid", 256)
-    lib.set_tuning("pipe", 5)
+    lib.set_tuning("pipe", 7)
     lib.set_tuning("pipe_na", 4)
+    lib.set_tuning("pipe_na8", 3)
 
 
 PIPE = "migan::sepconv_pipe_kernel<"

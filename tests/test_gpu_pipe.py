@@ -28,12 +28,13 @@ def lib(pkg):
 @pytest.fixture(autouse=True, params=[4, 8])
 def knobs(request, lib):
     lib.set_tuning("pipe_na", request.param)
-    lib.set_tuning("pipe", 7)          # every form, also the ones the default plan leaves to the one-tile kernels
+    lib.set_tuning("pipe_na8", 0)      # (this wave count for every form)
     yield
     lib.set_tuning("pipe_min_tiles", 256)
     lib.set_tuning("pipe_grid", 256)
-    lib.set_tuning("pipe", 5)
+    lib.set_tuning("pipe", 7)
     lib.set_tuning("pipe_na", 4)
+    lib.set_tuning("pipe_na8", 3)
 
 
 # (h, w, batch, persistent workgroups): 0 = the default grid (one per CU)
@@ -101,7 +102,7 @@ def test_pipelined_forward_is_deterministic_and_matches_the_one_tile_kernels(pkg
     try:
         y0, names0 = run()
     finally:
-        lib.set_tuning("pipe", 5)
+        lib.set_tuning("pipe", 7)
     assert not any(n.startswith(PIPE) for n in names0)
     scale = float(ys[0].abs().max())
     assert float((ys[0] - y0[0]).abs().max()) <= 2e-5 * max(1.0, scale)

@@ -144,3 +144,24 @@ def test_two_ranks_on_one_gpu_or_the_reason_rccl_gives(dev, tmp_path):
     reason = [l for l in text.splitlines() if "RCCL_ERROR" in l or "TIMEOUT" in l or "Duplicate GPU" in l or "ncclInvalidUsage" in l]
     assert "RESULT wrong" not in text, text[-1500:]
     pytest.skip("two ranks on the single MI355X of this box: " + (reason[0][:400] if reason else text[-400:]))
+
+
+def test_forward_on_a_cu_masked_stream_gives_the_same_image(pkg):
+    """bench.py --reserve-cus: the forward on a stream whose CU mask leaves 16 CUs to the RCCL kernels (hipExtStreamCreateWithCUMask)"""
+    import torch
+    dev = torch.device("cuda", 0)
+    sd = pkg.synth.make_state_dict(64, seed=5)
+    m = pkg.Generator(resolution=64)
+    m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd.items()})
+    m = m.to(dev).eval()
+    m.set_streams(1)
+    x = torch.from_numpy(pkg.synth.make_input(4, 64, seed=5)).to(dev)
+    with torch.no_grad():
+        want = m(x).clone()
+        masked = pkg.distributed.cu_masked_stream(dev, 16)
+        masked.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(masked):
+            got = m(x).clone()
+        torch.cuda.current_stream(dev).wait_stream(masked)
+    torch.cuda.synchronize()
+    assert torch.equal(got, want)

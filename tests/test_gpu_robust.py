@@ -49,3 +49,46 @@ def test_nan_input_reference_propagates_kernels_clamp(pkg, dev):
         yc = m(torch.from_numpy(clean).to(dev)).cpu().numpy()
     # ... and far from the bad pixel only the globally mixed part of the signal moved
     assert float(np.abs(y - yc)[..., 40:, 40:].max()) < float(np.abs(yc).max())
+
+
+# ---- the NaN-propagating build (libmigan_hip_strictnan.so, -DMIGAN_STRICT_NAN): Tensor.clamp's behaviour, reference :21-23 -------------
+@pytest.fixture(scope="module")
+def strict_lib(pkg):
+    lib = pkg.hipbind.load_library(nan_policy="propagate")
+    assert lib.nan_policy() == "propagate" and lib.backend() == "hip:gfx950"
+    return lib
+
+
+@pytest.mark.parametrize("kw", [dict(cin=64, cout=64, h=32, batch=2), dict(cin=64, cout=128, h=16, batch=2, down=2),
+                                dict(cin=128, cout=64, h=16, batch=2, up=2, noise=True, skip=True), dict(cin=256, cout=256, h=16, batch=1)])
+def test_strict_nan_operator_mask_follows_the_oracle(pkg, dev, strict_lib, kw):
+    """one NaN input element: the output is NaN exactly where the oracle's is (the 3x3 neighbourhood, every output channel, FIR spread)"""
+    from tests.sepconv_case import run_sepconv_case
+    strict_lib.set_tuning("pipe_min_tiles", 1)
+    try:
+        run_sepconv_case(strict_lib, pkg, CudaMem(dev), seed=13, nan_at=(0, 5, 7, 9), **kw)
+    finally:
+        strict_lib.set_tuning("pipe_min_tiles", 256)
+
+
+def test_strict_nan_generator_matches_the_reference_and_the_default_build(pkg, dev):
+    res = 64
+    sd = pkg.synth.make_state_dict(res, seed=61, regime="export")
+
+    def model(policy):
+        m = pkg.Generator(resolution=res, nan_policy=policy)
+        m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd.items()}, strict=True)
+        return m.to(dev).eval()
+
+    strict, default = model("propagate"), model("clamp")
+    x = pkg.synth.make_input(2, res, seed=61)
+    with torch.no_grad():
+        ys, yd = strict(torch.from_numpy(x).to(dev)).cpu().numpy(), default(torch.from_numpy(x).to(dev)).cpu().numpy()
+    assert np.array_equal(ys, yd)                                 # finite inputs: the two builds compute the same bits
+    x[0, 1, 10, 10] = np.nan                                      # image 0 only
+    ref = torc.generator(x, sd, res).numpy()
+    with torch.no_grad():
+        y = strict(torch.from_numpy(x).to(dev)).cpu().numpy()
+    assert np.array_equal(np.isnan(y), np.isnan(ref))             # Tensor.clamp semantics: image 0 is lost, image 1 untouched
+    assert np.isnan(ref[0]).all() and np.isfinite(ref[1]).all()
+    np.testing.assert_allclose(y[1], ref[1], rtol=0, atol=1e-4 * max(1.0, float(np.abs(ref[1]).max())))
