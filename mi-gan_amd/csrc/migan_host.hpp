@@ -103,12 +103,14 @@ struct Tuning {
   int stagger = -1;            // MIGAN_STAGGER: launch index of the first half after which the second half starts (-1: plan default)
   int debug_split = 0;         // diagnostics: keep the two-sub-batch execution in keep-intermediates mode
   int stagger_pct = 22;        // MIGAN_STAGGER_PCT: the next sub-batch starts after this share of a forward's launches
-  int pipe = 7;                // MIGAN_PIPE bit mask: software-pipelined persistent kernels (sepconv_pipe_kernel; fp32 storage, f16x2 GEMM) for
-                               // 1 plain (+ fused ToRGB) layers, 2 the fused-FromRGB layer, 4 FIR-up layers -- wherever an instantiation exists
+  int pipe = 15;               // MIGAN_PIPE bit mask: software-pipelined persistent kernels (sepconv_pipe_kernel; fp32 storage, f16x2 GEMM) for
+                               // 1 plain (+ fused ToRGB) layers, 2 the fused-FromRGB layer, 4 FIR-up layers, 8 down=2 layers as one fused launch
+                               // (sepconv_pipedown_kernel) -- wherever an instantiation exists
                                // (the 512 x 512 layers of migan-512: -5 / -10 / -9 % per layer, profiles/r04_pipe_layers.txt)
   int pipe_grid = 256;         // MIGAN_PIPE_GRID: persistent workgroups of those launches (one 12- or 16-wave workgroup per CU on MI355X)
   int pipe_na = 4;             // waves of the depthwise group of those workgroups (4 or 8), for the layers in pipe_na8 the other value
-  int pipe_na8 = 3;            // bit mask like `pipe`: layers that take the other count (default: plain and fused-FromRGB layers run 8 + 8 waves, FIR-up 4 + 8)
+  int pipe_na8 = 11;           // bit mask like `pipe`: layers whose depthwise group has 8 waves whatever pipe_na says (default: plain, fused-FromRGB and
+                               // fused down=2 layers run 8 + 8 waves, FIR-up layers 4 + 8: profiles/r04_pipe_layers.txt)
   int pipe_min_tiles = 256;    // launches with fewer tiles keep the one-tile-per-workgroup kernels
 };
 inline Tuning& tuning() {
@@ -319,6 +321,11 @@ inline const char* wide_name(const Geo& g) {
     return g.torgb ? "migan::sepconv_wide_kernel<true, 0, false, true, true>" : "migan::sepconv_wide_kernel<false, 0, false, true, true>";
   return n[wide_ball() ? 1 : 0][g.gemmv == 3 ? 1 : 0][g.torgb ? 1 : 0][g.stv];
 }
+// symbol of the fused-SeparableConv2d kernel this thread launched last (migan_last_kernel: tests ask which form ran)
+inline const char*& last_kernel_ref() {
+  thread_local const char* n = "";
+  return n;
+}
 // sepconv_pipe_kernel (migan_pipe.hpp): the software-pipelined persistent form of a layer, where an instantiation exists.  Chosen per
 // launch from the batch: every launch of two or more images of a given layer takes the same decision (tiles >= pipe_min_tiles holds
 // from batch 2 on for the layers that have an instantiation), so an image is bit-identical whatever batch >= 2 it is in.
@@ -339,6 +346,24 @@ inline const PipeEntry* pick_pipe(const Geo& g, int cin, int cout, int batch, bo
       return &e;
   }
   return nullptr;
+}
+// sepconv_pipedown_kernel: a down=2 layer as ONE launch (depthwise + FIR-down feed the 1x1 through LDS) instead of dwfir_kernel + pointwise
+// GEMM with the half-resolution tensor going through HBM; where one workgroup can own all of Cout (an instantiation exists) and the
+// launch has enough tiles.  Same decision for every batch >= 2 (see pick_pipe).
+DownSlice pipedown_slice();
+inline const DownEntry* pick_pipedown(int cin, int cout, int h_in, int w_in, int batch, int stv, int gemmv) {
+  if (!(tuning().pipe & 8) || stv != 0 || gemmv != 2 || batch < 2) return nullptr;
+  if (h_in % 8 != 0 || w_in % 32 != 0) return nullptr;                        // whole 4 x 16 low-resolution tiles
+  if ((h_in / 8) * (w_in / 32) * batch < tuning().pipe_min_tiles) return nullptr;
+  const int na = (tuning().pipe_na8 & 8) ? 8 : tuning().pipe_na;
+  const DownSlice sl = pipedown_slice();
+  const DownEntry* best = nullptr;
+  for (int i = 0; i < sl.n; ++i) {
+    const DownEntry& e = sl.entries[i];
+    if (e.NT == cout && e.cin == cin && (e.na == na || best == nullptr)) best = &e;
+    if (best && best->na == na) break;
+  }
+  return best;
 }
 inline const char* kernel_name(const Geo& g);
 inline const KernelEntry& pick_kernel(const Geo& g) {
@@ -428,6 +453,8 @@ inline void prepare_kernels() {
   {
     const PipeSlice sl = pipe_slice();
     for (int i = 0; i < sl.n; ++i) rt_check(rt::allow_dynamic_lds((const void*)sl.entries[i].fn, 160 * 1024), "hipFuncSetAttribute");
+    const DownSlice ds = pipedown_slice();
+    for (int i = 0; i < ds.n; ++i) rt_check(rt::allow_dynamic_lds((const void*)ds.entries[i].fn, 160 * 1024), "hipFuncSetAttribute");
   }
   for (int t = 0; t < 2; ++t)
     for (int sv = 0; sv < 3; ++sv) {
@@ -510,11 +537,7 @@ inline unsigned grid_of(const Geo& g, int batch, bool fused_rgb = false) {
 
 // name of the kernel launch_sepconv runs for this geometry and batch
 inline const char* launched_kernel_name(Geo g, int cin, int cout, int batch, bool fused_rgb);
-// symbol of the fused-SeparableConv2d kernel this thread launched last (migan_last_kernel: tests ask which form ran)
-inline const char*& last_kernel_ref() {
-  thread_local const char* n = "";
-  return n;
-}
+
 inline void launch_sepconv(Geo g, const SepArgs& a, rt::stream_t stream) {
   prepare_kernels();
   const bool fused_rgb = a.trgb_w != nullptr;
@@ -549,6 +572,15 @@ inline const char* launched_kernel_name(Geo g, int cin, int cout, int batch, boo
   return kernel_name(g);
 }
 
+inline void launch_pipedown(const DownEntry& e, SepArgs a, rt::stream_t stream) {
+  prepare_kernels();
+  MIGAN_CHECK(a.wsplit != nullptr, MIGAN_EINVAL, "internal: the fused down=2 kernel needs the fp16 weight planes");
+  a.tiles_x = a.W / 32; a.tiles_y = a.H / 8; a.nchunks = 1;
+  a.prof = prof_buffer();
+  const unsigned tiles = (unsigned)(a.tiles_x * a.tiles_y * a.B);
+  rt_check(rt::launch(e.fn, a, std::min(tiles, (unsigned)tuning().pipe_grid), (unsigned)pipe_threads(e.na), e.lds_bytes, stream), e.name);
+  last_kernel_ref() = e.name;
+}
 inline void launch_dwfir(const DwGeo& g, DwFirArgs a, rt::stream_t stream, int stv = 0) {
   prepare_kernels();
   a.lgGH = g.lgGH; a.lgGW = g.lgGW; a.lgIMGS = g.lgIMGS;
@@ -998,7 +1030,25 @@ inline void migan_handle::run_range(const migan::Plan& P, const float* x, float*
   for (size_t li = 0; li < P.launches.size(); ++li) {
     const Launch& L = P.launches[li];
     if (timed) rt_check(rt::event_record(events[2 * li], stream), "hipEventRecord");
-    if (L.is_dwfir) {
+    // a down=2 layer is two plan entries (depthwise + FIR-down, pointwise GEMM); where the fused kernel applies, the first entry launches
+    // nothing and the second launches sepconv_pipedown_kernel on the first one's input
+    const bool dw_fused = L.is_dwfir && li + 1 < P.launches.size() &&
+                          pick_pipedown(L.cin, P.launches[li + 1].cout, L.hin, L.win, n, stv, gemm) != nullptr;
+    const bool pw_fused = !L.is_dwfir && !L.is_rgb && L.g.mode == MODE_PW && li >= 1 && P.launches[li - 1].is_dwfir &&
+                          pick_pipedown(L.cin, L.cout, P.launches[li - 1].hin, P.launches[li - 1].win, n, stv, gemm) != nullptr;
+    if (dw_fused) {
+      L.kernel_last = pick_pipedown(L.cin, P.launches[li + 1].cout, L.hin, L.win, n, stv, gemm)->name;      // (its bytes belong to that launch)
+    } else if (pw_fused) {
+      const Launch& D = P.launches[li - 1];
+      const DownEntry* de = pick_pipedown(L.cin, L.cout, D.hin, D.win, n, stv, gemm);
+      SepArgs a{};
+      a.x = bptr(D.in_buf); a.y = bptr(L.out_buf);
+      a.wdw = wptr(D.w_dw); a.bdw = wptr(D.b_dw); a.wpw = wptr(L.w_pw);
+      a.wsplit = wsplit + L.wsplit_off;
+      a.B = n; a.H = D.hin; a.W = D.win; a.CI = L.cin; a.CO = L.cout; a.HO = L.hout; a.WO = L.wout;
+      launch_pipedown(*de, a, stream);
+      L.kernel_last = de->name;
+    } else if (L.is_dwfir) {
       DwFirArgs a{};
       a.x = bptr(L.in_buf); a.y = (float*)bptr(L.out_buf); a.wdw = wptr(L.w_dw); a.bdw = wptr(L.b_dw);
       a.B = n; a.H = L.hin; a.W = L.win; a.C = L.cin;
@@ -1448,6 +1498,24 @@ int migan_sepconv_forward(const migan_sepconv_desc* d, void* stream) {
   const bool have_planes = d->wsplit != nullptr && d->wsplit_bytes >= wsplit_need;
   MIGAN_CHECK(stv == 0 || have_planes, MIGAN_EINVAL, "16-bit activation storage needs the wsplit buffer (fp16 GEMM variants)");
   const int gemmv = have_planes ? want : 0;
+  const DownEntry* fused_down = nullptr;
+  if (d->down == 2 && have_planes && d->fromrgb_weight == nullptr && d->torgb_weight == nullptr && d->noise_const == nullptr && d->skip == nullptr)
+    fused_down = pick_pipedown(d->cin, d->cout, h_in, w_in, d->batch, stv, gemmv);
+  if (fused_down) {
+    // one launch: depthwise + FIR-down feed the 1x1 through LDS (no scratch tensor)
+    SplitArgs sa{};
+    sa.dst = (unsigned short*)d->wsplit;
+    sa.f16 = 1;
+    sa.src[0] = (const float*)d->conv2_weight; sa.dst_off[0] = kSplitHeader; sa.count[0] = (unsigned)(d->cin * d->cout); sa.ci[0] = (unsigned)d->cin; sa.n = 1;
+    launch_split(sa, (rt::stream_t)stream);
+    SepArgs a{};
+    a.x = d->x; a.y = d->y;
+    a.wdw = (const float*)d->conv1_weight; a.bdw = (const float*)d->conv1_bias; a.wpw = (const float*)d->conv2_weight;
+    a.wsplit = (const unsigned short*)d->wsplit + kSplitHeader;
+    a.B = d->batch; a.H = h_in; a.W = w_in; a.CI = d->cin; a.CO = d->cout; a.HO = h_out; a.WO = w_out;
+    launch_pipedown(*fused_down, a, (rt::stream_t)stream);
+    return MIGAN_OK;
+  }
   if (d->down == 2) {
     // reference :155-161: depthwise+act+FIR at res_in (dwfir kernel), then the 1x1 at res_in/2
     MIGAN_CHECK(d->fromrgb_weight == nullptr, MIGAN_EINVAL, "fromrgb is only fused into plain layers");

@@ -896,4 +896,418 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(pipe_threads(NA), (NA + kPipeBWaves) / 4) 
   PPROF_END(AT);
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------------
+// down=2 SeparableConv2d as ONE pipelined kernel (reference :154-163: depthwise 3x3 + bias -> lrelu_agc -> Downsample2d (4x4 FIR,
+// stride 2, :58-76) -> 1x1 conv -> lrelu_agc).  Rounds 1-3 ran it as dwfir_kernel + a pointwise GEMM with the half-resolution
+// Cin-channel tensor round-tripping through HBM (1.35x the algorithmic traffic of these layers, profiles/r03_pmc_traffic_*).  Here the
+// FIR result never leaves the CU: it is written as the fp16 hi/lo A operand of the 1x1 straight into LDS.
+//
+//   tile    4 x 16 low-resolution output pixels (64 GEMM rows) x NT output channels, K walked in chunks of 16 input channels
+//   DMA     the 12 x 36-pixel input window of chunk s+R-1 (27 KB) -> LDS ring, and the chunk's weight planes
+//   A       stage 1: depthwise 3x3 + bias + act on the 10 x 34 grid the FIR window touches (zero outside the image: the FIR's padding)
+//           -> d_s; [barrier]; stage 2: 16-tap FIR, x 2^7, fp16 split -> A planes of chunk s+1        (two barriers per chunk)
+//   B       8 waves = 2 row blocks x 4 column groups: MFMAs of chunk s; the previous tile's epilogue (wave-private transpose, activation,
+//           stores) under the next tile's chunks, as in sepconv_pipe_kernel
+//
+// The depthwise + FIR stage runs once per pixel only while one workgroup owns all of Cout (Cout <= 256); wider layers keep the two-kernel form.
+template <int NT, int CIN, int R>
+struct DownLds {
+  static constexpr int KC = 16, NKC = CIN / KC;
+  static constexpr int IN_UNITS = 12 * 36 * 4;                      // 16-byte units of one input window chunk ([432 pixels][16 channels] fp32)
+  static constexpr int A_BUF = 2 * 64 * 32;                         // hi + lo plane, [64 rows][16 k] fp16
+  static constexpr int B_CHUNK = 2 * NT * 32;                       // hi + lo plane of one chunk, [NT rows][16 k] fp16
+  static constexpr bool WRES = NKC * B_CHUNK <= 32 * 1024;
+  static constexpr int NBUF_B = WRES ? NKC : 2;
+  static constexpr int D_SZ = 10 * 34 * KC * 4;                     // depthwise grid
+  template <int AT> static constexpr int in_slot() { return (IN_UNITS + AT - 1) / AT * AT * 16; }
+  template <int AT> static constexpr int off_d() { return R * in_slot<AT>(); }
+  template <int AT> static constexpr int off_a() { return off_d<AT>() + D_SZ; }
+  template <int AT> static constexpr int off_b() { return off_a<AT>() + 2 * A_BUF; }
+  template <int AT> static constexpr int off_w() { return off_b<AT>() + NBUF_B * B_CHUNK; }
+  template <int AT> static constexpr int off_t() { return off_w<AT>() + NKC * 640; }
+  template <int AT> static constexpr int total() { return off_t<AT>() + kPipeBWaves * 32 * 32 * 4; }
+};
+
+template <int NT, int CIN, int R, int NA>
+MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(pipe_threads(NA), (NA + kPipeBWaves) / 4) sepconv_pipedown_kernel(const SepArgs p) {
+  typedef DownLds<NT, CIN, R> L;
+  constexpr int AT = NA * 64, KC = 16, QC = 4, LG_QC = 2, NKC = L::NKC, MT = 64, GH = 4, GW = 16, lgGW = 4;
+  constexpr int IGH = 12, IGW = 36, NPIXW = IGH * IGW, NITEMS = NPIXW * QC, DH = 10, DW = 34, DH2 = 5;
+  constexpr int DNI = (NITEMS + AT - 1) / AT;
+  constexpr bool WRES = L::WRES;
+  constexpr int DNB = (4 * NT + AT - 1) / AT;                       // weight-plane DMAs per group-A thread and chunk (4 NT units)
+  static_assert((4 * NT) % AT == 0, "weight planes must split evenly over group A");
+  constexpr int NTIW = NT / 128;                                    // 32-column blocks of a B wave (2 row blocks x 4 column groups)
+  static_assert(NT == 128 || NT == 256, "one workgroup owns 128 or 256 output channels");
+  static_assert(R == 2, "two-slot ring");
+  static_assert(L::template total<AT>() <= 160 * 1024, "LDS budget");
+  MIGAN_DYN_SMEM(smem);
+  char* const lds = reinterpret_cast<char*>(smem);
+  constexpr int IN_SLOT = L::template in_slot<AT>();
+  constexpr int OFF_D = L::template off_d<AT>(), OFF_A = L::template off_a<AT>(), OFF_B = L::template off_b<AT>(), OFF_W = L::template off_w<AT>(),
+                OFF_T = L::template off_t<AT>();
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave_u = MIGAN_UNIFORM(tid >> 6);
+  const bool groupA = tid < AT;
+  const int HO = p.H >> 1, WO = p.W >> 1;                            // p.H, p.W: the full-resolution input; the GEMM runs at HO x WO
+
+  // ---- tile schedule (as sepconv_pipe_kernel) ------------------------------------------------------------------------------------
+  const int ntiles = p.tiles_x * p.tiles_y * p.nchunks * p.B;
+  const int xcd = (int)blockIdx.x & 7;
+  const int tq = ntiles >> 3, tr = ntiles & 7;
+  const int tcnt = tq + (xcd < tr ? 1 : 0);
+  const int tbase = xcd < tr ? xcd * (tq + 1) : tr * (tq + 1) + (xcd - tr) * tq;
+  const int tstep = ((int)gridDim.x + 7 - xcd) >> 3;
+  const int tl0 = (int)blockIdx.x >> 3;
+  const int T = tl0 < tcnt ? (tcnt - tl0 + tstep - 1) / tstep : 0;
+  if (T == 0) return;
+  const int G = T * NKC;
+  PPROF_BEGIN();
+  struct TileCur {
+    int n, x, y, b;
+  };
+  const int st_n = tstep % p.nchunks, st_r1 = tstep / p.nchunks;
+  const int st_x = st_r1 % p.tiles_x, st_r2 = st_r1 / p.tiles_x;
+  const int st_y = st_r2 % p.tiles_y, st_b = st_r2 / p.tiles_y;
+  TileCur tile0;
+  {
+    int t = tbase + tl0;
+    tile0.n = t % p.nchunks; t /= p.nchunks;
+    tile0.x = t % p.tiles_x; t /= p.tiles_x;
+    tile0.y = t % p.tiles_y;
+    tile0.b = t / p.tiles_y;
+  }
+  auto tile_next = [&](TileCur& c) {
+    int carry = 0;
+    c.n += st_n;
+    if (c.n >= p.nchunks) { c.n -= p.nchunks; carry = 1; }
+    c.x += st_x + carry; carry = 0;
+    if (c.x >= p.tiles_x) { c.x -= p.tiles_x; carry = 1; }
+    c.y += st_y + carry; carry = 0;
+    if (c.y >= p.tiles_y) { c.y -= p.tiles_y; carry = 1; }
+    c.b += st_b + carry;
+  };
+
+  if (groupA) {
+    const int lt = tid;
+    float* const w_s = reinterpret_cast<float*>(lds + OFF_W);
+    float* const d_s = reinterpret_cast<float*>(lds + OFF_D);
+    // depthwise taps + bias of every 16-channel chunk: per chunk tap-major [9][16], then bias [16]
+    for (int i = lt; i < CIN * 9 / 4; i += AT) {
+      const f4 v = ld4(p.wdw + i * 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int f = i * 4 + e, ch = f / 9, tap = f - ch * 9;
+        w_s[(ch >> 4) * 160 + tap * 16 + (ch & 15)] = v[e];
+      }
+    }
+    for (int i = lt; i < CIN / 4; i += AT) st4(w_s + ((i * 4) >> 4) * 160 + 144 + ((i * 4) & 15), ld4(p.bdw + i * 4));
+
+    // weight planes (chunk-major [plane][CIN/32][CO][32] fp16): the 16-channel half (c & 1) of 32-channel block c >> 1 -> [plane][NT][16]
+    const MIGAN_BUF wbuf = MIGAN_MAKE_BUF(p.wsplit, (unsigned)(2 * p.CO * CIN) * 2u);
+    unsigned dboff[DNB];
+#pragma unroll
+    for (int j = 0; j < DNB; ++j) {
+      const int u = lt + j * AT;                         // unit (plane, row n, 16-byte slot)
+      const int plane = u / (2 * NT), rem = u % (2 * NT);
+      dboff[j] = (unsigned)(plane * p.CO * CIN + (rem >> 1) * 32 + (rem & 1) * 8) * 2u;
+    }
+    auto dma_b = [&](int n0_, int chunk, int buf) {
+      float* bb = reinterpret_cast<float*>(lds + OFF_B + buf * L::B_CHUNK);
+      const unsigned soff = (unsigned)((chunk >> 1) * 32 * p.CO + n0_ * 32 + (chunk & 1) * 16) * 2u;
+#pragma unroll
+      for (int j = 0; j < DNB; ++j) MIGAN_LDS_DMA16(wbuf, dboff[j], soff, bb + (j * AT + wave_u * 64) * 4);
+    };
+    // input window: interior windows use offsets relative to their first pixel (computed once) + a scalar origin
+    unsigned dgoff[DNI], drel[DNI], tile_soff = 0;
+#pragma unroll
+    for (int j = 0; j < DNI; ++j) {
+      const int i = lt + j * AT;
+      drel[j] = 0xfffff000u;
+      if (i < NITEMS) {
+        const int c4 = i & (QC - 1), pix = i >> LG_QC;
+        drel[j] = (unsigned)(((pix / IGW) * p.W + (pix % IGW)) * CIN + c4 * 4) * 4u;
+      }
+    }
+    auto make_dgoff = [&](int gy0_, int gx0_) {            // (gy0_, gx0_): low-resolution tile origin
+      const int iy0 = 2 * gy0_ - 2, ix0 = 2 * gx0_ - 2;
+      if (iy0 >= 0 && iy0 + IGH <= p.H && ix0 >= 0 && ix0 + IGW <= p.W) {
+#pragma unroll
+        for (int j = 0; j < DNI; ++j) dgoff[j] = drel[j];
+        tile_soff = (unsigned)((iy0 * p.W + ix0) * CIN) * 4u;
+        return;
+      }
+      tile_soff = 0;
+#pragma unroll
+      for (int j = 0; j < DNI; ++j) {
+        const int i = lt + j * AT;
+        unsigned g = 0xfffff000u;
+        if (i < NITEMS) {
+          const int c4 = i & (QC - 1), pix = i >> LG_QC;
+          const int yy = iy0 + pix / IGW, xx = ix0 + pix % IGW;
+          if (yy >= 0 && yy < p.H && xx >= 0 && xx < p.W) g = (unsigned)((yy * p.W + xx) * CIN + c4 * 4) * 4u;
+        }
+        dgoff[j] = g;
+      }
+    };
+    const unsigned img_bytes = (unsigned)(p.H * p.W * CIN) * 4u;
+    auto dma_in = [&](int b0_, int chunk, int slot) {
+      float* in_s = reinterpret_cast<float*>(lds + slot * IN_SLOT);
+      const MIGAN_BUF xbuf = MIGAN_MAKE_BUF(reinterpret_cast<const char*>(p.x) + (size_t)b0_ * img_bytes, img_bytes);
+#pragma unroll
+      for (int j = 0; j < DNI; ++j) MIGAN_LDS_DMA16(xbuf, dgoff[j], tile_soff + (unsigned)(chunk * KC) * 4u, in_s + (j * AT + wave_u * 64) * 4);
+    };
+    // stage 1: depthwise 3x3 + bias + act on the 10 x 34 grid (rows 2 gy0 - 1 .., columns 2 gx0 - 1 ..) -> d_s; one item = 2 vertically
+    // adjacent grid pixels x 4 channels; positions outside the image are the FIR's zero padding (reference :67)
+    auto stage1 = [&](int slot, int chunk, int gy0_, int gx0_) {
+      const float* in_s = reinterpret_cast<const float*>(lds + slot * IN_SLOT);
+      const float* wc = w_s + chunk * 160;
+      const int c4 = lt & (QC - 1);
+      f4 w[9];
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) w[tap] = ld4(wc + tap * KC + c4 * 4);
+      const f4 bias = ld4(wc + KC * 9 + c4 * 4);
+      const int yim0 = 2 * gy0_ - 1, xim0 = 2 * gx0_ - 1;
+      for (int it = lt; it < DH2 * DW * QC; it += AT) {
+        const int r = it >> LG_QC;
+        const int dx = r % DW, dy0 = 2 * (r / DW);
+        const float* ip = in_s + (dy0 * IGW + dx) * KC + c4 * 4;
+        f4 win[4][3];
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+          win[rr][0] = ld4(ip); win[rr][1] = ld4(ip + KC); win[rr][2] = ld4(ip + 2 * KC);
+          ip += IGW * KC;
+        }
+        const int xim = xim0 + dx;
+        const bool colin = xim >= 0 && xim < p.W;
+        float* dp = d_s + (dy0 * DW + dx) * KC + c4 * 4;
+#pragma unroll
+        for (int o = 0; o < 2; ++o) {
+          f4 sacc = bias;
+#pragma unroll
+          for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) sacc += w[ky * 3 + kx] * win[o + ky][kx];
+          const int yim = yim0 + dy0 + o;
+          f4 d = {0.f, 0.f, 0.f, 0.f};
+          if (colin && yim >= 0 && yim < p.H) d = act4(sacc);
+          st4(dp + o * DW * KC, d);
+        }
+      }
+    };
+    // stage 2: 4x4 FIR, stride 2, taps outer([1,3,3,1])/64 (reference Downsample2d :58-76), x 2^7, fp16 hi/lo -> A planes
+    auto stage2 = [&](int abuf) {
+      char* a_b = lds + OFF_A + abuf * L::A_BUF;
+      for (int it = lt; it < MT * QC; it += AT) {
+        const int c4 = it & (QC - 1), m = it >> LG_QC;
+        const int ox = m & (GW - 1), oy = m >> lgGW;
+        const float* dp = d_s + ((2 * oy) * DW + 2 * ox) * KC + c4 * 4;
+        f4 a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ky = 0; ky < 4; ++ky) {
+          const float fy = (ky == 0 || ky == 3) ? 1.0f : 3.0f;
+#pragma unroll
+          for (int kx = 0; kx < 4; ++kx) {
+            const float fx = (kx == 0 || kx == 3) ? 1.0f : 3.0f;
+            a += (fy * fx * (1.0f / 64.0f)) * ld4(dp + (ky * DW + kx) * KC);
+          }
+        }
+        u2v h1, h2;
+        split2_f16(a * kF16AScale, h1, h2);
+        char* d = a_b + m * 32 + c4 * 8;
+        *reinterpret_cast<u2v*>(d) = h1;
+        *reinterpret_cast<u2v*>(d + MT * 32) = h2;
+      }
+    };
+
+    // cursors
+    int is = 0, ic = 0, ik = 0, ib0 = 0, in0 = 0, igy0 = 0, igx0 = 0;
+    TileCur itc = tile0;
+    auto icoords = [&]() { in0 = itc.n * NT; ib0 = itc.b; igy0 = itc.y * GH; igx0 = itc.x * GW; };
+    icoords();
+    make_dgoff(igy0, igx0);
+    auto issue = [&]() {                                  // input window of step `is` -> slot is & 1
+      if (is < G) {
+        dma_in(ib0, ic, is & 1);
+        ++is;
+        if (++ic == NKC) {
+          ic = 0;
+          if (++ik < T) { tile_next(itc); icoords(); make_dgoff(igy0, igx0); }
+        }
+      }
+    };
+    // streamed weight planes of step `bs` -> slot bs & 1 (that slot is read by the MFMAs of step bs - 2: issued after they are done)
+    int bs = 0, bc = 0, bk = 0, bn0 = in0;
+    TileCur btc = tile0;
+    auto issue_b = [&]() -> bool {
+      if (bs >= G) return false;
+      dma_b(bn0, bc, bs & 1);
+      ++bs;
+      if (++bc == NKC) {
+        bc = 0;
+        if (++bk < T) { tile_next(btc); bn0 = btc.n * NT; }
+      }
+      return true;
+    };
+    // the tile the depthwise stage is working on
+    int dk = 0, dc = 0, dgy0 = igy0, dgx0 = igx0;
+    TileCur dtc = tile0;
+    auto dadvance = [&]() {
+      if (++dc == NKC) {
+        dc = 0;
+        if (++dk < T) { tile_next(dtc); dgy0 = dtc.y * GH; dgx0 = dtc.x * GW; }
+      }
+    };
+    if constexpr (WRES) {
+#pragma unroll
+      for (int c = 0; c < NKC; ++c) dma_b(in0, c, c);
+    } else {
+      issue_b();                                          // steps 0 and 1
+      issue_b();
+    }
+    issue();                                              // step 0
+    issue();                                              // step 1
+    MIGAN_WAIT_VMCNT(DNI);                                // everything but the window of step 1 landed (G >= NKC >= 4 steps)
+    MIGAN_BARRIER_LDS();                                  // P1
+    stage1(0, 0, dgy0, dgx0);
+    MIGAN_BARRIER_LDS();                                  // P2
+    stage2(0);
+    dadvance();
+    MIGAN_WAIT_VMCNT(0);                                  // step 1 landed
+    MIGAN_BARRIER_LDS();                                  // barrier 0
+    for (int g = 0; g < G; ++g) {
+      // step g, first half: B multiplies chunk g; here: refill slot g & 1 (read by stage 1 of step g), stage 1 of step g+1
+      issue();                                            // step g+2
+      PPROF_MARK(0);
+      if (g + 1 < G) stage1((g + 1) & 1, dc, dgy0, dgx0);
+      PPROF_MARK(1);
+      MIGAN_BARRIER_LDS();
+      PPROF_MARK(3);
+      // second half: stage 2 of step g+1 -> A planes (g+1) & 1, last read by the MFMAs of step g-1
+      if (g + 1 < G) { stage2((g + 1) & 1); dadvance(); }
+      PPROF_MARK(14);
+      // window of step g+2 (issued a half-step ago) and weight planes of step g+1 (issued a step ago) landed; the planes of step g+2,
+      // issued now into the slot the MFMAs of step g have just finished with, stay in flight
+      bool newer = false;
+      if constexpr (!WRES) newer = issue_b();
+      if (newer) MIGAN_WAIT_VMCNT(DNB); else MIGAN_WAIT_VMCNT(0);
+      PPROF_MARK(2);
+      MIGAN_BARRIER_LDS();
+      PPROF_MARK(3);
+    }
+    PPROF_END(AT);
+    return;
+  }
+
+  // ================================================= group B ============================================================================
+  const int wb = wave_u - NA;
+  const int rb = wb & 1, cb = wb >> 1;                           // row block (32 GEMM rows), column group (NT / 4 columns)
+  const int l31 = lane & 31, half = lane >> 5;
+  f16v acc[NTIW], accp[NTIW];
+#pragma unroll
+  for (int j = 0; j < NTIW; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc[j][r] = 0.0f; accp[j][r] = 0.0f; }
+  auto mfma_chunk = [&](int abuf, int bbuf, bool first) {
+    const char* ab = lds + OFF_A + abuf * L::A_BUF + (rb * 32 + l31) * 32 + half * 16;
+    const char* bb = lds + OFF_B + bbuf * L::B_CHUNK + half * 16;
+    const f4 a_hi = ld4(reinterpret_cast<const float*>(ab)), a_lo = ld4(reinterpret_cast<const float*>(ab + MT * 32));
+#pragma unroll
+    for (int j = 0; j < NTIW; ++j) {
+      const char* q = bb + ((cb * NTIW + j) * 32 + l31) * 32;
+      const f4 b_hi = ld4(reinterpret_cast<const float*>(q)), b_lo = ld4(reinterpret_cast<const float*>(q + NT * 32));
+      if (first) acc[j] = f16v{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      acc[j] = MIGAN_MFMA_F16_32X32X16(a_lo, b_hi, acc[j]);
+      acc[j] = MIGAN_MFMA_F16_32X32X16(a_hi, b_lo, acc[j]);
+      acc[j] = MIGAN_MFMA_F16_32X32X16(a_hi, b_hi, acc[j]);
+    }
+  };
+  const float acc_scale = reinterpret_cast<const float*>(p.wsplit)[-4];
+  const float gain_s = 1.41421356237309515f * acc_scale;         // (no noise on these layers: the scale folds into the activation gain, exactly)
+  const size_t img_out_bytes = (size_t)HO * WO * p.CO * 4;
+  int ck = 0, cn0 = 0, cb0 = 0, cgy0 = 0, cgx0 = 0, pn0 = 0, pb0 = 0, pgy0 = 0, pgx0 = 0;
+  TileCur ctc = tile0;
+  auto ccoords = [&]() { cn0 = ctc.n * NT; cb0 = ctc.b; cgy0 = ctc.y * GH; cgx0 = ctc.x * GW; };
+  ccoords();
+  // transpose patch (as sepconv_pipe_kernel: [32 rows][32 channels] fp32, 16-byte slots XOR-swizzled by (row >> 1) & 7)
+  float* const t_s = reinterpret_cast<float*>(lds + OFF_T) + wb * (32 * 32);
+  const int q4 = lane & 7, prow = lane >> 3;
+  int twr[4];
+  {
+    const int u = (l31 >> 2) ^ (2 * half);
+#pragma unroll
+    for (int v = 0; v < 4; ++v) twr[v] = (4 * half) * 32 + ((u ^ ((v & 1) + 4 * (v >> 1))) << 2) + (l31 & 3);
+  }
+  const int trd0 = prow * 32 + ((q4 ^ (prow >> 1)) << 2), trd1 = prow * 32 + ((q4 ^ (prow >> 1) ^ 4) << 2);
+  auto stage_block = [&](const f16v& a) {
+    MIGAN_WAVE_SYNC();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) t_s[twr[((r >> 1) & 1) + 2 * ((r >> 2) & 1)] + ((r & 3) + 8 * (r >> 2)) * 32] = a[r];
+    MIGAN_WAVE_SYNC();
+  };
+  f4 tv[4];
+  auto fetch_block = [&]() {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) tv[q] = ld4(t_s + ((q & 1) ? trd1 : trd0) + q * 8 * 32);
+  };
+  // pixel of (q, lane): GEMM row 32 rb + 8 q + prow -> tile row 2 rb + (q >> 1), column 8 (q & 1) + prow
+  auto finish_block = [&](int j) {
+    char* yb = reinterpret_cast<char*>(p.y) + (size_t)pb0 * img_out_bytes;
+    const unsigned pix0 = (unsigned)((pgy0 + 2 * rb) * WO + pgx0 + prow);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const f4 v = act4g(tv[q], gain_s);
+      const unsigned pix = pix0 + (unsigned)((q >> 1) * WO + (q & 1) * 8);
+      Io<0>::st(yb, (pix * (unsigned)p.CO + (unsigned)(pn0 + (cb * NTIW + j) * 32 + q4 * 4)) * 4u, v);
+    }
+  };
+  auto hand_over = [&]() {
+    stage_block(acc[0]);
+#pragma unroll
+    for (int j = 1; j < NTIW; ++j) accp[j] = acc[j];
+    pn0 = cn0; pb0 = cb0; pgy0 = cgy0; pgx0 = cgx0;
+    if (++ck < T) { tile_next(ctc); ccoords(); }
+  };
+  MIGAN_BARRIER_LDS();                                          // P1
+  MIGAN_BARRIER_LDS();                                          // P2
+  MIGAN_BARRIER_LDS();                                          // barrier 0
+  // first tile: nothing to finish under it
+#pragma unroll
+  for (int c = 0; c < NKC; ++c) {
+    mfma_chunk(c & 1, WRES ? c : (c & 1), c == 0);
+    if (c == NKC - 1) hand_over();
+    MIGAN_BARRIER_LDS();
+    MIGAN_BARRIER_LDS();
+  }
+  for (int t = 1; t < T; ++t) {
+#pragma unroll
+    for (int c = 0; c < NKC; ++c) {
+      PPROF_MARK(7);
+      if (c < NTIW) fetch_block();
+      mfma_chunk(c & 1, WRES ? c : (c & 1), c == 0);
+      PPROF_MARK(4);
+      if (c < NTIW) {
+        finish_block(c);
+        if (c + 1 < NTIW) stage_block(accp[c + 1 < NTIW ? c + 1 : 0]);
+      }
+      PPROF_MARK(9);
+      if (c == NKC - 1) hand_over();
+      PPROF_MARK(7);
+      MIGAN_BARRIER_LDS();
+      MIGAN_BARRIER_LDS();
+      PPROF_MARK(6);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < NTIW; ++j) {
+    fetch_block();
+    finish_block(j);
+    if (j + 1 < NTIW) stage_block(accp[j + 1 < NTIW ? j + 1 : 0]);
+  }
+  PPROF_MARK(9);
+  PPROF_END(AT);
+}
+
 }  // namespace migan

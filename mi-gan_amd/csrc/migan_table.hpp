@@ -99,5 +99,16 @@ struct PipeSlice {
   const PipeEntry* entries;
   int n;
 };
+// sepconv_pipedown_kernel instantiations: the fused down=2 layer, one workgroup owns all NT = Cout output channels
+struct DownEntry {
+  int NT, cin, ring, na;
+  SepKernelFn fn;
+  const char* name;
+  size_t lds_bytes;
+};
+struct DownSlice {
+  const DownEntry* entries;
+  int n;
+};
 
 }  // namespace migan

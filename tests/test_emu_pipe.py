@@ -31,9 +31,9 @@ def small_grids(request, lib):
     yield
     lib.set_tuning("pipe_min_tiles", 256)
     lib.set_tuning("pipe_grid", 256)
-    lib.set_tuning("pipe", 7)
+    lib.set_tuning("pipe", 15)
     lib.set_tuning("pipe_na", 4)
-    lib.set_tuning("pipe_na8", 3)
+    lib.set_tuning("pipe_na8", 11)
 
 
 PIPE = "migan::sepconv_pipe_kernel<"
@@ -75,3 +75,20 @@ def test_pipe_off_takes_the_one_tile_kernels(lib, pkg):
 def test_single_image_keeps_the_latency_tiles(lib, pkg):
     run_sepconv_case(lib, pkg, HostMem(), cin=64, cout=64, h=16, w=32, batch=1, noise=True, seed=3)
     assert lib.last_kernel().startswith("migan::sepconv_kernel<"), lib.last_kernel()
+
+DOWN = "migan::sepconv_pipedown_kernel<"
+
+
+@pytest.mark.parametrize("h,w,batch", [(16, 32, 2), (8, 32, 3), (24, 64, 2), (32, 32, 5)])
+@pytest.mark.parametrize("cin,cout", [(64, 128), (128, 256)])
+def test_fused_down(lib, pkg, h, w, batch, cin, cout):
+    """down=2 as one launch: depthwise + FIR-down feed the 1x1 through LDS (4 x 16 low-resolution tiles, image borders = the FIR's zero padding)"""
+    lib.set_tuning("pipe", 15)
+    run_sepconv_case(lib, pkg, HostMem(), cin=cin, cout=cout, h=h, w=w, batch=batch, down=2, seed=11)
+    assert lib.last_kernel().startswith(DOWN + f"{cout}, {cin}, "), lib.last_kernel()
+
+
+def test_fused_down_off_takes_the_two_kernel_form(lib, pkg):
+    lib.set_tuning("pipe", 7)
+    run_sepconv_case(lib, pkg, HostMem(), cin=64, cout=128, h=16, w=32, batch=2, down=2, seed=11)
+    assert lib.last_kernel().startswith("migan::sepconv_kernel<3,"), lib.last_kernel()

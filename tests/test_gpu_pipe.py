@@ -32,9 +32,9 @@ def knobs(request, lib):
     yield
     lib.set_tuning("pipe_min_tiles", 256)
     lib.set_tuning("pipe_grid", 256)
-    lib.set_tuning("pipe", 7)
+    lib.set_tuning("pipe", 15)
     lib.set_tuning("pipe_na", 4)
-    lib.set_tuning("pipe_na8", 3)
+    lib.set_tuning("pipe_na8", 11)
 
 
 # (h, w, batch, persistent workgroups): 0 = the default grid (one per CU)
@@ -102,7 +102,19 @@ def test_pipelined_forward_is_deterministic_and_matches_the_one_tile_kernels(pkg
     try:
         y0, names0 = run()
     finally:
-        lib.set_tuning("pipe", 7)
+        lib.set_tuning("pipe", 15)
     assert not any(n.startswith(PIPE) for n in names0)
     scale = float(ys[0].abs().max())
     assert float((ys[0] - y0[0]).abs().max()) <= 2e-5 * max(1.0, scale)
+
+DOWN = "migan::sepconv_pipedown_kernel<"
+
+
+@pytest.mark.parametrize("h,w,batch,grid", [(128, 128, 8, 0), (16, 32, 3, 8), (256, 256, 2, 0), (64, 96, 3, 64)])
+@pytest.mark.parametrize("cin,cout", [(64, 128), (128, 256)])
+def test_fused_down(lib, pkg, dev, h, w, batch, grid, cin, cout):
+    """down=2 as one launch: depthwise + FIR-down feed the 1x1 through LDS"""
+    _grid(lib, grid)
+    lib.set_tuning("pipe", 15)
+    run_sepconv_case(lib, pkg, CudaMem(dev), cin=cin, cout=cout, h=h, w=w, batch=batch, down=2, seed=11)
+    assert lib.last_kernel().startswith(DOWN + f"{cout}, {cin}, "), lib.last_kernel()
