@@ -104,7 +104,8 @@ struct Tuning {
   int debug_split = 0;         // diagnostics: keep the two-sub-batch execution in keep-intermediates mode
   int stagger_pct = 22;        // MIGAN_STAGGER_PCT: the next sub-batch starts after this share of a forward's launches
   int pipe = 15;               // MIGAN_PIPE bit mask: software-pipelined persistent kernels (sepconv_pipe_kernel; fp32 storage, f16x2 GEMM) for
-                               // 1 plain (+ fused ToRGB) layers, 2 the fused-FromRGB layer, 4 FIR-up layers, 8 down=2 layers as one fused launch
+                               // 1 plain (+ fused ToRGB) layers, 2 the fused-FromRGB layer, 4 FIR-up layers, 8 down=2 layers as one fused launch, 16 (off) FIR-up
+                               // layers with more than 64 output channels as 64-column chunks
                                // (sepconv_pipedown_kernel) -- wherever an instantiation exists
                                // (the 512 x 512 layers of migan-512: -5 / -10 / -9 % per layer, profiles/r04_pipe_layers.txt)
   int pipe_grid = 256;         // MIGAN_PIPE_GRID: persistent workgroups of those launches (one 12- or 16-wave workgroup per CU on MI355X)
@@ -340,9 +341,16 @@ inline const PipeEntry* pick_pipe(const Geo& g, int cin, int cout, int batch, bo
   const PipeSlice sl = pipe_slice();
   for (int i = 0; i < sl.n; ++i) {
     const PipeEntry& e = sl.entries[i];
-    const int na = (tuning().pipe_na8 & bit) ? 8 : tuning().pipe_na;
-    if (e.mode == g.mode && e.NT == g.NT && e.cin == cin && e.fromrgb == g.fromrgb && e.torgb == fused_rgb && e.na == na && cout == g.NT * g.nchunks &&
-        (PipeResident(e) ? g.nchunks == 1 : true))
+    int na = (tuning().pipe_na8 & bit) ? 8 : tuning().pipe_na;
+    if (g.mode == MODE_NORMAL && g.NT == 128) na = 4;    // (the 128-column tiles exist with 4 depthwise waves only: migan_pipe_table.inc)
+    // FIR-up layers always run 64-column tiles here (the shared result tile of 128 columns does not fit beside the ring): a layer
+    // with more output channels is walked as cout / 64 column chunks per pixel tile, whatever column tile the one-tile plan uses
+    const int nt = g.mode == MODE_UP ? 64 : g.NT;
+    // ... and only where that is the whole layer (synthesis.b512.conv1), unless pipe bit 16 asks for the chunked form: it recomputes the
+    // depthwise stage per 64-column chunk and measured 10-30 % SLOWER than the 128-column one-tile kernels on synthesis.b256 / b128 / b64 .conv1
+    if (g.mode == MODE_UP && cout != nt && !(tuning().pipe & 16)) continue;
+    if (e.mode == g.mode && e.NT == nt && e.cin == cin && e.fromrgb == g.fromrgb && e.torgb == fused_rgb && e.na == na && cout % nt == 0 &&
+        cout == g.NT * g.nchunks && (PipeResident(e) ? cout == nt : true))
       return &e;
   }
   return nullptr;
@@ -543,9 +551,11 @@ inline void launch_sepconv(Geo g, const SepArgs& a, rt::stream_t stream) {
   const bool fused_rgb = a.trgb_w != nullptr;
   if (const PipeEntry* pe = pick_pipe(g, a.CI, a.CO, a.B, fused_rgb, a.u8_img != nullptr)) {
     MIGAN_CHECK(a.wsplit != nullptr, MIGAN_EINVAL, "internal: the pipelined kernel needs the fp16 weight planes");
-    const unsigned tiles = tiles_of(g, a.B);
+    SepArgs ap = a;
+    ap.nchunks = a.CO / pe->NT;                          // (FIR-up: 64-column chunks, see pick_pipe)
+    const unsigned tiles = (unsigned)(g.tiles_x * g.tiles_y * ap.nchunks * a.B);
     const unsigned grid = std::min(tiles, (unsigned)tuning().pipe_grid);
-    rt_check(rt::launch(pe->fn, a, grid, (unsigned)pipe_threads(pe->na), pe->lds_bytes, stream), pe->name);
+    rt_check(rt::launch(pe->fn, ap, grid, (unsigned)pipe_threads(pe->na), pe->lds_bytes, stream), pe->name);
     last_kernel_ref() = pe->name;
     return;
   }

@@ -92,3 +92,19 @@ def test_fused_down_off_takes_the_two_kernel_form(lib, pkg):
     lib.set_tuning("pipe", 7)
     run_sepconv_case(lib, pkg, HostMem(), cin=64, cout=128, h=16, w=32, batch=2, down=2, seed=11)
     assert lib.last_kernel().startswith("migan::sepconv_kernel<3,"), lib.last_kernel()
+
+@pytest.mark.parametrize("cin,cout,h,w,batch", [(256, 128, 8, 16, 2), (256, 128, 12, 20, 3), (512, 256, 6, 14, 2), (512, 512, 8, 8, 2)])
+def test_fir_up_streamed_weight_planes(lib, pkg, cin, cout, h, w, batch):
+    """FIR-up layers with more input / output channels: 64-column chunks per pixel tile, weight planes through the two-slot ring
+    (tuning bit 16: off in the default plan, where it measured slower than the one-tile kernels)"""
+    lib.set_tuning("pipe", 31)
+    lib.set_tuning("pipe_na", 4)
+    run_sepconv_case(lib, pkg, HostMem(), cin=cin, cout=cout, h=h, w=w, batch=batch, up=2, noise=True, skip=True, seed=17)
+    assert lib.last_kernel().startswith(PIPE + f"2, 64, {cin}, false, false"), lib.last_kernel()
+
+@pytest.mark.parametrize("h,w,batch", [(16, 32, 2), (8, 16, 3), (24, 16, 2)])
+@pytest.mark.parametrize("torgb", [False, True])
+def test_plain_128_to_128(lib, pkg, h, w, batch, torgb):
+    """the 256 x 256 layers of migan-512: 128-column tiles (two blocks per B wave), weight planes streamed through the two-slot ring"""
+    run_sepconv_case(lib, pkg, HostMem(), cin=128, cout=128, h=h, w=w, batch=batch, noise=True, torgb=torgb, with_prev=torgb, seed=19)
+    assert lib.last_kernel().startswith(PIPE + "0, 128, 128, false, " + ("true" if torgb else "false")), lib.last_kernel()

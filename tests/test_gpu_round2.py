@@ -26,7 +26,7 @@ def tuned(pkg):
     lib = pkg.load_library()
     changed = {}
     defaults = dict(kc16=0, kc16_minw=3, w3=3, wide=3, nt256=1, persist_min=8192, persist_grid=512, streams=2, stagger=-1,
-                    small=1, small_max_wgs=512, small_kc=64, small_up32=1, small_dwfir=1, small_ksplit=1)
+                    small=1, small_max_wgs=512, small_kc=64, small_up32=1, small_dwfir=1, small_ksplit=1, pipe=15)
 
     def set_(key, value):
         changed[key] = True
@@ -157,6 +157,7 @@ def test_sepconv_three_workgroup_tiles(pkg, dev, tuned, storage, case):
 
 def test_generator_512_with_three_workgroup_tiles(pkg, dev, tuned):
     tuned("w3", 7)
+    tuned("pipe", 0)            # (the default plan runs these layers on the pipelined kernels; the one-tile forms stay covered here)
     res, seed, batch = 512, 32, 2
     m, sd = _model(pkg, res, seed, dev)
     x = pkg.synth.make_input(batch, res, seed=seed)
@@ -168,6 +169,7 @@ def test_generator_512_with_three_workgroup_tiles(pkg, dev, tuned):
 
 def test_generator_512_with_kc16_tiles(pkg, dev, tuned):
     tuned("kc16", 7)
+    tuned("pipe", 0)
     res, seed, batch = 512, 32, 2
     m, sd = _model(pkg, res, seed, dev)
     x = pkg.synth.make_input(batch, res, seed=seed)
