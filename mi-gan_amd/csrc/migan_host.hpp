@@ -105,14 +105,17 @@ struct Tuning {
   int stagger_pct = 22;        // MIGAN_STAGGER_PCT: the next sub-batch starts after this share of a forward's launches
   int pipe = 15;               // MIGAN_PIPE bit mask: software-pipelined persistent kernels (sepconv_pipe_kernel; fp32 storage, f16x2 GEMM) for
                                // 1 plain (+ fused ToRGB) layers, 2 the fused-FromRGB layer, 4 FIR-up layers, 8 down=2 layers as one fused launch, 16 (off) FIR-up
-                               // layers with more than 64 output channels as 64-column chunks
+                               // layers with more than 64 output channels as 64-column chunks, 32 (off) the 256 / 512-channel plain layers as 128-column chunks
                                // (sepconv_pipedown_kernel) -- wherever an instantiation exists
                                // (the 512 x 512 layers of migan-512: -5 / -10 / -9 % per layer, profiles/r04_pipe_layers.txt)
   int pipe_grid = 256;         // MIGAN_PIPE_GRID: persistent workgroups of those launches (one 12- or 16-wave workgroup per CU on MI355X)
   int pipe_na = 4;             // waves of the depthwise group of those workgroups (4 or 8), for the layers in pipe_na8 the other value
-  int pipe_na8 = 11;           // bit mask like `pipe`: layers whose depthwise group has 8 waves whatever pipe_na says (default: plain, fused-FromRGB and
-                               // fused down=2 layers run 8 + 8 waves, FIR-up layers 4 + 8: profiles/r04_pipe_layers.txt)
+  int pipe_na8 = 9;            // bit mask like `pipe` (bits 1, 2, 4): layers whose depthwise group has 8 waves whatever pipe_na says (default: plain layers
+                               // run 8 + 8 waves, fused-FromRGB and FIR-up layers 4 + 8: profiles/r04_pipe_layers.txt)
+  int pipe_dna = 12;           // depthwise + FIR waves of the fused down=2 kernel: 4 or 8 (+ 8 GEMM / epilogue waves) or 12 (+ 4)
   int pipe_min_tiles = 256;    // launches with fewer tiles keep the one-tile-per-workgroup kernels
+  int pipe_min_batch = 1;      // smallest batch that takes them (1: a single-image forward runs them on its 512x512 / 256x256 layers too -- 2048 / 512 tiles;
+                               // latency_b1 0.70 -> 0.66 ms; its other layers run the latency tiles, so it is not bit-identical to a batched forward either way)
 };
 inline Tuning& tuning() {
   static Tuning t = [] {
@@ -334,18 +337,21 @@ PipeSlice pipe_slice();
 inline bool PipeResident(const PipeEntry& e) { return (e.cin / 32) * (2 * e.NT * 64) <= 32 * 1024; }    // all weight planes of a column tile stay in LDS
 inline const PipeEntry* pick_pipe(const Geo& g, int cin, int cout, int batch, bool fused_rgb, bool u8) {
   const int bit = g.fromrgb ? 2 : (g.mode == MODE_UP ? 4 : 1);
-  if (!(tuning().pipe & bit) || g.stv != 0 || g.gemmv != 2 || !g.maing || g.wide || g.MT != 128 || g.KC != 32 || g.lgIMGS != 0) return nullptr;
+  // (pipe bit 32, experiment, off: the 256 / 512-channel plain layers -- sepconv_wide_kernel's -- as 128-column chunks of the pipelined kernel:
+  // encoder.b128.conv1 0.379 -> 0.373 ms, the 512-channel layers 0.30 -> 0.37 (depthwise recomputed per chunk): profiles/LOG.md)
+  const bool wide_as_chunks = g.wide && (tuning().pipe & 32) && !fused_rgb && g.mode == MODE_NORMAL;
+  if (!(tuning().pipe & bit) || g.stv != 0 || g.gemmv != 2 || !g.maing || (g.wide && !wide_as_chunks) || g.MT != 128 || g.KC != 32 || g.lgIMGS != 0) return nullptr;
   if (g.mode != MODE_NORMAL && g.mode != MODE_UP) return nullptr;
-  if (batch < 2 || g.tiles_x * g.tiles_y * g.nchunks * batch < tuning().pipe_min_tiles) return nullptr;
+  if (batch < tuning().pipe_min_batch || g.tiles_x * g.tiles_y * g.nchunks * batch < tuning().pipe_min_tiles) return nullptr;
   (void)u8;
   const PipeSlice sl = pipe_slice();
   for (int i = 0; i < sl.n; ++i) {
     const PipeEntry& e = sl.entries[i];
-    int na = (tuning().pipe_na8 & bit) ? 8 : tuning().pipe_na;
-    if (g.mode == MODE_NORMAL && g.NT == 128) na = 4;    // (the 128-column tiles exist with 4 depthwise waves only: migan_pipe_table.inc)
     // FIR-up layers always run 64-column tiles here (the shared result tile of 128 columns does not fit beside the ring): a layer
     // with more output channels is walked as cout / 64 column chunks per pixel tile, whatever column tile the one-tile plan uses
-    const int nt = g.mode == MODE_UP ? 64 : g.NT;
+    const int nt = g.mode == MODE_UP ? 64 : (wide_as_chunks ? 128 : g.NT);
+    int na = (tuning().pipe_na8 & bit) ? 8 : tuning().pipe_na;
+    if ((g.mode == MODE_NORMAL && nt == 128) || g.mode == MODE_UP) na = 4;    // (these forms exist with 4 depthwise waves only: migan_pipe_table.inc)
     // ... and only where that is the whole layer (synthesis.b512.conv1), unless pipe bit 16 asks for the chunked form: it recomputes the
     // depthwise stage per 64-column chunk and measured 10-30 % SLOWER than the 128-column one-tile kernels on synthesis.b256 / b128 / b64 .conv1
     if (g.mode == MODE_UP && cout != nt && !(tuning().pipe & 16)) continue;
@@ -360,10 +366,10 @@ inline const PipeEntry* pick_pipe(const Geo& g, int cin, int cout, int batch, bo
 // launch has enough tiles.  Same decision for every batch >= 2 (see pick_pipe).
 DownSlice pipedown_slice();
 inline const DownEntry* pick_pipedown(int cin, int cout, int h_in, int w_in, int batch, int stv, int gemmv) {
-  if (!(tuning().pipe & 8) || stv != 0 || gemmv != 2 || batch < 2) return nullptr;
+  if (!(tuning().pipe & 8) || stv != 0 || gemmv != 2 || batch < tuning().pipe_min_batch) return nullptr;
   if (h_in % 8 != 0 || w_in % 32 != 0) return nullptr;                        // whole 4 x 16 low-resolution tiles
   if ((h_in / 8) * (w_in / 32) * batch < tuning().pipe_min_tiles) return nullptr;
-  const int na = (tuning().pipe_na8 & 8) ? 8 : tuning().pipe_na;
+  const int na = tuning().pipe_dna;
   const DownSlice sl = pipedown_slice();
   const DownEntry* best = nullptr;
   for (int i = 0; i < sl.n; ++i) {
@@ -588,7 +594,7 @@ inline void launch_pipedown(const DownEntry& e, SepArgs a, rt::stream_t stream) 
   a.tiles_x = a.W / 32; a.tiles_y = a.H / 8; a.nchunks = 1;
   a.prof = prof_buffer();
   const unsigned tiles = (unsigned)(a.tiles_x * a.tiles_y * a.B);
-  rt_check(rt::launch(e.fn, a, std::min(tiles, (unsigned)tuning().pipe_grid), (unsigned)pipe_threads(e.na), e.lds_bytes, stream), e.name);
+  rt_check(rt::launch(e.fn, a, std::min(tiles, (unsigned)tuning().pipe_grid), (unsigned)((e.na + e.nb) * 64), e.lds_bytes, stream), e.name);
   last_kernel_ref() = e.name;
 }
 inline void launch_dwfir(const DwGeo& g, DwFirArgs a, rt::stream_t stream, int stv = 0) {
@@ -1751,7 +1757,9 @@ int migan_set_tuning(const char* key, int value) {
   else if (k == "pipe_grid") t.pipe_grid = std::max(8, value / 8 * 8);
   else if (k == "pipe_na") t.pipe_na = value == 8 ? 8 : 4;
   else if (k == "pipe_na8") t.pipe_na8 = value;
+  else if (k == "pipe_dna") t.pipe_dna = value;
   else if (k == "pipe_min_tiles") t.pipe_min_tiles = std::max(1, value);
+  else if (k == "pipe_min_batch") t.pipe_min_batch = std::max(1, value);
   else throw Error(MIGAN_EINVAL, "unknown tuning key: " + k);
   MIGAN_API_END
 }

@@ -42,10 +42,15 @@ struct PipeLds {
   static constexpr int OFF_A = OFF_IN + R * IN_SLOT;
   static constexpr int OFF_B = OFF_A + 2 * A_BUF;
   static constexpr int OFF_W = OFF_B + NBUF_B * B_CHUNK;            // depthwise taps, per chunk tap-major [9][32] + bias [32]
-  static constexpr int OFF_F = OFF_W + NKC * 1280;                  // FROMRGB: fromrgb weights per chunk input-major [4][32] + bias [32]
-  static constexpr int OFF_RGB = OFF_F + (FROMRGB ? NKC * 640 : 0); // FROMRGB: raw network input of the halo tile, two tiles
-  static constexpr int OFF_T = OFF_RGB + (FROMRGB ? 2 * 180 * 16 : 0);
-  static constexpr int T_SZ = MODE == MODE_UP ? 128 * (NT + 4) * 4 : kPipeBWaves * 32 * 32 * 4;   // FIR-up: shared result tile; plain: one transpose patch per B wave
+  static constexpr bool TAPS_RES = NKC <= 8;                        // all chunks resident; otherwise a two-chunk ring refilled through registers
+  // FROMRGB (the 1x1 conv 4 -> Cin as a bf16x3-split MFMA, K = 4 inputs + the bias against a "pixel is inside the image" flag):
+  static constexpr int OFF_F = OFF_W + (TAPS_RES ? NKC : 2) * 1280; // its B operand: per chunk [3 pieces][32 columns][8 bf16: w0..w3, bias, 0, 0, 0]
+  static constexpr int F_SZ = FROMRGB ? NKC * 3 * 32 * 16 : 0;
+  static constexpr int OFF_RGB = OFF_F + F_SZ;                      // its A operand, two tiles: [3 pieces][192 rows][8 bf16: x0..x3, flag, 0, 0, 0], then 16 zero bytes
+  static constexpr int RGB_BUF = 3 * 192 * 16;
+  static constexpr int OFF_T = OFF_RGB + (FROMRGB ? 2 * RGB_BUF + 16 : 0);
+  static constexpr int T_SZ = MODE == MODE_UP ? 128 * (64 + 4) * 4 : kPipeBWaves * 32 * 32 * 4;   // FIR-up: shared result tile of 64 columns (a 128-column
+                                                                    // layer passes its two halves through it one after the other); plain: one transpose patch per B wave
   static constexpr int OFF_P = OFF_T + T_SZ;                       // plain + ToRGB: per-pixel partial sums of the waves of column half 1, [128 pixels][4]
   static constexpr int TOTAL = OFF_P + (MODE == MODE_UP ? 0 : 128 * 16);
   static_assert(TOTAL <= 160 * 1024, "LDS budget");
@@ -138,89 +143,124 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(pipe_threads(NA), (NA + kPipeBWaves) / 4) 
     gx0_ = c.x * p.sx - p.off;
   };
 
-  // ---- FROMRGB: the input tile is act(fromrgb(network input)) (reference :194-195), BUILT instead of copied -- by every thread of the
-  // workgroup (item i = tid + j NBT of the [180 pixels][8 channel quads] tile; a thread's items all have channel quad tid & 7, so its
-  // 4 x 4 weights + bias are read once per chunk).  Each group keeps its own cursor over the K steps.
-  constexpr int NBT = pipe_threads(NA), BNI = (NITEMS + NBT - 1) / NBT;
+  // ---- FROMRGB: the input tile is act(fromrgb(network input)) (reference :194-195), BUILT instead of copied.  fromrgb is a 1x1
+  // convolution (4 -> Cin, with bias): it runs on the matrix cores like the other 1x1s, as v_mfma_f32_32x32x16_bf16 on bf16x3-split operands
+  // (x = h1 + h2 + h3, six products: fp32-grade, and bf16 has fp32's exponent range, so the unbounded network input needs no scaling).
+  // K = 5 of 16: the four input planes and a flag that is 1 inside the image and 0 on the conv's zero padding, against which the bias
+  // is multiplied -- a padding pixel comes out as exactly 0 = act(0), as the reference's F.pad of the activated tensor.  Group A turns the
+  // raw pixels of the next tile into the A operand pieces; group B (waves 0..5: one 32-pixel row block each) multiplies, activates and
+  // writes chunk s+2 of the tile while group A runs the depthwise stage of chunk s+1.  (Rounds 1-3 and the first form of this kernel did
+  // the 4 -> Cin products as scalar FMA chains on the VALU: half of this layer's instructions, profiles/r04_pipe_phase_profile.txt (4).)
   struct BuildCursor {
-    int is, ic, ik, slot, gy0, gx0, b0;
-    unsigned mask;                                       // bit j = item j of this thread is a pixel inside the image
-    TileCur tc;
+    int is, ic, ik, slot;
   };
-  auto build_mask = [&](BuildCursor& bc) {
-    bc.mask = 0;
-#pragma unroll
-    for (int j = 0; j < BNI; ++j) {
-      const int i = tid + j * NBT;
-      if (i < NITEMS) {
-        const int pix = i >> LG_QC;
-        const int ix = pix % IGW, iy = pix / IGW;
-        const int yy = bc.gy0 - 1 + iy, xx = bc.gx0 - 1 + ix;
-        if (yy >= 0 && yy < p.H && xx >= 0 && xx < p.W) bc.mask |= 1u << j;
-      }
-    }
-  };
-  auto build_begin = [&](BuildCursor& bc) {
-    bc.is = bc.ic = bc.ik = bc.slot = 0;
-    bc.tc = tile0;
-    int n0_;
-    tile_coords(bc.tc, n0_, bc.b0, bc.gy0, bc.gx0);
-    build_mask(bc);
-  };
-  // build this thread's share of step bc.is into its ring slot, then move the cursor on; returns true when that was the last chunk of a tile
-  auto build_step = [&](BuildCursor& bc) -> bool {
+  auto build_begin = [&](BuildCursor& bc) { bc.is = bc.ic = bc.ik = bc.slot = 0; };
+  // move the cursor one K step on; returns true when that was the last chunk of a tile
+  auto build_advance = [&](BuildCursor& bc) -> bool {
     if (bc.is >= G) return false;
-    if (!MIGAN_ABL(16)) {
-      float* in_s = reinterpret_cast<float*>(lds + L::OFF_IN + bc.slot * L::IN_SLOT);
-      const float* rgb_s = reinterpret_cast<const float*>(lds + L::OFF_RGB + (bc.ik & 1) * NPIX * 16);
-      const float* wr = reinterpret_cast<const float*>(lds + L::OFF_F) + bc.ic * 160 + (tid & (QC - 1)) * 4;
-      const f4 w0 = ld4(wr), w1 = ld4(wr + 32), w2 = ld4(wr + 64), w3 = ld4(wr + 96), bb = ld4(wr + 128);
-#pragma unroll
-      for (int j = 0; j < BNI; ++j) {
-        const int i = tid + j * NBT;
-        if (i < NITEMS) {
-          f4 v = {0.f, 0.f, 0.f, 0.f};
-          if (bc.mask & (1u << j)) v = act4(fromrgb_quad(ld4(rgb_s + (i >> LG_QC) * 4), w0, w1, w2, w3, bb));
-          st4(in_s + i * 4, v);
-        }
-      }
-    }
     ++bc.is;
     bc.slot = bc.slot + 1 == R ? 0 : bc.slot + 1;
     if (++bc.ic < NKC) return false;
     bc.ic = 0;
-    if (++bc.ik < T) {
-      int n0_;
-      tile_next(bc.tc);
-      tile_coords(bc.tc, n0_, bc.b0, bc.gy0, bc.gx0);
-      build_mask(bc);
-    }
+    ++bc.ik;
     return true;
   };
 
+  // unit u of a step = row block u (32 halo-tile pixels) x the chunk's 32 channels: A pieces from the pixel buffer of the step's tile
+  // (lanes 32..63 = k 8..15 read the zero slot), B pieces of the chunk (gain folded in), six bf16 MFMAs (smallest products first),
+  // leaky-relu + clamp on the accumulators, one ds_write_b32 per value (lane = channel).  Rows 180..191 of a slot are never read.
+  // (with 8 + 8 waves the six units of a step are split: group B's waves 0..2 take units 0..2, group A's waves 3..5 units 3..5 -- the
+  // depthwise group has the slack for them; with 4 + 8 waves group A is the busy one and group B's waves 0..5 take them all)
+  auto build_units = [&](const BuildCursor& bc, int wave, int nwaves) {
+    if (bc.is >= G || MIGAN_ABL(16)) return;
+    const int bl31 = tid & 31, bhalf = (tid >> 5) & 1;
+    const char* r_s = lds + L::OFF_RGB;
+    float* in_s = reinterpret_cast<float*>(lds + L::OFF_IN + bc.slot * L::IN_SLOT);
+    for (int u = wave; u >= 0 && u < 6; u += nwaves) {
+      const char* ap = bhalf ? r_s + 2 * L::RGB_BUF : r_s + (bc.ik & 1) * L::RGB_BUF + (u * 32 + bl31) * 16;
+      const char* bp = bhalf ? r_s + 2 * L::RGB_BUF : lds + L::OFF_F + bc.ic * (3 * 32 * 16) + bl31 * 16;
+      const int astr = bhalf ? 0 : 192 * 16, bstr = bhalf ? 0 : 32 * 16;
+      f4 a[3], b[3];
+#pragma unroll
+      for (int pc = 0; pc < 3; ++pc) {
+        a[pc] = ld4(reinterpret_cast<const float*>(ap + pc * astr));
+        b[pc] = ld4(reinterpret_cast<const float*>(bp + pc * bstr));
+      }
+      f16v c = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      c = MIGAN_MFMA_BF16_32X32X16(a[2], b[0], c);
+      c = MIGAN_MFMA_BF16_32X32X16(a[1], b[1], c);
+      c = MIGAN_MFMA_BF16_32X32X16(a[0], b[2], c);
+      c = MIGAN_MFMA_BF16_32X32X16(a[1], b[0], c);
+      c = MIGAN_MFMA_BF16_32X32X16(a[0], b[1], c);
+      c = MIGAN_MFMA_BF16_32X32X16(a[0], b[0], c);
+      float* o = in_s + (u * 32 + 4 * bhalf) * KC + bl31;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float v = c[r];                                                   // = gain * fromrgb(x)
+        o[((r & 3) + 8 * (r >> 2)) * KC] = MIGAN_CLAMP(fmaxf(v, v * 0.2f), -256.0f, 256.0f);
+      }
+    }
+  };
+
+  // issue priority to the depthwise group where it is the critical one by a margin (profiles/r04_pipe_phase_profile.txt): four waves beside
+  // the fused-FromRGB build.  (Priority to group B in the other forms: -2 % on the 64 -> 64 + ToRGB layer, +4 % on the FIR-up layer: not used.)
   if (groupA) {
+    if (FROMRGB && NA == 4) MIGAN_SETPRIO(2);
     // =============================================== group A: DMA issue + depthwise stage ===========================================
     const int lt = tid;
     float* const w_s = reinterpret_cast<float*>(lds + L::OFF_W);
-    // depthwise taps + bias of every chunk, once per workgroup: conv1.weight [CIN][9] -> per chunk tap-major [9][32], then bias [32]
-    for (int i = lt; i < CIN * 9 / 4; i += AT) {
-      const f4 v = ld4(p.wdw + i * 4);
+    // depthwise taps + bias: conv1.weight [CIN][9] -> per chunk tap-major [9][32], then bias [32].  All chunks once per workgroup where they
+    // fit (TAPS_RES), otherwise chunk s+2 is fetched into registers during interval s and stored into the ring half the depthwise stage of
+    // step s has finished with
+    constexpr bool TAPS_RES = L::TAPS_RES;
+    if constexpr (TAPS_RES) {
+      for (int i = lt; i < CIN * 9 / 4; i += AT) {
+        const f4 v = ld4(p.wdw + i * 4);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int f = i * 4 + e, ch = f / 9, tap = f - ch * 9;
-        w_s[(ch >> 5) * 320 + tap * 32 + (ch & 31)] = v[e];
+        for (int e = 0; e < 4; ++e) {
+          const int f = i * 4 + e, ch = f / 9, tap = f - ch * 9;
+          w_s[(ch >> 5) * 320 + tap * 32 + (ch & 31)] = v[e];
+        }
       }
+      for (int i = lt; i < CIN / 4; i += AT) st4(w_s + ((i * 4) >> 5) * 320 + 288 + ((i * 4) & 31), ld4(p.bdw + i * 4));
     }
-    for (int i = lt; i < CIN / 4; i += AT) st4(w_s + ((i * 4) >> 5) * 320 + 288 + ((i * 4) & 31), ld4(p.bdw + i * 4));
-    if constexpr (FROMRGB) {
-      // fromrgb.weight [CIN][4] -> per chunk input-major [4][32], then bias [32] (reference :186)
-      float* const f_s = reinterpret_cast<float*>(lds + L::OFF_F);
-      for (int i = lt; i < CIN; i += AT) {
-        const f4 v = ld4(p.frgb_w + i * 4);
+    f4 rtap = {0.f, 0.f, 0.f, 0.f};
+    auto load_taps = [&](int chunk) {                    // (72 threads: 4 consecutive floats of the chunk's [32][9] taps; 8 more: its bias)
+      if (lt < 72) rtap = ld4(p.wdw + chunk * 288 + lt * 4);
+      else if (lt < 80) rtap = ld4(p.bdw + chunk * 32 + (lt - 72) * 4);
+    };
+    auto store_taps = [&](int buf) {
+      float* wc = w_s + buf * 320;
+      if (lt < 72) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) f_s[(i >> 5) * 160 + e * 32 + (i & 31)] = v[e];
+        for (int e = 0; e < 4; ++e) {
+          const int f = lt * 4 + e;
+          wc[(f % 9) * 32 + f / 9] = rtap[e];
+        }
+      } else if (lt < 80) {
+        st4(wc + 288 + (lt - 72) * 4, rtap);
       }
-      for (int i = lt; i < CIN / 4; i += AT) st4(f_s + ((i * 4) >> 5) * 160 + 128 + ((i * 4) & 31), ld4(p.frgb_b + i * 4));
+    };
+    if constexpr (FROMRGB) {
+      // fromrgb.weight [CIN][4] + bias [CIN] (reference :186) -> B operand pieces, per chunk [3][32 columns][8 bf16]
+      char* const f_s = lds + L::OFF_F;
+      for (int i = lt; i < CIN; i += AT) {
+        const f4 w = ld4(p.frgb_w + i * 4) * 1.41421356237309515f;             // lrelu_agc's gain (positive) commutes with the leaky relu
+        u2v w1, w2, w3, b1, b2, b3;
+        split3_bf16(w, w1, w2, w3);
+        split3_bf16(f4{p.frgb_b[i] * 1.41421356237309515f, 0.f, 0.f, 0.f}, b1, b2, b3);
+        char* d = f_s + (i >> 5) * (3 * 32 * 16) + (i & 31) * 16;
+        *reinterpret_cast<u4v*>(d) = u4v{w1.x, w1.y, b1.x, 0u};
+        *reinterpret_cast<u4v*>(d + 32 * 16) = u4v{w2.x, w2.y, b2.x, 0u};
+        *reinterpret_cast<u4v*>(d + 2 * 32 * 16) = u4v{w3.x, w3.y, b3.x, 0u};
+      }
+      // rows 180..191 of both A-operand buffers (the sixth row block's padding) and the zero slot: written once
+      char* const r_s = lds + L::OFF_RGB;
+      for (int i = lt; i < 2 * 3 * 12; i += AT) {
+        const int buf = i / 36, rem = i % 36;
+        *reinterpret_cast<u4v*>(r_s + buf * L::RGB_BUF + (rem / 12) * (192 * 16) + (180 + rem % 12) * 16) = u4v{0u, 0u, 0u, 0u};
+      }
+      if (lt == 0) *reinterpret_cast<u4v*>(r_s + 2 * L::RGB_BUF) = u4v{0u, 0u, 0u, 0u};
     }
 
     // ---- 1x1 weight planes (split_weights_kernel: chunk-major [plane][CIN/32][CO][32] fp16) -> LDS, XOR swizzle on the SOURCE side ----
@@ -287,12 +327,15 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(pipe_threads(NA), (NA + kPipeBWaves) / 4) 
 
     // ---- FROMRGB: the raw 4-channel network input of the halo tile, one tile ahead, through registers into LDS (this group) ----------
     f4 rraw = {0.f, 0.f, 0.f, 0.f};
+    bool rvalid = false;
     auto load_raw = [&](int b0_, int gy0_, int gx0_) {
       f4 v = {0.f, 0.f, 0.f, 0.f};
+      rvalid = false;
       if (lt < NPIX) {
         const int ix = lt % IGW, iy = lt / IGW;
         const int yy = gy0_ - 1 + iy, xx = gx0_ - 1 + ix;
         if (yy >= 0 && yy < p.H && xx >= 0 && xx < p.W) {
+          rvalid = true;
           if (p.u8_img) {
             v = pack_pixel(p.u8_img, p.u8_mask, ((size_t)b0_ * p.H + yy) * p.W + xx);
           } else {
@@ -304,14 +347,23 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(pipe_threads(NA), (NA + kPipeBWaves) / 4) 
       }
       rraw = v;
     };
+    // raw pixel -> the three bf16 pieces of its A-operand row [x0, x1, x2, x3, flag, 0, 0, 0] (flag = 1.0 inside the image: exact in bf16)
     auto store_raw = [&](int buf) {
-      if (lt < NPIX) st4(reinterpret_cast<float*>(lds + L::OFF_RGB + buf * NPIX * 16) + lt * 4, rraw);
+      if (lt < NPIX) {
+        u2v h1, h2, h3;
+        split3_bf16(rraw, h1, h2, h3);
+        char* d = lds + L::OFF_RGB + buf * L::RGB_BUF + lt * 16;
+        *reinterpret_cast<u4v*>(d) = u4v{h1.x, h1.y, rvalid ? 0x3f80u : 0u, 0u};
+        *reinterpret_cast<u4v*>(d + 192 * 16) = u4v{h2.x, h2.y, 0u, 0u};
+        *reinterpret_cast<u4v*>(d + 2 * 192 * 16) = u4v{h3.x, h3.y, 0u, 0u};
+      }
     };
+
     // ---- depthwise 3x3 + bias + act (x 2^7) + fp16 hi/lo split of one chunk: one SEGH-row strip x 4 channels per thread --------------
     auto depthwise = [&](int slot, int chunk, int abuf) {
       if (MIGAN_ABL(4)) return;
       const float* in_s = reinterpret_cast<const float*>(lds + L::OFF_IN + slot * L::IN_SLOT);
-      const float* wc = w_s + chunk * 320;
+      const float* wc = w_s + (TAPS_RES ? chunk : (chunk & 1)) * 320;
       char* a_b = lds + L::OFF_A + abuf * L::A_BUF;
       const int c4 = lt & (QC - 1);
       const int gx = (lt >> LG_QC) & (GW - 1);
@@ -403,10 +455,11 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(pipe_threads(NA), (NA + kPipeBWaves) / 4) 
       if (rk < T) { tile_next(rtc); tile_coords(rtc, rn0, rb0, rgy0, rgx0); load_raw(rb0, rgy0, rgx0); }
       BuildCursor bcur;
       build_begin(bcur);
-      MIGAN_BARRIER_LDS();                                     // P1: taps, fromrgb weights, weight planes, raw(0) visible (B waits here too)
-      // produce(step s): build this group's share of its input tile; after the last chunk of a tile, hand the next tile's raw pixels over
+      MIGAN_BARRIER_LDS();                                     // P1: taps, fromrgb operands, weight planes, raw(0) visible (B waits here too)
+      // produce(step s): group B builds the input tile of that step; here: after the last chunk of a tile, hand the next tile's pixels over
       auto produce = [&]() {
-        if (build_step(bcur) && bcur.ik < T) {
+        if constexpr (NA == 8) build_units(bcur, (tid >> 6) >= 3 && (tid >> 6) < 6 ? (tid >> 6) : -1, 8);
+        if (build_advance(bcur) && bcur.ik < T) {
           store_raw(bcur.ik & 1);                               // raw(tile ik): that buffer was last read two tiles ago
           ++rk;
           if (rk < T) { tile_next(rtc); tile_coords(rtc, rn0, rb0, rgy0, rgx0); load_raw(rb0, rgy0, rgx0); }
@@ -431,6 +484,10 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(pipe_threads(NA), (NA + kPipeBWaves) / 4) 
       }
     } else {
       // ---- prologue: resident weight planes, the first R input chunks in flight -----------------------------------------------------
+      if constexpr (!TAPS_RES) {
+        load_taps(0); store_taps(0);
+        load_taps(1); store_taps(1);
+      }
       if constexpr (WRES) {
 #pragma unroll
         for (int c = 0; c < NKC; ++c) dma_b(in0, c, c);
@@ -456,9 +513,11 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(pipe_threads(NA), (NA + kPipeBWaves) / 4) 
         // MFMAs of step g-1) are free: refill them first, then the depthwise stage of step g+1
         if constexpr (!WRES) { if (g >= 1) issue_b(); }        // step g+1 (steps 0 and 1 were issued by the prologue)
         issue_in();                                            // step g+R
+        if constexpr (!TAPS_RES) { if (g + 2 < G) load_taps((dc + 1) % NKC); }      // taps of step g+2 (dc is the chunk of step g+1)
         PPROF_MARK(0);
         if (g + 1 < G) depthwise(dslot, dc, (g + 1) & 1);
         PPROF_MARK(1);
+        if constexpr (!TAPS_RES) { if (g + 2 < G) store_taps(g & 1); }              // ring half of step g: its depthwise stage ran an interval ago
         dslot = dslot + 1 == R ? 0 : dslot + 1;
         dc = dc + 1 == NKC ? 0 : dc + 1;
         // before the barrier that starts interval g+1: input of step g+2 and weights of step g+1 landed.  Everything issued before the
@@ -469,8 +528,10 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(pipe_threads(NA), (NA + kPipeBWaves) / 4) 
         PPROF_MARK(3);
       }
     }
-    if constexpr (MODE == MODE_UP || TORGB) {
-      MIGAN_BARRIER_LDS();                                     // the last tile: group B publishes its result tile / ToRGB partial sums
+    if constexpr (TORGB) MIGAN_BARRIER_LDS();                   // the last tile: group B hands its ToRGB partial sums over
+    if constexpr (MODE == MODE_UP) {
+#pragma unroll
+      for (int i = 0; i < 2 * (NT / 64) - 1; ++i) MIGAN_BARRIER_LDS();      // ... publishes its result tile, one 64-column half at a time
     }
     PPROF_END(AT);
     return;
@@ -541,8 +602,12 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(pipe_threads(NA), (NA + kPipeBWaves) / 4) 
 
   BuildCursor bcur;
   if constexpr (FROMRGB) build_begin(bcur);
+  auto build_step = [&](BuildCursor& bc) {
+    build_units(bc, NA == 8 && wb >= 3 ? -1 : wb, 8);
+    build_advance(bc);
+  };
   MIGAN_BARRIER_LDS();                                          // P1
-  if constexpr (FROMRGB) {                                      // this group's share of the input tiles of steps 0 and 1
+  if constexpr (FROMRGB) {                                      // the input tiles of steps 0 and 1
     build_step(bcur);
     build_step(bcur);
   }
@@ -764,13 +829,18 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(pipe_threads(NA), (NA + kPipeBWaves) / 4) 
     // ---- FIR-up layers (reference Upsample2d :79-103 after the 1x1): the 2x polyphase FIR needs the 3x3 neighbourhood of the GEMM
     // result, so the accumulators of a finished tile go to a dedicated LDS result tile during the first K step of the next tile
     // (published by that step's barrier) and the 6 x 14 interior pixels x NT/4 channel quads are worked off in the steps after it ----
-    constexpr int GS = NT + 4, QN = NT / 4, LG_QN = (QN == 16) ? 4 : 5;
-    static_assert(QN == 16 || QN == 32, "FIR-up tiles: 64 or 128 output channels");
+    // A 128-column layer passes its two 64-column halves through the result tile one after the other (phase h: the waves of column half h
+    // write, then all eight waves run that half's FIR items), half the K steps of the next tile each.
+    constexpr int GS = 64 + 4, QN = 16, LG_QN = 4, NH = NT / 64;
+    static_assert(NT == 64 || NT == 128, "FIR-up tiles: 64 or 128 output channels");
+    constexpr int SP = NKC / NH;                                // K steps per phase: one to write the half, SP - 1 for its items
+    static_assert(NKC % NH == 0 && SP >= 2, "too few K steps to hide the FIR epilogue under");
     constexpr int BT = kPipeBWaves * 64;
     constexpr int STEP = BT >> LG_QN;                           // GEMM rows between the items of a thread
     constexpr int ITEMS = MT * QN / BT;
     float* const g_s = reinterpret_cast<float*>(lds + L::OFF_T);
-    auto acc_to_lds = [&]() {
+    auto acc_to_lds = [&](int h) {
+      if (NH == 2 && cbk != h) return;                          // (wave-uniform)
 #pragma unroll
       for (int j = 0; j < NTIW; ++j)
 #pragma unroll
@@ -780,7 +850,7 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(pipe_threads(NA), (NA + kPipeBWaves) / 4) 
           const int ly = pgy0 + (row >> lgGW), lx = pgx0 + (row & (GW - 1));
           float v = accp[j][r];
           if (ly < 0 || ly >= p.H || lx < 0 || lx >= p.W) v = 0.0f;
-          g_s[row * GS + cbk * (NT / 2) + j * 32 + l31] = v;
+          g_s[row * GS + (NH == 2 ? j * 32 : cbk * 32) + l31] = v;
         }
     };
     const int c4 = tb & (QN - 1), m0 = tb >> LG_QN;
@@ -791,20 +861,20 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(pipe_threads(NA), (NA + kPipeBWaves) / 4) 
       f4 sk[2][2];
       float nzv[2][2];
     };
-    auto item_geo = [&](int k, int& m, unsigned& lpix, unsigned& loff) -> bool {
+    auto item_geo = [&](int k, int h, int& m, unsigned& lpix, unsigned& loff) -> bool {
       m = m0 + k * STEP;
       const int gy = m >> lgGW, gx = m & (GW - 1);
       if (gy < 1 || gy > GH - 2 || gx < 1 || gx > GW - 2) return false;
       const int ly = pgy0 + gy, lx = pgx0 + gx;
       if (ly >= p.H || lx >= p.W) return false;                  // ragged right / bottom edge of the tile grid
       lpix = (unsigned)((2 * ly) * p.WO + 2 * lx);
-      loff = (lpix * (unsigned)p.CO + (unsigned)(pn0 + c4 * 4)) * 4u;
+      loff = (lpix * (unsigned)p.CO + (unsigned)(pn0 + h * 64 + c4 * 4)) * 4u;
       return true;
     };
-    auto item_load = [&](int k, ItemIo& io) {
+    auto item_load = [&](int k, int h, ItemIo& io) {
       int m;
       unsigned lpix, loff;
-      if (!item_geo(k, m, lpix, loff)) return;
+      if (!item_geo(k, h, m, lpix, loff)) return;
       const char* sb = p.skip ? reinterpret_cast<const char*>(p.skip) + (size_t)pb0 * img_out_bytes : nullptr;
 #pragma unroll
       for (int a = 0; a < 2; ++a)
@@ -815,11 +885,11 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(pipe_threads(NA), (NA + kPipeBWaves) / 4) 
           io.sk[a][bb] = sb ? Io<0>::ld_once(sb, loff + dp * (unsigned)p.CO * 4u) : f4{0.f, 0.f, 0.f, 0.f};
         }
     };
-    auto item_finish = [&](int k, const ItemIo& io) {
+    auto item_finish = [&](int k, int h, const ItemIo& io) {
       if (MIGAN_ABL(2)) return;
       int m;
       unsigned lpix, loff;
-      if (!item_geo(k, m, lpix, loff)) return;
+      if (!item_geo(k, h, m, lpix, loff)) return;
       char* yb = reinterpret_cast<char*>(p.y) + (size_t)pb0 * img_out_bytes;
       f4 e[3], o[3];
 #pragma unroll
@@ -844,9 +914,9 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(pipe_threads(NA), (NA + kPipeBWaves) / 4) 
           if (!MIGAN_ABL(1)) Io<0>::st(yb, loff + (unsigned)(a * p.WO + bb) * (unsigned)p.CO * 4u, v);
         }
     };
-    // items of slice c (c = 1 .. NKC-1): an even share of the thread's ITEMS rows
-    constexpr int SL = NKC - 1;
-    auto slice_of = [](int k) { return 1 + k * SL / ITEMS; };
+    // step c of a tile: phase h = c / SP; its first step writes the half, step 1 + i of the phase runs the items k with slice_of(k) == i
+    constexpr int SL = SP - 1;
+    auto slice_of = [](int k) { return k * SL / ITEMS; };
     ItemIo io[2];
     // (first tile peeled off, for the reason given in the plain form)
 #pragma unroll
@@ -858,23 +928,25 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(pipe_threads(NA), (NA + kPipeBWaves) / 4) 
     for (int t = 1; t < T; ++t) {
 #pragma unroll
       for (int c = 0; c < NKC; ++c) {
+        constexpr int dummy = 0; (void)dummy;
+        const int h = c / SP, cs = c % SP;                      // (compile-time after unrolling)
         // (the first item of this step's slice asks for its noise / skip values before the MFMAs)
-        if (c >= 1) {
+        if (cs >= 1) {
 #pragma unroll
           for (int k = 0; k < ITEMS; ++k)
-            if (slice_of(k) == c && (k == 0 || slice_of(k - 1) != c)) item_load(k, io[k & 1]);
+            if (slice_of(k) == cs - 1 && (k == 0 || slice_of(k - 1) != cs - 1)) item_load(k, h, io[k & 1]);
         }
         PPROF_MARK(7);
         mfma_chunk(c & 1, WRES ? c : (c & 1), c == 0);
         PPROF_MARK(4);
-        if (c == 0) {
-          acc_to_lds();                                         // (the previous result tile was consumed before the last barrier)
+        if (cs == 0) {
+          acc_to_lds(h);                                        // (the previous half's items finished before the last barrier)
         } else {
 #pragma unroll
           for (int k = 0; k < ITEMS; ++k)
-            if (slice_of(k) == c) {
-              if (k + 1 < ITEMS && slice_of(k + 1) == c) item_load(k + 1, io[(k + 1) & 1]);
-              item_finish(k, io[k & 1]);
+            if (slice_of(k) == cs - 1) {
+              if (k + 1 < ITEMS && slice_of(k + 1) == cs - 1) item_load(k + 1, h, io[(k + 1) & 1]);
+              item_finish(k, h, io[k & 1]);
             }
         }
         if (c == NKC - 1) hand_over();
@@ -883,13 +955,17 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(pipe_threads(NA), (NA + kPipeBWaves) / 4) 
         PPROF_MARK(6);
       }
     }
-    acc_to_lds();
-    MIGAN_BARRIER_LDS();                                        // (group A joins this one)
-    item_load(0, io[0]);
 #pragma unroll
-    for (int k = 0; k < ITEMS; ++k) {
-      if (k + 1 < ITEMS) item_load(k + 1, io[(k + 1) & 1]);
-      item_finish(k, io[k & 1]);
+    for (int h = 0; h < NH; ++h) {
+      if (h > 0) MIGAN_BARRIER_LDS();                           // every wave is done with the previous half (group A joins these barriers)
+      acc_to_lds(h);
+      MIGAN_BARRIER_LDS();
+      item_load(0, h, io[0]);
+#pragma unroll
+      for (int k = 0; k < ITEMS; ++k) {
+        if (k + 1 < ITEMS) item_load(k + 1, h, io[(k + 1) & 1]);
+        item_finish(k, h, io[k & 1]);
+      }
     }
   }
   PPROF_MARK(5);
@@ -906,8 +982,9 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(pipe_threads(NA), (NA + kPipeBWaves) / 4) 
 //   DMA     the 12 x 36-pixel input window of chunk s+R-1 (27 KB) -> LDS ring, and the chunk's weight planes
 //   A       stage 1: depthwise 3x3 + bias + act on the 10 x 34 grid the FIR window touches (zero outside the image: the FIR's padding)
 //           -> d_s; [barrier]; stage 2: 16-tap FIR, x 2^7, fp16 split -> A planes of chunk s+1        (two barriers per chunk)
-//   B       8 waves = 2 row blocks x 4 column groups: MFMAs of chunk s; the previous tile's epilogue (wave-private transpose, activation,
-//           stores) under the next tile's chunks, as in sepconv_pipe_kernel
+//   B       NB = 8 or 4 waves = 2 row blocks x 4 or 2 column groups: the MFMAs of chunk s in the first half of a step (beside stage 1), a slice
+//           of the previous tile's epilogue (wave-private transpose, activation, stores) in the second (beside stage 2)
+//   The kernel is bound by group A (stage 1 above all): NA = 12, NB = 4 is the default split (profiles/r04_pipe_layers.txt).
 //
 // The depthwise + FIR stage runs once per pixel only while one workgroup owns all of Cout (Cout <= 256); wider layers keep the two-kernel form.
 template <int NT, int CIN, int R>
@@ -918,34 +995,37 @@ struct DownLds {
   static constexpr int B_CHUNK = 2 * NT * 32;                       // hi + lo plane of one chunk, [NT rows][16 k] fp16
   static constexpr bool WRES = NKC * B_CHUNK <= 32 * 1024;
   static constexpr int NBUF_B = WRES ? NKC : 2;
-  static constexpr int D_SZ = 10 * 34 * KC * 4;                     // depthwise grid
-  template <int AT> static constexpr int in_slot() { return (IN_UNITS + AT - 1) / AT * AT * 16; }
-  template <int AT> static constexpr int off_d() { return R * in_slot<AT>(); }
-  template <int AT> static constexpr int off_a() { return off_d<AT>() + D_SZ; }
-  template <int AT> static constexpr int off_b() { return off_a<AT>() + 2 * A_BUF; }
-  template <int AT> static constexpr int off_w() { return off_b<AT>() + NBUF_B * B_CHUNK; }
-  template <int AT> static constexpr int off_t() { return off_w<AT>() + NKC * 640; }
-  template <int AT> static constexpr int total() { return off_t<AT>() + kPipeBWaves * 32 * 32 * 4; }
+  static constexpr int DWP = 17;                                    // depthwise grid [10 rows][column parity][17][16 channels] fp32: the stride-2 FIR reads
+  static constexpr int D_SZ = 10 * 2 * DWP * KC * 4;                // become contiguous; odd columns 64 bytes mod 128 after the even ones (stage-1 stores)
+  static constexpr int IN_SLOT = IN_UNITS * 16;                     // (1728 units = 27 waves' worth of DMA lanes exactly)
+  static constexpr int OFF_D = R * IN_SLOT;
+  static constexpr int OFF_A = OFF_D + D_SZ;
+  static constexpr int OFF_B = OFF_A + 2 * A_BUF;
+  static constexpr int OFF_W = OFF_B + NBUF_B * B_CHUNK;
+  static constexpr int OFF_T = OFF_W + NKC * 640;
+  template <int NB> static constexpr int total() { return OFF_T + NB * 32 * 32 * 4; }
 };
 
-template <int NT, int CIN, int R, int NA>
-MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(pipe_threads(NA), (NA + kPipeBWaves) / 4) sepconv_pipedown_kernel(const SepArgs p) {
+template <int NT, int CIN, int R, int NA, int NB>
+MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS((NA + NB) * 64, (NA + NB) / 4) sepconv_pipedown_kernel(const SepArgs p) {
   typedef DownLds<NT, CIN, R> L;
   constexpr int AT = NA * 64, KC = 16, QC = 4, LG_QC = 2, NKC = L::NKC, MT = 64, GH = 4, GW = 16, lgGW = 4;
-  constexpr int IGH = 12, IGW = 36, NPIXW = IGH * IGW, NITEMS = NPIXW * QC, DH = 10, DW = 34, DH2 = 5;
-  constexpr int DNI = (NITEMS + AT - 1) / AT;
+  constexpr int IGH = 12, IGW = 36, NPIXW = IGH * IGW, NITEMS = NPIXW * QC, DH = 10, DW = 34, DH2 = 5, DWP = L::DWP;
+  constexpr int DNI = (NITEMS + AT - 1) / AT;                       // (the waves past unit 1728 skip their last one: `dshort`)
   constexpr bool WRES = L::WRES;
   constexpr int DNB = (4 * NT + AT - 1) / AT;                       // weight-plane DMAs per group-A thread and chunk (4 NT units)
-  static_assert((4 * NT) % AT == 0, "weight planes must split evenly over group A");
-  constexpr int NTIW = NT / 128;                                    // 32-column blocks of a B wave (2 row blocks x 4 column groups)
+  static_assert(NB == 4 || NB == 8, "2 row blocks x 2 or 4 column groups");
+  constexpr int NTIW = NT * 2 / (32 * NB);                          // 32-column blocks of a B wave
+  // two blocks per wave at most ride under the next tile (block 0 in the transpose patch, block 1 in a second register set); with more,
+  // the whole epilogue runs at the tile's end -- group B has the slack (this kernel is bound by the depthwise + FIR stage of group A)
+  constexpr bool DEFER = NTIW <= 2;
+  static_assert(NTIW <= NKC, "one epilogue block per K step");
   static_assert(NT == 128 || NT == 256, "one workgroup owns 128 or 256 output channels");
   static_assert(R == 2, "two-slot ring");
-  static_assert(L::template total<AT>() <= 160 * 1024, "LDS budget");
+  static_assert(L::template total<NB>() <= 160 * 1024, "LDS budget");
   MIGAN_DYN_SMEM(smem);
   char* const lds = reinterpret_cast<char*>(smem);
-  constexpr int IN_SLOT = L::template in_slot<AT>();
-  constexpr int OFF_D = L::template off_d<AT>(), OFF_A = L::template off_a<AT>(), OFF_B = L::template off_b<AT>(), OFF_W = L::template off_w<AT>(),
-                OFF_T = L::template off_t<AT>();
+  constexpr int IN_SLOT = L::IN_SLOT, OFF_D = L::OFF_D, OFF_A = L::OFF_A, OFF_B = L::OFF_B, OFF_W = L::OFF_W, OFF_T = L::OFF_T;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -991,6 +1071,7 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(pipe_threads(NA), (NA + kPipeBWaves) / 4) 
   };
 
   if (groupA) {
+    MIGAN_SETPRIO(2);                                    // (the critical group of this kernel)
     const int lt = tid;
     float* const w_s = reinterpret_cast<float*>(lds + OFF_W);
     float* const d_s = reinterpret_cast<float*>(lds + OFF_D);
@@ -1007,6 +1088,7 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(pipe_threads(NA), (NA + kPipeBWaves) / 4) 
 
     // weight planes (chunk-major [plane][CIN/32][CO][32] fp16): the 16-channel half (c & 1) of 32-channel block c >> 1 -> [plane][NT][16]
     const MIGAN_BUF wbuf = MIGAN_MAKE_BUF(p.wsplit, (unsigned)(2 * p.CO * CIN) * 2u);
+    const bool bshort = MIGAN_UNIFORM((DNB - 1) * AT + wave_u * 64) >= 4 * NT;     // this wave's last unit lies past the planes (12 waves)
     unsigned dboff[DNB];
 #pragma unroll
     for (int j = 0; j < DNB; ++j) {
@@ -1018,9 +1100,11 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(pipe_threads(NA), (NA + kPipeBWaves) / 4) 
       float* bb = reinterpret_cast<float*>(lds + OFF_B + buf * L::B_CHUNK);
       const unsigned soff = (unsigned)((chunk >> 1) * 32 * p.CO + n0_ * 32 + (chunk & 1) * 16) * 2u;
 #pragma unroll
-      for (int j = 0; j < DNB; ++j) MIGAN_LDS_DMA16(wbuf, dboff[j], soff, bb + (j * AT + wave_u * 64) * 4);
+      for (int j = 0; j < DNB; ++j)
+        if (j + 1 < DNB || !bshort) MIGAN_LDS_DMA16(wbuf, dboff[j], soff, bb + (j * AT + wave_u * 64) * 4);
     };
     // input window: interior windows use offsets relative to their first pixel (computed once) + a scalar origin
+    const bool dshort = MIGAN_UNIFORM((DNI - 1) * AT + wave_u * 64) >= NITEMS;     // this wave's last window unit lies past the slot
     unsigned dgoff[DNI], drel[DNI], tile_soff = 0;
 #pragma unroll
     for (int j = 0; j < DNI; ++j) {
@@ -1057,7 +1141,8 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(pipe_threads(NA), (NA + kPipeBWaves) / 4) 
       float* in_s = reinterpret_cast<float*>(lds + slot * IN_SLOT);
       const MIGAN_BUF xbuf = MIGAN_MAKE_BUF(reinterpret_cast<const char*>(p.x) + (size_t)b0_ * img_bytes, img_bytes);
 #pragma unroll
-      for (int j = 0; j < DNI; ++j) MIGAN_LDS_DMA16(xbuf, dgoff[j], tile_soff + (unsigned)(chunk * KC) * 4u, in_s + (j * AT + wave_u * 64) * 4);
+      for (int j = 0; j < DNI; ++j)
+        if (j + 1 < DNI || !dshort) MIGAN_LDS_DMA16(xbuf, dgoff[j], tile_soff + (unsigned)(chunk * KC) * 4u, in_s + (j * AT + wave_u * 64) * 4);
     };
     // stage 1: depthwise 3x3 + bias + act on the 10 x 34 grid (rows 2 gy0 - 1 .., columns 2 gx0 - 1 ..) -> d_s; one item = 2 vertically
     // adjacent grid pixels x 4 channels; positions outside the image are the FIR's zero padding (reference :67)
@@ -1082,7 +1167,7 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(pipe_threads(NA), (NA + kPipeBWaves) / 4) 
         }
         const int xim = xim0 + dx;
         const bool colin = xim >= 0 && xim < p.W;
-        float* dp = d_s + (dy0 * DW + dx) * KC + c4 * 4;
+        float* dp = d_s + ((dy0 * 2 + (dx & 1)) * DWP + (dx >> 1)) * KC + c4 * 4;
 #pragma unroll
         for (int o = 0; o < 2; ++o) {
           f4 sacc = bias;
@@ -1093,17 +1178,18 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(pipe_threads(NA), (NA + kPipeBWaves) / 4) 
           const int yim = yim0 + dy0 + o;
           f4 d = {0.f, 0.f, 0.f, 0.f};
           if (colin && yim >= 0 && yim < p.H) d = act4(sacc);
-          st4(dp + o * DW * KC, d);
+          st4(dp + o * (2 * DWP * KC), d);
         }
       }
     };
-    // stage 2: 4x4 FIR, stride 2, taps outer([1,3,3,1])/64 (reference Downsample2d :58-76), x 2^7, fp16 hi/lo -> A planes
+    // stage 2: 4x4 FIR, stride 2, taps outer([1,3,3,1])/64 (reference Downsample2d :58-76), x 2^7, fp16 hi/lo -> A planes.  (Splitting an
+    // item's 16 taps over two lanes -- 512 items, eight waves' worth -- measured 4 % slower: profiles/r04_pipe_layers.txt)
     auto stage2 = [&](int abuf) {
       char* a_b = lds + OFF_A + abuf * L::A_BUF;
       for (int it = lt; it < MT * QC; it += AT) {
         const int c4 = it & (QC - 1), m = it >> LG_QC;
         const int ox = m & (GW - 1), oy = m >> lgGW;
-        const float* dp = d_s + ((2 * oy) * DW + 2 * ox) * KC + c4 * 4;
+        const float* dp = d_s + ((2 * oy) * 2 * DWP + ox) * KC + c4 * 4;
         f4 a = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int ky = 0; ky < 4; ++ky) {
@@ -1111,7 +1197,7 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(pipe_threads(NA), (NA + kPipeBWaves) / 4) 
 #pragma unroll
           for (int kx = 0; kx < 4; ++kx) {
             const float fx = (kx == 0 || kx == 3) ? 1.0f : 3.0f;
-            a += (fy * fx * (1.0f / 64.0f)) * ld4(dp + (ky * DW + kx) * KC);
+            a += (fy * fx * (1.0f / 64.0f)) * ld4(dp + ((ky * 2 + (kx & 1)) * DWP + (kx >> 1)) * KC);
           }
         }
         u2v h1, h2;
@@ -1169,7 +1255,7 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(pipe_threads(NA), (NA + kPipeBWaves) / 4) 
     }
     issue();                                              // step 0
     issue();                                              // step 1
-    MIGAN_WAIT_VMCNT(DNI);                                // everything but the window of step 1 landed (G >= NKC >= 4 steps)
+    if (dshort) MIGAN_WAIT_VMCNT(DNI - 1); else MIGAN_WAIT_VMCNT(DNI);       // everything but the window of step 1 landed (G >= NKC >= 4 steps)
     MIGAN_BARRIER_LDS();                                  // P1
     stage1(0, 0, dgy0, dgx0);
     MIGAN_BARRIER_LDS();                                  // P2
@@ -1192,7 +1278,7 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(pipe_threads(NA), (NA + kPipeBWaves) / 4) 
       // issued now into the slot the MFMAs of step g have just finished with, stay in flight
       bool newer = false;
       if constexpr (!WRES) newer = issue_b();
-      if (newer) MIGAN_WAIT_VMCNT(DNB); else MIGAN_WAIT_VMCNT(0);
+      if (newer && !bshort) MIGAN_WAIT_VMCNT(DNB); else if (newer && DNB > 1) MIGAN_WAIT_VMCNT(DNB > 1 ? DNB - 1 : 0); else MIGAN_WAIT_VMCNT(0);
       PPROF_MARK(2);
       MIGAN_BARRIER_LDS();
       PPROF_MARK(3);
@@ -1203,26 +1289,32 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(pipe_threads(NA), (NA + kPipeBWaves) / 4) 
 
   // ================================================= group B ============================================================================
   const int wb = wave_u - NA;
-  const int rb = wb & 1, cb = wb >> 1;                           // row block (32 GEMM rows), column group (NT / 4 columns)
+  const int rb = wb & 1, cb = wb >> 1;                           // row block (32 GEMM rows), column group (NT / (NB / 2) columns)
   const int l31 = lane & 31, half = lane >> 5;
-  f16v acc[NTIW], accp[NTIW];
+  f16v acc[NTIW], accp[DEFER ? NTIW : 1];
 #pragma unroll
   for (int j = 0; j < NTIW; ++j)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { acc[j][r] = 0.0f; accp[j][r] = 0.0f; }
+    for (int r = 0; r < 16; ++r) { acc[j][r] = 0.0f; if (DEFER) accp[j][r] = 0.0f; }
   auto mfma_chunk = [&](int abuf, int bbuf, bool first) {
     const char* ab = lds + OFF_A + abuf * L::A_BUF + (rb * 32 + l31) * 32 + half * 16;
     const char* bb = lds + OFF_B + bbuf * L::B_CHUNK + half * 16;
     const f4 a_hi = ld4(reinterpret_cast<const float*>(ab)), a_lo = ld4(reinterpret_cast<const float*>(ab + MT * 32));
+    f4 b_hi[NTIW], b_lo[NTIW];
 #pragma unroll
     for (int j = 0; j < NTIW; ++j) {
       const char* q = bb + ((cb * NTIW + j) * 32 + l31) * 32;
-      const f4 b_hi = ld4(reinterpret_cast<const float*>(q)), b_lo = ld4(reinterpret_cast<const float*>(q + NT * 32));
+      b_hi[j] = ld4(reinterpret_cast<const float*>(q));
+      b_lo[j] = ld4(reinterpret_cast<const float*>(q + NT * 32));
       if (first) acc[j] = f16v{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-      acc[j] = MIGAN_MFMA_F16_32X32X16(a_lo, b_hi, acc[j]);
-      acc[j] = MIGAN_MFMA_F16_32X32X16(a_hi, b_lo, acc[j]);
-      acc[j] = MIGAN_MFMA_F16_32X32X16(a_hi, b_hi, acc[j]);
     }
+    // product by product across the wave's column blocks: consecutive MFMAs go to different accumulators
+#pragma unroll
+    for (int j = 0; j < NTIW; ++j) acc[j] = MIGAN_MFMA_F16_32X32X16(a_lo, b_hi[j], acc[j]);
+#pragma unroll
+    for (int j = 0; j < NTIW; ++j) acc[j] = MIGAN_MFMA_F16_32X32X16(a_hi, b_lo[j], acc[j]);
+#pragma unroll
+    for (int j = 0; j < NTIW; ++j) acc[j] = MIGAN_MFMA_F16_32X32X16(a_hi, b_hi[j], acc[j]);
   };
   const float acc_scale = reinterpret_cast<const float*>(p.wsplit)[-4];
   const float gain_s = 1.41421356237309515f * acc_scale;         // (no noise on these layers: the scale folds into the activation gain, exactly)
@@ -1264,38 +1356,67 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(pipe_threads(NA), (NA + kPipeBWaves) / 4) 
     }
   };
   auto hand_over = [&]() {
-    stage_block(acc[0]);
-#pragma unroll
-    for (int j = 1; j < NTIW; ++j) accp[j] = acc[j];
     pn0 = cn0; pb0 = cb0; pgy0 = cgy0; pgx0 = cgx0;
+    if constexpr (DEFER) {
+      stage_block(acc[0]);
+#pragma unroll
+      for (int j = 1; j < NTIW; ++j) accp[j] = acc[j];
+    } else {
+#pragma unroll
+      for (int j = 0; j < NTIW; ++j) {
+        stage_block(acc[j]);
+        fetch_block();
+        finish_block(j);
+      }
+    }
     if (++ck < T) { tile_next(ctc); ccoords(); }
   };
   MIGAN_BARRIER_LDS();                                          // P1
   MIGAN_BARRIER_LDS();                                          // P2
   MIGAN_BARRIER_LDS();                                          // barrier 0
+  if constexpr (!DEFER) {
+    for (int t = 0; t < T; ++t) {
+#pragma unroll
+      for (int c = 0; c < NKC; ++c) {
+        PPROF_MARK(7);
+        mfma_chunk(c & 1, WRES ? c : (c & 1), c == 0);
+        PPROF_MARK(4);
+        MIGAN_BARRIER_LDS();
+        PPROF_MARK(6);
+        if (c == NKC - 1) hand_over();                          // (second half of the step: group A runs the FIR stage)
+        PPROF_MARK(9);
+        MIGAN_BARRIER_LDS();
+        PPROF_MARK(6);
+      }
+    }
+    PPROF_END(AT);
+    return;
+  } else {
   // first tile: nothing to finish under it
 #pragma unroll
   for (int c = 0; c < NKC; ++c) {
     mfma_chunk(c & 1, WRES ? c : (c & 1), c == 0);
-    if (c == NKC - 1) hand_over();
     MIGAN_BARRIER_LDS();
+    if (c == NKC - 1) hand_over();
     MIGAN_BARRIER_LDS();
   }
   for (int t = 1; t < T; ++t) {
 #pragma unroll
     for (int c = 0; c < NKC; ++c) {
       PPROF_MARK(7);
-      if (c < NTIW) fetch_block();
       mfma_chunk(c & 1, WRES ? c : (c & 1), c == 0);
       PPROF_MARK(4);
+      MIGAN_BARRIER_LDS();
+      PPROF_MARK(6);
+      // second half of the step (group A runs the FIR stage): a slice of the previous tile's epilogue
       if (c < NTIW) {
+        fetch_block();
         finish_block(c);
         if (c + 1 < NTIW) stage_block(accp[c + 1 < NTIW ? c + 1 : 0]);
       }
       PPROF_MARK(9);
       if (c == NKC - 1) hand_over();
       PPROF_MARK(7);
-      MIGAN_BARRIER_LDS();
       MIGAN_BARRIER_LDS();
       PPROF_MARK(6);
     }
@@ -1308,6 +1429,7 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(pipe_threads(NA), (NA + kPipeBWaves) / 4) 
   }
   PPROF_MARK(9);
   PPROF_END(AT);
+  }
 }
 
 }  // namespace migan

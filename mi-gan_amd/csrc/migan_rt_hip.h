@@ -106,6 +106,12 @@ __device__ __forceinline__ MIGAN_BUF migan_make_buf(const void* p, unsigned byte
 // the lanes of one wave exchange data through LDS: in-order LDS + lockstep execution need no instruction, only a fence the scheduler
 // will not move LDS accesses across (the CPU emulator, whose lanes are independent fibers, synchronises the wave here)
 #define MIGAN_WAVE_SYNC() __builtin_amdgcn_wave_barrier()
+// s_setprio: issue priority of this wave among the waves of its SIMD (0 = default .. 3)
+#ifdef MIGAN_NO_PRIO
+#define MIGAN_SETPRIO(n) do {} while (0)
+#else
+#define MIGAN_SETPRIO(n) __builtin_amdgcn_s_setprio(n)
+#endif
 
 namespace rt {
 typedef hipStream_t stream_t;

@@ -101,7 +101,7 @@ struct PipeSlice {
 };
 // sepconv_pipedown_kernel instantiations: the fused down=2 layer, one workgroup owns all NT = Cout output channels
 struct DownEntry {
-  int NT, cin, ring, na;
+  int NT, cin, ring, na, nb;
   SepKernelFn fn;
   const char* name;
   size_t lds_bytes;

@@ -42,7 +42,7 @@ for i, (L, t) in enumerate(zip(launches, ms)):
     if "pipe" in L["kernel"]:
         cyc = [out[k] / n / 1000.0 for k in range(16)]
         print(f"{L['layer']:26s} {t:8.3f} {out[8]:7d}  pipe kcycles/WG A[issue {cyc[0]:.0f} depthwise {cyc[1]:.0f} vmcnt {cyc[2]:.0f} barrier {cyc[3]:.0f}]"
-              f" B[mfma {cyc[4]:.0f} noise-wait {cyc[5]:.0f} block-epi {cyc[9]:.0f} rgb-part {cyc[10]:.0f} rgb-fin {cyc[11]:.0f} request {cyc[12]:.0f} build {cyc[13]:.0f} rest {cyc[7]:.0f} barrier {cyc[6]:.0f}]")
+              f" B[mfma {cyc[4]:.0f} noise-wait {cyc[5]:.0f} block-epi {cyc[9]:.0f} rgb-part {cyc[10]:.0f} rgb-fin {cyc[11]:.0f} request {cyc[12]:.0f} build {cyc[13]:.0f} rest {cyc[7]:.0f} barrier {cyc[6]:.0f}] A-stage2 {cyc[14]:.0f}")
         continue
     if "wide" in L["kernel"]:
         cyc = [out[k] / n for k in range(8)]

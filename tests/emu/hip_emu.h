@@ -318,6 +318,7 @@ inline void hipemu_wait_vmcnt(int n) {
 #define MIGAN_WAIT_VMCNT(n) hipemu_wait_vmcnt(n)
 #define MIGAN_BARRIER_LDS() hipemu::block_barrier()
 #define MIGAN_WAVE_SYNC() hipemu::wave_barrier()
+#define MIGAN_SETPRIO(n) do {} while (0)
 
 // ---- the runtime surface the host code uses ----------------------------------------------------------
 namespace rt {

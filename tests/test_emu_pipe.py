@@ -28,12 +28,13 @@ def small_grids(request, lib):
     lib.set_tuning("pipe_grid", 8)
     lib.set_tuning("pipe_na", request.param)
     lib.set_tuning("pipe_na8", 0)      # (this wave count for every form)
-    yield
+    yield request.param
+    lib.set_tuning("pipe_dna", 12)
     lib.set_tuning("pipe_min_tiles", 256)
     lib.set_tuning("pipe_grid", 256)
     lib.set_tuning("pipe", 15)
     lib.set_tuning("pipe_na", 4)
-    lib.set_tuning("pipe_na8", 11)
+    lib.set_tuning("pipe_na8", 9)
 
 
 PIPE = "migan::sepconv_pipe_kernel<"
@@ -72,20 +73,42 @@ def test_pipe_off_takes_the_one_tile_kernels(lib, pkg):
     assert lib.last_kernel().startswith("migan::sepconv_kernel<"), lib.last_kernel()
 
 
-def test_single_image_keeps_the_latency_tiles(lib, pkg):
+def test_single_image_forwards_take_them_too_unless_told_otherwise(lib, pkg):
     run_sepconv_case(lib, pkg, HostMem(), cin=64, cout=64, h=16, w=32, batch=1, noise=True, seed=3)
-    assert lib.last_kernel().startswith("migan::sepconv_kernel<"), lib.last_kernel()
+    assert lib.last_kernel().startswith(PIPE), lib.last_kernel()
+    lib.set_tuning("pipe_min_batch", 2)
+    try:
+        run_sepconv_case(lib, pkg, HostMem(), cin=64, cout=64, h=16, w=32, batch=1, noise=True, seed=3)
+        assert lib.last_kernel().startswith("migan::sepconv_kernel<"), lib.last_kernel()
+    finally:
+        lib.set_tuning("pipe_min_batch", 1)
+
+
+@pytest.mark.parametrize("cin,cout", [(256, 256), (512, 512)])
+def test_wide_layers_as_128_column_chunks(lib, pkg, cin, cout):
+    """tuning bit 32 (off by default: measured no faster than sepconv_wide_kernel): the streamed weight planes and, at 512 input channels,
+    the streamed depthwise taps of the plain form"""
+    lib.set_tuning("pipe", 63)
+    run_sepconv_case(lib, pkg, HostMem(), cin=cin, cout=cout, h=16, w=16, batch=2, noise=True, seed=5)
+    assert lib.last_kernel().startswith(PIPE + f"0, 128, {cin}, false, false"), lib.last_kernel()
 
 DOWN = "migan::sepconv_pipedown_kernel<"
 
 
 @pytest.mark.parametrize("h,w,batch", [(16, 32, 2), (8, 32, 3), (24, 64, 2), (32, 32, 5)])
 @pytest.mark.parametrize("cin,cout", [(64, 128), (128, 256)])
-def test_fused_down(lib, pkg, h, w, batch, cin, cout):
-    """down=2 as one launch: depthwise + FIR-down feed the 1x1 through LDS (4 x 16 low-resolution tiles, image borders = the FIR's zero padding)"""
+@pytest.mark.parametrize("dna,nb", [(4, 8), (8, 8), (12, 4)])
+def test_fused_down(lib, pkg, small_grids, h, w, batch, cin, cout, dna, nb):
+    """down=2 as one launch: depthwise + FIR-down feed the 1x1 through LDS (4 x 16 low-resolution tiles, image borders = the FIR's zero padding);
+    4, 8 or 12 depthwise + FIR waves beside 8, 8 or 4 GEMM / epilogue waves (with 4 and 256 columns: the epilogue at the tile's end)"""
+    if small_grids != 4:
+        pytest.skip("this kernel's wave split is its own parameter")
     lib.set_tuning("pipe", 15)
+    lib.set_tuning("pipe_dna", dna)
     run_sepconv_case(lib, pkg, HostMem(), cin=cin, cout=cout, h=h, w=w, batch=batch, down=2, seed=11)
-    assert lib.last_kernel().startswith(DOWN + f"{cout}, {cin}, "), lib.last_kernel()
+    if (cin, dna) == (128, 8):
+        dna = 4                                         # (no 8 + 8 instantiation for 128 -> 256: two registers short)
+    assert lib.last_kernel() == DOWN + f"{cout}, {cin}, 2, {dna}, {nb}>", lib.last_kernel()
 
 
 def test_fused_down_off_takes_the_two_kernel_form(lib, pkg):

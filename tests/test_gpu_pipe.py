@@ -34,7 +34,7 @@ def knobs(request, lib):
     lib.set_tuning("pipe_grid", 256)
     lib.set_tuning("pipe", 15)
     lib.set_tuning("pipe_na", 4)
-    lib.set_tuning("pipe_na8", 11)
+    lib.set_tuning("pipe_na8", 9)
 
 
 # (h, w, batch, persistent workgroups): 0 = the default grid (one per CU)
@@ -112,12 +112,19 @@ DOWN = "migan::sepconv_pipedown_kernel<"
 
 @pytest.mark.parametrize("h,w,batch,grid", [(128, 128, 8, 0), (16, 32, 3, 8), (256, 256, 2, 0), (64, 96, 3, 64)])
 @pytest.mark.parametrize("cin,cout", [(64, 128), (128, 256)])
-def test_fused_down(lib, pkg, dev, h, w, batch, grid, cin, cout):
-    """down=2 as one launch: depthwise + FIR-down feed the 1x1 through LDS"""
+@pytest.mark.parametrize("dna,nb", [(4, 8), (8, 8), (12, 4)])
+def test_fused_down(lib, pkg, dev, h, w, batch, grid, cin, cout, dna, nb):
+    """down=2 as one launch: depthwise + FIR-down feed the 1x1 through LDS; 4 / 8 / 12 depthwise + FIR waves beside 8 / 8 / 4 GEMM waves"""
     _grid(lib, grid)
     lib.set_tuning("pipe", 15)
-    run_sepconv_case(lib, pkg, CudaMem(dev), cin=cin, cout=cout, h=h, w=w, batch=batch, down=2, seed=11)
-    assert lib.last_kernel().startswith(DOWN + f"{cout}, {cin}, "), lib.last_kernel()
+    lib.set_tuning("pipe_dna", dna)
+    try:
+        run_sepconv_case(lib, pkg, CudaMem(dev), cin=cin, cout=cout, h=h, w=w, batch=batch, down=2, seed=11)
+        if (cin, dna) == (128, 8):
+            dna = 4                                         # (no 8 + 8 instantiation for 128 -> 256: two registers short)
+        assert lib.last_kernel() == DOWN + f"{cout}, {cin}, 2, {dna}, {nb}>", lib.last_kernel()
+    finally:
+        lib.set_tuning("pipe_dna", 12)
 
 @pytest.mark.parametrize("cin,cout,h,w,batch,grid", [(256, 128, 64, 64, 4, 0), (256, 128, 12, 20, 3, 8), (512, 256, 32, 32, 4, 0), (512, 512, 16, 16, 8, 0)])
 def test_fir_up_streamed_weight_planes(lib, pkg, dev, cin, cout, h, w, batch, grid):

@@ -107,3 +107,19 @@ def test_occupancy_budgets_of_the_default_plan_kernels(tmp_path):
     spilled = sorted(k for k, v in sep.items() if v["private_segment_fixed_size"] and k[7] == 1 and k[9] in (2, 3) and k[3] == 32
                      and not (k[0] == 2 and k[6] == 3))
     assert spilled == [], spilled
+
+
+@pytest.mark.skipif(not os.path.exists(f"{LLVM}/llvm-readelf"), reason="needs the ROCm LLVM tools")
+def test_pipelined_kernels_fit_their_workgroup(tmp_path):
+    """sepconv_pipe_kernel / sepconv_pipedown_kernel run ONE workgroup of 12 or 16 waves per CU: 3 or 4 waves per SIMD, i.e. at most 168
+    or 128 registers per lane.  No instantiation may spill (a spilling form was measured 1.7x slower: profiles/r04_pipe_layers.txt)."""
+    pkg = importlib.import_module("mi-gan_amd")
+    res = kernel_resources(pkg.library_path(), str(tmp_path))
+    pipe = {_targs(k): v for k, v in res.items() if "sepconv_pipe_kernel" in k}          # (MODE, NT, CIN, FROMRGB, TORGB, R, NA)
+    down = {_targs(k): v for k, v in res.items() if "sepconv_pipedown_kernel" in k}      # (NT, CIN, R, NA, NB)
+    assert len(pipe) >= 9 and len(down) >= 5
+    for table in (pipe, down):
+        for targs, v in table.items():
+            waves = targs[-1] + 8 if table is pipe else targs[-2] + targs[-1]
+            cap = 168 if waves == 12 else 128
+            assert v["vgpr_count"] + v["agpr_count"] <= cap and v["private_segment_fixed_size"] == 0 and v["vgpr_spill_count"] == 0, (targs, v)
