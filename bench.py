@@ -125,7 +125,8 @@ def roofline_from_launches(launches, ms_rounds, batch, gemm="f32"):
         g["flops"] += L["flops"] * batch
         g["mfma"] += L["mfma_flops"] * batch
         g["bytes"] += L["bytes"] * batch
-        g["n"] += 1
+        # the first half of a fused down=2 layer is a plan entry that launches nothing: its bytes and flops belong to the fused kernel's launch
+        g["n"] += 0 if (L["layer"].endswith(".dwfir") and "pipedown" in L["kernel"]) else 1
         g["layers"].append(L["layer"])
     peak_mfma = PEAK_BF16_MFMA_TFLOPS / MFMA_PRODUCTS[gemm] if MFMA_PRODUCTS.get(gemm) else PEAK_F32_MFMA_TFLOPS
     name, g = max(groups.items(), key=lambda kv: kv[1]["ms"])
