@@ -81,6 +81,7 @@ struct Tuning {
                                // (waves 0-3 depthwise + half the MFMAs), 2 = waves 4-7 run all the MFMAs (-3..6 % per layer), 3 (default) = 2 +
                                // LDS-DMA staging of the input tile and the weight planes where the storage is fp32 (another -5..10 %):
                                // profiles/r03_wide_kernel.md
+  int wide_up = 1;             // FIR-up layers with Cout % 256 == 0 on the 256-column tile as well (sepconv_wide_kernel<..., UP>; needs wide == 3)
   int nt256 = 1;               // MIGAN_NT256=0|1: 64-pixel x 256-channel tiles for the 256-channel layer that feeds ToRGB (fuses it)
   int ablate = 0;              // MIGAN_ABLATE (measurement builds compiled with -DMIGAN_ABLATE only)
   int persist_min = 8192;      // MIGAN_PERSIST_MIN: launches with at least this many tiles run persistent workgroups
@@ -202,6 +203,10 @@ inline Geo choose_geo(int mode, int cin, int cout, int h_in, int w_in, bool from
     if (small >= 2) { g.MT = 32; g.NT = 128; GH = 4; GW = 8; IMGS = 1; }   // 4x8 grid of GEMM pixels, 2x6 interior
     else if (small) { g.MT = 64; g.NT = 128; GH = 8; GW = 8; IMGS = 1; }   // 8x8 grid, 6x6 interior
     else if (sq2 && h_in < 8) { GH = 8; GW = 8; IMGS = 2; }
+    else if (cout % 256 == 0 && g.gemmv == 2 && stv == 0 && tuning().wide == 3 && tuning().wide_up) {
+      // FIR-up with 256-column tiles (sepconv_wide_kernel<..., UP>): the depthwise stage and the input tile once per 256 output channels
+      g.wide = true; g.NT = 256; GH = 8; GW = 16; IMGS = 1;
+    }
     else { GH = 8; GW = 16; IMGS = 1; }
     g.sy = GH - 2; g.sx = GW - 2; g.off = 1;     // 1-pixel halo of GEMM outputs is recomputed per tile
     g.tiles_y = cdiv(h_in, g.sy); g.tiles_x = cdiv(w_in, g.sx);
@@ -317,7 +322,10 @@ inline SepKernelFn wide_fn(bool torgb, int stv, bool x1 = false, bool ball = fal
   if (dma) return torgb ? sepconv_wide_kernel<true, 0, false, true, true> : sepconv_wide_kernel<false, 0, false, true, true>;
   return f[ball ? 1 : 0][x1 ? 1 : 0][torgb ? 1 : 0][stv];
 }
+inline SepKernelFn wide_up_fn() { return sepconv_wide_kernel<false, 0, false, true, true, true>; }
+constexpr const char* kWideUpName = "migan::sepconv_wide_kernel<false, 0, false, true, true, true>";
 inline const char* wide_name(const Geo& g) {
+  if (g.mode == MODE_UP) return kWideUpName;
   static const char* n[2][2][2][3] = {
       {{MIGAN_WIDE_NAMES(false, false, false), MIGAN_WIDE_NAMES(true, false, false)}, {MIGAN_WIDE_NAMES(false, true, false), MIGAN_WIDE_NAMES(true, true, false)}},
       {{MIGAN_WIDE_NAMES(false, false, true), MIGAN_WIDE_NAMES(true, false, true)}, {MIGAN_WIDE_NAMES(false, true, true), MIGAN_WIDE_NAMES(true, true, true)}}};
@@ -340,7 +348,8 @@ inline const PipeEntry* pick_pipe(const Geo& g, int cin, int cout, int batch, bo
   // (pipe bit 32, experiment, off: the 256 / 512-channel plain layers -- sepconv_wide_kernel's -- as 128-column chunks of the pipelined kernel:
   // encoder.b128.conv1 0.379 -> 0.373 ms, the 512-channel layers 0.30 -> 0.37 (depthwise recomputed per chunk): profiles/LOG.md)
   const bool wide_as_chunks = g.wide && (tuning().pipe & 32) && !fused_rgb && g.mode == MODE_NORMAL;
-  if (!(tuning().pipe & bit) || g.stv != 0 || g.gemmv != 2 || !g.maing || (g.wide && !wide_as_chunks) || g.MT != 128 || g.KC != 32 || g.lgIMGS != 0) return nullptr;
+  const bool up_chunks = g.wide && g.mode == MODE_UP && (tuning().pipe & 16);     // (the chunked FIR-up experiment takes the wide-tile FIR-up layers too)
+  if (!(tuning().pipe & bit) || g.stv != 0 || g.gemmv != 2 || !g.maing || (g.wide && !wide_as_chunks && !up_chunks) || g.MT != 128 || g.KC != 32 || g.lgIMGS != 0) return nullptr;
   if (g.mode != MODE_NORMAL && g.mode != MODE_UP) return nullptr;
   if (batch < tuning().pipe_min_batch || g.tiles_x * g.tiles_y * g.nchunks * batch < tuning().pipe_min_tiles) return nullptr;
   (void)u8;
@@ -477,6 +486,7 @@ inline void prepare_kernels() {
         if (sv) rt_check(rt::allow_dynamic_lds((const void*)wide_fn(t != 0, sv, true, ball != 0), 160 * 1024), "hipFuncSetAttribute");
       }
       if (sv == 0) rt_check(rt::allow_dynamic_lds((const void*)wide_fn(t != 0, 0, false, true, true), 160 * 1024), "hipFuncSetAttribute");
+      if (sv == 0 && t == 0) rt_check(rt::allow_dynamic_lds((const void*)wide_up_fn(), 160 * 1024), "hipFuncSetAttribute");
       rt_check(rt::allow_dynamic_lds((const void*)dwfir_fn(t != 0, sv), 96 * 1024), "hipFuncSetAttribute");
       if (sv) rt_check(rt::allow_dynamic_lds((const void*)dwfir_fn(t != 0, sv + 2), 96 * 1024), "hipFuncSetAttribute");
     }
@@ -571,8 +581,8 @@ inline void launch_sepconv(Geo g, const SepArgs& a, rt::stream_t stream) {
               "ToRGB can only be fused into a plain layer whose output channels fit one column tile");
   if (g.wide) {
     MIGAN_CHECK(a.wsplit != nullptr, MIGAN_EINVAL, "internal: the wide kernel needs the fp16 weight planes");
-    rt_check(rt::launch(wide_fn(fused_rgb, g.stv, g.gemmv == 3, wide_ball(), wide_dma(g.stv, g.gemmv == 3)), a, tiles_of(g, a.B), kWideThreads, g.lds_bytes,
-                        stream), wide_name(g));
+    const SepKernelFn fn = g.mode == MODE_UP ? wide_up_fn() : wide_fn(fused_rgb, g.stv, g.gemmv == 3, wide_ball(), wide_dma(g.stv, g.gemmv == 3));
+    rt_check(rt::launch(fn, a, tiles_of(g, a.B), kWideThreads, g.lds_bytes, stream), wide_name(g));
     last_kernel_ref() = wide_name(g);
     return;
   }
@@ -1739,6 +1749,7 @@ int migan_set_tuning(const char* key, int value) {
   else if (k == "kc16_minw") t.kc16_minw = std::min(4, std::max(2, value));
   else if (k == "w3") t.w3 = value;
   else if (k == "wide") t.wide = value;
+  else if (k == "wide_up") t.wide_up = value;
   else if (k == "small") t.small = value;
   else if (k == "small_max_wgs") t.small_max_wgs = value;
   else if (k == "small_kc") t.small_kc = value;

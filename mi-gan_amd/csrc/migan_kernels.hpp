@@ -1172,9 +1172,14 @@ constexpr int kWideThreads = 512;
 // image is a buffer descriptor, so pixels outside it (conv zero padding) are lane offsets beyond its range and arrive as zeros;
 // the XOR swizzle of the weight planes is applied to the SOURCE address (the LDS destination of a DMA is linear in the lane).
 // Every wave waits for its own DMAs (explicit s_waitcnt vmcnt(0)) ahead of the barrier that publishes them.
-template <bool TORGB, int STV = 0, bool X1 = false, bool BALL = false, bool DMA = false>
+// UP (round 4, on the DMA form): FIR-up layers with Cout % 256 == 0 (synthesis conv1 at 128x128 and below in migan-512) -- the 8x16 grid of GEMM
+// pixels overlaps its neighbours by one pixel (tile pitch 6x14, as sepconv_kernel<MODE_UP>), the epilogue turns every interior pixel of
+// the result tile into its 2x2 output pixels (polyphase 1/4, 3/4 taps, reference Upsample2d :79-104) + noise + activation + skip.  One
+// workgroup per 256 columns instead of one per 128: the depthwise stage and the input tile are read half as often.
+template <bool TORGB, int STV = 0, bool X1 = false, bool BALL = false, bool DMA = false, bool UP = false>
 MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(kWideThreads, 2) sepconv_wide_kernel(const SepArgs p) {
   static_assert(!DMA || (STV == 0 && BALL), "the LDS-DMA staging is built for fp32 storage on the dedicated-MFMA-wave form");
+  static_assert(!UP || (DMA && !TORGB), "the FIR-up epilogue is built on the LDS-DMA form");
   typedef Io<STV> IoT;
   constexpr unsigned OE = IoT::ESZ;
   MIGAN_DYN_SMEM(smem);
@@ -1217,7 +1222,7 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(kWideThreads, 2) sepconv_wide_kernel(const
   const int nch = t % p.nchunks; t /= p.nchunks;
   const int tx = t % p.tiles_x;  t /= p.tiles_x;
   const int ty = t % p.tiles_y;
-  const int n0 = nch * NT, b0 = t / p.tiles_y, gy0 = ty * GH, gx0 = tx * GW;
+  const int n0 = nch * NT, b0 = t / p.tiles_y, gy0 = ty * p.sy - p.off, gx0 = tx * p.sx - p.off;     // (plain: pitch 8 x 16, off 0)
 
   // per-thread item descriptors (constant across K chunks)
   unsigned goff[NI], boff[NB], vmask = 0, emask = 0;
@@ -1469,7 +1474,13 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(kWideThreads, 2) sepconv_wide_kernel(const
         for (int r = 0; r < 16; ++r) {
           const int row = wme * WROWS + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * halfe;
           const int col = wne * WCOLS + j * 32 + l31e;
-          g_s[row * GS + col] = acc[i][j][r];
+          float v = acc[i][j][r];
+          if constexpr (UP) {
+            // halo pixels outside the low-resolution image contribute zeros to the upsampling FIR (reference pads with zeros :101)
+            const int ly = gy0 + (row >> lgGW), lx = gx0 + (row & (GW - 1));
+            if (ly < 0 || ly >= p.H || lx < 0 || lx >= p.W) v = 0.0f;
+          }
+          g_s[row * GS + col] = v;
         }
   };
 
@@ -1600,6 +1611,65 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(kWideThreads, 2) sepconv_wide_kernel(const
 #pragma unroll
       for (int ch = 0; ch < 3; ++ch) up_taps(p.img_prev + ((size_t)b0 * 3 + ch) * plane4, p.HO >> 1, p.WO >> 1, rgb_oy, rgb_ox, pv[ch]);
     }
+  }
+  if constexpr (UP) {
+    // each item owns one interior low-resolution pixel x 4 channels and produces its 2x2 output pixels from the 3x3 neighbourhood in g_s.
+    // Items of a thread: GEMM rows m0 + 8 k -> grid row k >> 1 (compile time: the halo rows drop out statically), column m0 + 8 (k & 1)
+    const int opix_t = 2 * gy0 * p.WO + 2 * (gx0 + gxt);                      // (signed: the first column may be a halo pixel left of the image)
+    const int ooff_t = opix_t * p.CO + n0 + c4 * 4;
+    auto up_items = [&](auto hn_, auto hs_) {
+      constexpr bool HN = decltype(hn_)::value, HS = decltype(hs_)::value;
+#pragma unroll
+      for (int kk = 0; kk < ITEMS; ++kk) {
+        const int dm = kk * STEP;
+        const int gy = dm >> lgGW, gx = gxt + (dm & (GW - 1));
+        if (gy < 1 || gy > GH - 2) continue;
+        const int ly = gy0 + gy, lx = gx0 + gx;
+        if (gx < 1 || gx > GW - 2 || ly >= p.H || lx >= p.W) continue;          // halo columns, ragged edge
+        const int m = m0 + dm;
+        const int upix = 2 * (dm >> lgGW) * p.WO + 2 * (dm & (GW - 1));         // uniform part (pixels)
+        typename IoT::raw4 sk[2][2];
+        float nz[2][2];
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+          for (int bb = 0; bb < 2; ++bb) {
+            const int dp = upix + a * p.WO + bb;
+            if constexpr (HN) nz[a][bb] = gnoise[(unsigned)(opix_t + dp)];
+            if constexpr (HS) sk[a][bb] = IoT::ld_once(sb, (unsigned)(ooff_t + dp * p.CO) * OE);
+          }
+        f4 e[3], o[3];
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+          const float* gp = g_s + (m + (dy - 1) * GW) * GS + c4 * 4;
+          const f4 l = ld4(gp - GS), ctr = ld4(gp), rgt = ld4(gp + GS);
+          e[dy] = 0.25f * l + 0.75f * ctr;
+          o[dy] = 0.75f * ctr + 0.25f * rgt;
+        }
+        f4 out[2][2];
+        out[0][0] = 0.25f * e[0] + 0.75f * e[1];
+        out[0][1] = 0.25f * o[0] + 0.75f * o[1];
+        out[1][0] = 0.75f * e[1] + 0.25f * e[2];
+        out[1][1] = 0.75f * o[1] + 0.25f * o[2];
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+          for (int bb = 0; bb < 2; ++bb) {
+            f4 v = out[a][bb];
+            if constexpr (HN) {
+              v = v * acc_scale + MIGAN_FMUL_RN(nz[a][bb], ns);
+              v = act4(v);
+            } else {
+              v = act4g(v, gain_s);
+            }
+            if constexpr (HS) v += IoT::cvt(sk[a][bb]);
+            IoT::st(yb, (unsigned)(ooff_t + (upix + a * p.WO + bb) * p.CO) * OE, v);
+          }
+      }
+    };
+    if (has_noise) { if (sb) up_items(TrueT{}, TrueT{}); else up_items(TrueT{}, FalseT{}); }
+    else { if (sb) up_items(FalseT{}, TrueT{}); else up_items(FalseT{}, FalseT{}); }
+    return;
   }
   const unsigned pix_t = (unsigned)((gy0 + gyt) * p.WO + gx0 + gxt);
   const unsigned off_t = (pix_t * (unsigned)p.CO + (unsigned)(n0 + c4 * 4)) * OE;      // lane byte offset

@@ -402,3 +402,25 @@ def test_sepconv_wide_tile_with_dedicated_mfma_waves(lib, pkg, storage, gemm, ca
         _sepconv(lib, pkg, storage=storage, gemm=gemm, **case)
     finally:
         lib.set_tuning("wide", 3)
+
+
+# ------------------------------------------------------------------------------------------------ FIR-up layers on the 256-column tile (round 4)
+WIDE_UP = "migan::sepconv_wide_kernel<false, 0, false, true, true, true>"
+
+
+@pytest.mark.parametrize("case", [
+    dict(cin=64, cout=256, h=16, batch=2, noise=True, skip=True),            # 3 x 2 tiles of 6 x 14 interior pixels, ragged on both edges
+    dict(cin=96, cout=512, h=12, w=20, batch=1, noise=True),                 # two column chunks, three K chunks, not a multiple of the tile
+    dict(cin=32, cout=256, h=8, w=16, batch=3, skip=True),                   # one K chunk, no noise
+    dict(cin=160, cout=256, h=6, w=14, batch=1, noise=True, skip=True),      # exactly one tile: every halo pixel lies outside the image
+])
+def test_fir_up_on_the_wide_tile(lib, pkg, case):
+    """up=2 SeparableConv2d with Cout % 256 == 0 (fp32 storage, f16x2 GEMM): sepconv_wide_kernel<..., UP>; off -> the 128-column kernel"""
+    _sepconv(lib, pkg, storage="f32", gemm=2, up=2, **case)
+    assert lib.last_kernel() == WIDE_UP, lib.last_kernel()
+    lib.set_tuning("wide_up", 0)
+    try:
+        _sepconv(lib, pkg, storage="f32", gemm=2, up=2, **case)
+        assert lib.last_kernel().startswith("migan::sepconv_kernel<2, "), lib.last_kernel()
+    finally:
+        lib.set_tuning("wide_up", 1)

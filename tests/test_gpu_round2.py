@@ -26,7 +26,7 @@ def tuned(pkg):
     lib = pkg.load_library()
     changed = {}
     defaults = dict(kc16=0, kc16_minw=3, w3=3, wide=3, nt256=1, persist_min=8192, persist_grid=512, streams=2, stagger=-1,
-                    small=1, small_max_wgs=512, small_kc=64, small_up32=1, small_dwfir=1, small_ksplit=1, pipe=15)
+                    small=1, small_max_wgs=512, small_kc=64, small_up32=1, small_dwfir=1, small_ksplit=1, pipe=15, wide_up=1)
 
     def set_(key, value):
         changed[key] = True
@@ -399,3 +399,24 @@ def test_training_snapshot_to_hip_forward(pkg, dev, golden_dir, tag):
     err = float(np.abs(y - g["y_train"]).max())
     assert err <= 1e-4 * max(1.0, float(g["y_absmax"])), err
     assert err <= 1e-3
+
+
+# ------------------------------------------------------------------------------------------------ FIR-up layers on the 256-column tile (round 4)
+WIDE_UP = "migan::sepconv_wide_kernel<false, 0, false, true, true, true>"
+
+
+@pytest.mark.parametrize("case", [
+    dict(cin=64, cout=256, h=16, batch=2, noise=True, skip=True),
+    dict(cin=96, cout=512, h=12, w=20, batch=3, noise=True),
+    dict(cin=512, cout=256, h=64, batch=2, noise=True, skip=True),           # synthesis.b128.conv1 of migan-512
+    dict(cin=512, cout=512, h=32, batch=4, noise=True, skip=True),           # synthesis.b64.conv1
+    dict(cin=160, cout=256, h=6, w=14, batch=1, skip=True),
+])
+def test_fir_up_on_the_wide_tile(pkg, dev, tuned, case):
+    """up=2 SeparableConv2d with Cout % 256 == 0: sepconv_wide_kernel<..., UP> against the oracle; with wide_up = 0 the 128-column kernel"""
+    lib = pkg.load_library()
+    run_sepconv_case(lib, pkg, CudaMem(dev), storage="f32", gemm=2, up=2, **case)
+    assert lib.last_kernel() == WIDE_UP, lib.last_kernel()
+    tuned("wide_up", 0)
+    run_sepconv_case(lib, pkg, CudaMem(dev), storage="f32", gemm=2, up=2, **case)
+    assert lib.last_kernel().startswith("migan::sepconv_kernel<2, "), lib.last_kernel()
