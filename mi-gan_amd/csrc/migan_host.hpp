@@ -310,8 +310,8 @@ inline const std::vector<KernelEntry>& kernel_table() {
 // sepconv_wide_kernel<TORGB, STV, X1, BALL, DMA>: x1 = GEMM variant "f16" (one fp16 piece per operand; 16-bit storage only);
 // ball = waves 4-7 run all the MFMAs (tuning().wide >= 2); dma = LDS-DMA staging (tuning().wide == 3, fp32 storage)
 #define MIGAN_WIDE_ROW(T, X, B) {sepconv_wide_kernel<T, 0, X, B>, sepconv_wide_kernel<T, 1, X, B>, sepconv_wide_kernel<T, 2, X, B>}
-#define MIGAN_WIDE_NAMES(T, X, B) {"migan::sepconv_wide_kernel<" #T ", 0, " #X ", " #B ", false>", "migan::sepconv_wide_kernel<" #T ", 1, " #X ", " #B ", false>", \
-                                   "migan::sepconv_wide_kernel<" #T ", 2, " #X ", " #B ", false>"}
+#define MIGAN_WIDE_NAMES(T, X, B) {"migan::sepconv_wide_kernel<" #T ", 0, " #X ", " #B ", false, false>", "migan::sepconv_wide_kernel<" #T ", 1, " #X ", " #B ", false, false>", \
+                                   "migan::sepconv_wide_kernel<" #T ", 2, " #X ", " #B ", false, false>"}
 inline bool wide_ball() { return tuning().wide >= 2; }
 inline bool wide_dma(int stv, bool x1) { return tuning().wide == 3 && stv == 0 && !x1; }
 inline SepKernelFn wide_fn(bool torgb, int stv, bool x1 = false, bool ball = false, bool dma = false) {
@@ -330,7 +330,7 @@ inline const char* wide_name(const Geo& g) {
       {{MIGAN_WIDE_NAMES(false, false, false), MIGAN_WIDE_NAMES(true, false, false)}, {MIGAN_WIDE_NAMES(false, true, false), MIGAN_WIDE_NAMES(true, true, false)}},
       {{MIGAN_WIDE_NAMES(false, false, true), MIGAN_WIDE_NAMES(true, false, true)}, {MIGAN_WIDE_NAMES(false, true, true), MIGAN_WIDE_NAMES(true, true, true)}}};
   if (wide_dma(g.stv, g.gemmv == 3))
-    return g.torgb ? "migan::sepconv_wide_kernel<true, 0, false, true, true>" : "migan::sepconv_wide_kernel<false, 0, false, true, true>";
+    return g.torgb ? "migan::sepconv_wide_kernel<true, 0, false, true, true, false>" : "migan::sepconv_wide_kernel<false, 0, false, true, true, false>";
   return n[wide_ball() ? 1 : 0][g.gemmv == 3 ? 1 : 0][g.torgb ? 1 : 0][g.stv];
 }
 // symbol of the fused-SeparableConv2d kernel this thread launched last (migan_last_kernel: tests ask which form ran)

@@ -52,7 +52,9 @@ struct PipeLds {
   static constexpr int T_SZ = MODE == MODE_UP ? 128 * (64 + 4) * 4 : kPipeBWaves * 32 * 32 * 4;   // FIR-up: shared result tile of 64 columns (a 128-column
                                                                     // layer passes its two halves through it one after the other); plain: one transpose patch per B wave
   static constexpr int OFF_P = OFF_T + T_SZ;                       // plain + ToRGB: per-pixel partial sums of the waves of column half 1, [128 pixels][4]
-  static constexpr int TOTAL = OFF_P + (MODE == MODE_UP ? 0 : 128 * 16);
+  static constexpr int OFF_PW = OFF_P + (MODE == MODE_UP ? 0 : 128 * 16);      // ToRGB: the window of the previous (half-resolution) image under a tile,
+  static constexpr int PW_SZ = 3 * 64 * 4;                                       // two tiles x [3 colours][6 rows x 10 columns, padded to 64] fp32
+  static constexpr int TOTAL = OFF_PW + (MODE == MODE_UP ? 0 : 2 * PW_SZ);
   static_assert(TOTAL <= 160 * 1024, "LDS budget");
 };
 
@@ -508,10 +510,36 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(pipe_threads(NA), (NA + kPipeBWaves) / 4) 
       MIGAN_BARRIER_LDS();                                     // barrier 0
       dslot = 1 % R;
       int dc = 1;
+      // ToRGB: the 6 x 10 window of the previous image under the tile whose first K step this is -> LDS (one 4-byte DMA instruction per
+      // colour, issued by wave 0; positions outside the image are lane offsets beyond the buffer = the upsampling FIR's zero padding).
+      // Group B reads it when it finishes that tile's ToRGB tail, NKC + NTIW steps later; the buffer is rewritten two tiles on.
+      TileCur wtc = tile0;
+      int wk = 0, wstep = 0;
+      const MIGAN_BUF pbuf = MIGAN_MAKE_BUF(p.img_prev, p.img_prev ? (unsigned)((size_t)p.B * 3 * (p.HO >> 1) * (p.WO >> 1)) * 4u : 0u);
+      auto issue_prev_window = [&]() {
+        if constexpr (TORGB) {
+          if (wstep == 0) {
+            if (p.img_prev && wave_u == 0) {                                    // (one wave: spread over three it measured 7 % slower)
+              const int hp = p.HO >> 1, wp = p.WO >> 1;
+              const int row = lane / 10, col = lane - row * 10;                 // (lanes 60..63: padding)
+              const int yy = ((wtc.y * p.sy - p.off) >> 1) - 1 + row, xx = ((wtc.x * p.sx - p.off) >> 1) - 1 + col;
+              const bool ok = lane < 60 && yy >= 0 && yy < hp && xx >= 0 && xx < wp;
+              const unsigned voff = ok ? (unsigned)(yy * wp + xx) * 4u : 0xfffff000u;
+              float* pw = reinterpret_cast<float*>(lds + L::OFF_PW + (wk & 1) * L::PW_SZ);
+#pragma unroll
+              for (int ch = 0; ch < 3; ++ch) MIGAN_LDS_DMA4(pbuf, voff, (unsigned)((wtc.b * 3 + ch) * hp * wp) * 4u, pw + ch * 64);
+            }
+            ++wk;
+            if (wk < T) tile_next(wtc);
+          }
+          wstep = wstep + 1 == NKC ? 0 : wstep + 1;
+        }
+      };
       for (int g = 0; g < G; ++g) {
         // interval g: B runs the MFMAs of step g.  Slot g % R (read by the depthwise stage of step g) and weight slot (g+1) & 1 (read by the
         // MFMAs of step g-1) are free: refill them first, then the depthwise stage of step g+1
         if constexpr (!WRES) { if (g >= 1) issue_b(); }        // step g+1 (steps 0 and 1 were issued by the prologue)
+        issue_prev_window();                                   // (older than the input chunk issued next: covered by the counted wait below)
         issue_in();                                            // step g+R
         if constexpr (!TAPS_RES) { if (g + 2 < G) load_taps((dc + 1) % NKC); }      // taps of step g+2 (dc is the chunk of step g+1)
         PPROF_MARK(0);
@@ -591,12 +619,13 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(pipe_threads(NA), (NA + kPipeBWaves) / 4) 
 
   // coordinates of the tile whose accumulators are in `accp` (pn0 etc.) and of the tile being accumulated (cn0 etc.)
   int ck = 0, cn0 = 0, cb0 = 0, cgy0 = 0, cgx0 = 0, pn0 = 0, pb0 = 0, pgy0 = 0, pgx0 = 0;
+  int ppar = 0;                                                   // parity of the tile being finished = its previous-image window buffer
   TileCur ctc = tile0;
   tile_coords(ctc, cn0, cb0, cgy0, cgx0);
   auto hand_over = [&]() {
 #pragma unroll
     for (int j = (MODE == MODE_NORMAL ? 1 : 0); j < NTIW; ++j) accp[j] = acc[j];      // (plain layers stage block 0 straight from `acc`)
-    pn0 = cn0; pb0 = cb0; pgy0 = cgy0; pgx0 = cgx0;
+    pn0 = cn0; pb0 = cb0; pgy0 = cgy0; pgx0 = cgx0; ppar = ck & 1;
     if (++ck < T) { tile_next(ctc); tile_coords(ctc, cn0, cb0, cgy0, cgx0); }
   };
 
@@ -646,12 +675,8 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(pipe_threads(NA), (NA + kPipeBWaves) / 4) 
         for (int ch = 0; ch < 3; ++ch) tw[j][ch] = ld4(p.trgb_w + ch * p.CO + cbk * (NT / 2) + j * 32 + q4 * 4);
     }
     // ToRGB tail (reference :308-313), run by the waves of column half 0: lane q4 < 4 of each 8-lane pixel group finishes pixel q = q4 of
-    // the group: own sums + the other half's (through LDS) + bias + the 2x-upsampled previous image, whose 2x2 taps per colour it holds in pv
-    float pv[3][4], pvn[3][4];
-#pragma unroll
-    for (int ch = 0; ch < 3; ++ch)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) pv[ch][e] = pvn[ch][e] = 0.0f;
+    // the group: own sums + the other half's (through LDS) + bias + the 2x-upsampled previous image (reference Upsample2d :79-104), whose
+    // 2x2 taps per colour it reads from the window group A has put into LDS (zeros outside the image: no border cases here)
     float* const part_s = reinterpret_cast<float*>(lds + L::OFF_P) + rb * (32 * 4);
     // pixel of (q, lane): GEMM row m = 32 rb + 8 q + prow -> tile row 2 rb + (q >> 1), column 8 (q & 1) + prow.
     // Everything the next epilogue loads (noise values, previous-image taps) is requested before the last store slice of the previous
@@ -663,24 +688,6 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(pipe_threads(NA), (NA + kPipeBWaves) / 4) 
 #pragma unroll
         for (int q = 0; q < 4; ++q) nzn[q] = *at_bytes(p.noise + ((q >> 1) * p.WO + (q & 1) * 8), px);
       }
-      if constexpr (TORGB) {
-        if (p.img_prev && cbk == 0 && q4 < 4) {
-          // 2x2 taps of Upsample2d under output pixel (oy, ox): clamped coordinates, combined by up_combine (zero outside)
-          const int oy = cgy0 + 2 * rb + (q4 >> 1), ox = cgx0 + (q4 & 1) * 8 + prow;
-          const int hp = p.HO >> 1, wp = p.WO >> 1;
-          const int y0 = (oy & 1) ? (oy >> 1) : (oy >> 1) - 1, x0 = (ox & 1) ? (ox >> 1) : (ox >> 1) - 1;
-          const int cy0 = y0 >= 0 ? y0 : 0, cy1 = y0 + 1 < hp ? y0 + 1 : hp - 1, cx0 = x0 >= 0 ? x0 : 0, cx1 = x0 + 1 < wp ? x0 + 1 : wp - 1;
-          const unsigned o00 = (unsigned)(cy0 * wp + cx0) * 4u, o01 = (unsigned)(cy0 * wp + cx1) * 4u;
-          const unsigned o10 = (unsigned)(cy1 * wp + cx0) * 4u, o11 = (unsigned)(cy1 * wp + cx1) * 4u;
-          const size_t plane4 = (size_t)hp * wp;
-#pragma unroll
-          for (int ch = 0; ch < 3; ++ch) {
-            const float* pl = p.img_prev + ((size_t)cb0 * 3 + ch) * plane4;
-            pvn[ch][0] = *at_bytes(pl, o00); pvn[ch][1] = *at_bytes(pl, o01);
-            pvn[ch][2] = *at_bytes(pl, o10); pvn[ch][3] = *at_bytes(pl, o11);
-          }
-        }
-      }
     };
     auto begin_tile_epilogue = [&]() {
       pix0 = (unsigned)((pgy0 + 2 * rb) * p.WO + pgx0 + prow);
@@ -689,10 +696,6 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(pipe_threads(NA), (NA + kPipeBWaves) / 4) 
       if constexpr (TORGB) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) rs[q][0] = rs[q][1] = rs[q][2] = 0.0f;
-#pragma unroll
-        for (int ch = 0; ch < 3; ++ch)
-#pragma unroll
-          for (int e = 0; e < 4; ++e) pv[ch][e] = pvn[ch][e];
       }
     };
     // A block of accumulators goes through the patch in three moves that sit in DIFFERENT places of the K step, so that no LDS round
@@ -752,8 +755,15 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(pipe_threads(NA), (NA + kPipeBWaves) / 4) 
         o3[1] += tbias[1]; MIGAN_OPAQUE_F(o3[1]);
         o3[2] += tbias[2]; MIGAN_OPAQUE_F(o3[2]);
         if (p.img_prev) {
+          const int y0 = (oy & 1) ? (oy >> 1) : (oy >> 1) - 1, x0 = (ox & 1) ? (ox >> 1) : (ox >> 1) - 1;     // first of the two taps per axis
+          const float wy0 = (oy & 1) ? 0.75f : 0.25f, wx0 = (ox & 1) ? 0.75f : 0.25f;
+          const float* pw = reinterpret_cast<const float*>(lds + L::OFF_PW + ppar * L::PW_SZ) + (y0 - (pgy0 >> 1) + 1) * 10 + (x0 - (pgx0 >> 1) + 1);
 #pragma unroll
-          for (int ch = 0; ch < 3; ++ch) o3[ch] = up_combine(pv[ch], oy, ox, p.HO >> 1, p.WO >> 1) + o3[ch];
+          for (int ch = 0; ch < 3; ++ch) {
+            const float r0 = wx0 * pw[ch * 64] + (1.0f - wx0) * pw[ch * 64 + 1];
+            const float r1 = wx0 * pw[ch * 64 + 10] + (1.0f - wx0) * pw[ch * 64 + 11];
+            o3[ch] = (wy0 * r0 + (1.0f - wy0) * r1) + o3[ch];
+          }
         }
         if (p.u8_out) {
           compose_pixel(p.u8_img, p.u8_mask, p.u8_out, (size_t)pb0 * plane + (size_t)oy * p.WO + ox, o3[0], o3[1], o3[2]);

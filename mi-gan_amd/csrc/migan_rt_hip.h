@@ -95,6 +95,9 @@ __device__ __forceinline__ MIGAN_BUF migan_make_buf(const void* p, unsigned byte
 // no VGPR and no ds_write in between.  Completion is tracked by vmcnt; hipcc waits for it (vmcnt(0)) at the next __syncthreads().
 #define MIGAN_LDS_DMA16(buf, voff, soff, ldsp) \
   __builtin_amdgcn_raw_ptr_buffer_load_lds((buf), (__attribute__((address_space(3))) void*)(ldsp), 16, (int)(voff), (int)(soff), 0, 0)
+// buffer_load_dword ... lds: 4 bytes per lane, LDS destination ldsp + 4 * lane
+#define MIGAN_LDS_DMA4(buf, voff, soff, ldsp) \
+  __builtin_amdgcn_raw_ptr_buffer_load_lds((buf), (__attribute__((address_space(3))) void*)(ldsp), 4, (int)(voff), (int)(soff), 0, 0)
 
 // ---- hand-placed synchronisation of the LDS-DMA pipelines (sepconv_pipe_kernel, sepconv_wide_kernel<..., DMA>) --------------------
 // s_waitcnt vmcnt(n): at most n of this wave's vector-memory operations (LDS-DMAs, loads, stores: issue order) still outstanding.

@@ -39,6 +39,7 @@ struct Dim3 {
 struct DmaOp {
   char* dst;
   unsigned char data[16];
+  int bytes = 16;
 };
 
 struct Lane {
@@ -306,13 +307,24 @@ inline void hipemu_lds_dma16(MIGAN_BUF b, unsigned voff, unsigned soff, float* w
   blk->lanes[blk->cur].dma.push_back(op);
 }
 #define MIGAN_LDS_DMA16(buf, voff, soff, ldsp) hipemu_lds_dma16((buf), (voff), (soff), (ldsp))
+inline void hipemu_lds_dma4(MIGAN_BUF b, unsigned voff, unsigned soff, float* wave_base) {       // buffer_load_dword ... lds
+  hipemu::Block* blk = hipemu::tl_blk;
+  const int lane = blk->cur & 63;
+  hipemu::DmaOp op;
+  op.bytes = 4;
+  op.dst = reinterpret_cast<char*>(wave_base) + 4 * lane;
+  if ((unsigned long long)voff + 4ull > (unsigned long long)b.n) std::memset(op.data, 0, 4);
+  else std::memcpy(op.data, b.p + voff + soff, 4);
+  blk->lanes[blk->cur].dma.push_back(op);
+}
+#define MIGAN_LDS_DMA4(buf, voff, soff, ldsp) hipemu_lds_dma4((buf), (voff), (soff), (ldsp))
 inline void hipemu_wait_vmcnt(int n) {
   hipemu::Block* blk = hipemu::tl_blk;
   std::vector<hipemu::DmaOp>& q = blk->lanes[blk->cur].dma;
   const size_t keep = (size_t)(n < 0 ? 0 : n);
   if (q.size() <= keep) return;
   const size_t done = q.size() - keep;
-  for (size_t i = 0; i < done; ++i) std::memcpy(q[i].dst, q[i].data, 16);
+  for (size_t i = 0; i < done; ++i) std::memcpy(q[i].dst, q[i].data, (size_t)q[i].bytes);
   q.erase(q.begin(), q.begin() + (long)done);
 }
 #define MIGAN_WAIT_VMCNT(n) hipemu_wait_vmcnt(n)
