@@ -44,11 +44,12 @@ struct PipeLds {
   static constexpr int OFF_W = OFF_B + NBUF_B * B_CHUNK;            // depthwise taps, per chunk tap-major [9][32] + bias [32]
   static constexpr bool TAPS_RES = NKC <= 8;                        // all chunks resident; otherwise a two-chunk ring refilled through registers
   // FROMRGB (the 1x1 conv 4 -> Cin as a bf16x3-split MFMA, K = 4 inputs + the bias against a "pixel is inside the image" flag):
-  static constexpr int OFF_F = OFF_W + (TAPS_RES ? NKC : 2) * 1280; // its B operand: per chunk [3 pieces][32 columns][8 bf16: w0..w3, bias, 0, 0, 0]
-  static constexpr int F_SZ = FROMRGB ? NKC * 3 * 32 * 16 : 0;
-  static constexpr int OFF_RGB = OFF_F + F_SZ;                      // its A operand, two tiles: [3 pieces][192 rows][8 bf16: x0..x3, flag, 0, 0, 0], then 16 zero bytes
-  static constexpr int RGB_BUF = 3 * 192 * 16;
-  static constexpr int OFF_T = OFF_RGB + (FROMRGB ? 2 * RGB_BUF + 16 : 0);
+  // K of one MFMA = the three bf16 pieces of a pixel side by side: k 0..4 = h1 [x0 x1 x2 x3 flag], k 5..9 = h2 [.. 0], k 10..14 = h3 [.. 0], k 15 = 0
+  static constexpr int OFF_F = OFF_W + (TAPS_RES ? NKC : 2) * 1280; // its B operands: per chunk three arrangements [32 columns][16 bf16]: (b1 b1 b1), (b2 b2 0), (b3 0 0)
+  static constexpr int F_SZ = FROMRGB ? NKC * 3 * 32 * 32 : 0;
+  static constexpr int OFF_RGB = OFF_F + F_SZ;                      // its A operand, two tiles: [192 rows][16 bf16]
+  static constexpr int RGB_BUF = 192 * 32;
+  static constexpr int OFF_T = OFF_RGB + (FROMRGB ? 2 * RGB_BUF : 0);
   static constexpr int T_SZ = MODE == MODE_UP ? 128 * (64 + 4) * 4 : kPipeBWaves * 32 * 32 * 4;   // FIR-up: shared result tile of 64 columns (a 128-column
                                                                     // layer passes its two halves through it one after the other); plain: one transpose patch per B wave
   static constexpr int OFF_P = OFF_T + T_SZ;                       // plain + ToRGB: per-pixel partial sums of the waves of column half 1, [128 pixels][4]
@@ -147,12 +148,14 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(pipe_threads(NA), (NA + kPipeBWaves) / 4) 
 
   // ---- FROMRGB: the input tile is act(fromrgb(network input)) (reference :194-195), BUILT instead of copied.  fromrgb is a 1x1
   // convolution (4 -> Cin, with bias): it runs on the matrix cores like the other 1x1s, as v_mfma_f32_32x32x16_bf16 on bf16x3-split operands
-  // (x = h1 + h2 + h3, six products: fp32-grade, and bf16 has fp32's exponent range, so the unbounded network input needs no scaling).
-  // K = 5 of 16: the four input planes and a flag that is 1 inside the image and 0 on the conv's zero padding, against which the bias
-  // is multiplied -- a padding pixel comes out as exactly 0 = act(0), as the reference's F.pad of the activated tensor.  Group A turns the
-  // raw pixels of the next tile into the A operand pieces; group B (waves 0..5: one 32-pixel row block each) multiplies, activates and
-  // writes chunk s+2 of the tile while group A runs the depthwise stage of chunk s+1.  (Rounds 1-3 and the first form of this kernel did
-  // the 4 -> Cin products as scalar FMA chains on the VALU: half of this layer's instructions, profiles/r04_pipe_phase_profile.txt (4).)
+  // (x = x1 + x2 + x3, the six products of order <= 2^-16: fp32-grade, and bf16 has fp32's exponent range, so the unbounded network input
+  // needs no scaling).  Only 5 of an MFMA's 16 K slots would be used by one piece (the four input planes and a flag that is 1 inside the
+  // image and 0 on the conv's zero padding, against which the bias is multiplied -- a padding pixel comes out as exactly 0 = act(0), as the
+  // reference's F.pad of the activated tensor), so the three pieces of a pixel sit side by side along K and three MFMAs against the
+  // weight arrangements (w1 w1 w1), (w2 w2 0), (w3 0 0) produce the six products (first form: one piece per MFMA, six MFMAs and three
+  // operand reads per unit: +5 %).  Group A turns the raw pixels of the next tile into A-operand rows; group B (waves 0..5: one 32-pixel
+  // row block each) multiplies, activates and writes chunk s+2 of the tile while group A runs the depthwise stage of chunk s+1.  (Rounds
+  // 1-3 and the first form of this kernel did the 4 -> Cin products as scalar FMA chains on the VALU.)
   struct BuildCursor {
     int is, ic, ik, slot;
   };
@@ -176,25 +179,19 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(pipe_threads(NA), (NA + kPipeBWaves) / 4) 
   auto build_units = [&](const BuildCursor& bc, int wave, int nwaves) {
     if (bc.is >= G || MIGAN_ABL(16)) return;
     const int bl31 = tid & 31, bhalf = (tid >> 5) & 1;
-    const char* r_s = lds + L::OFF_RGB;
+    const char* r_s = lds + L::OFF_RGB + (bc.ik & 1) * L::RGB_BUF + bhalf * 16;
+    const char* f_s = lds + L::OFF_F + bc.ic * (3 * 32 * 32) + bl31 * 32 + bhalf * 16;
     float* in_s = reinterpret_cast<float*>(lds + L::OFF_IN + bc.slot * L::IN_SLOT);
     for (int u = wave; u >= 0 && u < 6; u += nwaves) {
-      const char* ap = bhalf ? r_s + 2 * L::RGB_BUF : r_s + (bc.ik & 1) * L::RGB_BUF + (u * 32 + bl31) * 16;
-      const char* bp = bhalf ? r_s + 2 * L::RGB_BUF : lds + L::OFF_F + bc.ic * (3 * 32 * 16) + bl31 * 16;
-      const int astr = bhalf ? 0 : 192 * 16, bstr = bhalf ? 0 : 32 * 16;
-      f4 a[3], b[3];
+      const f4 a = ld4(reinterpret_cast<const float*>(r_s + (u * 32 + bl31) * 32));
+      f4 b[3];                                                   // (held in registers across the tiles they measured 15 % slower: indexed by chunk)
 #pragma unroll
-      for (int pc = 0; pc < 3; ++pc) {
-        a[pc] = ld4(reinterpret_cast<const float*>(ap + pc * astr));
-        b[pc] = ld4(reinterpret_cast<const float*>(bp + pc * bstr));
-      }
+      for (int q = 0; q < 3; ++q) b[q] = ld4(reinterpret_cast<const float*>(f_s + q * (32 * 32)));
+      // (x1 + x2 + x3) b1 + (x1 + x2) b2 + x1 b3: the six products of order <= 2^-16, smallest first
       f16v c = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-      c = MIGAN_MFMA_BF16_32X32X16(a[2], b[0], c);
-      c = MIGAN_MFMA_BF16_32X32X16(a[1], b[1], c);
-      c = MIGAN_MFMA_BF16_32X32X16(a[0], b[2], c);
-      c = MIGAN_MFMA_BF16_32X32X16(a[1], b[0], c);
-      c = MIGAN_MFMA_BF16_32X32X16(a[0], b[1], c);
-      c = MIGAN_MFMA_BF16_32X32X16(a[0], b[0], c);
+      c = MIGAN_MFMA_BF16_32X32X16(a, b[2], c);
+      c = MIGAN_MFMA_BF16_32X32X16(a, b[1], c);
+      c = MIGAN_MFMA_BF16_32X32X16(a, b[0], c);
       float* o = in_s + (u * 32 + 4 * bhalf) * KC + bl31;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -204,8 +201,6 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(pipe_threads(NA), (NA + kPipeBWaves) / 4) 
     }
   };
 
-  // issue priority to the depthwise group where it is the critical one by a margin (profiles/r04_pipe_phase_profile.txt): four waves beside
-  // the fused-FromRGB build.  (Priority to group B in the other forms: -2 % on the 64 -> 64 + ToRGB layer, +4 % on the FIR-up layer: not used.)
   if (groupA) {
     if (FROMRGB && NA == 4) MIGAN_SETPRIO(2);
     // =============================================== group A: DMA issue + depthwise stage ===========================================
@@ -244,25 +239,34 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(pipe_threads(NA), (NA + kPipeBWaves) / 4) 
       }
     };
     if constexpr (FROMRGB) {
-      // fromrgb.weight [CIN][4] + bias [CIN] (reference :186) -> B operand pieces, per chunk [3][32 columns][8 bf16]
+      // fromrgb.weight [CIN][4] + bias [CIN] (reference :186), x gain -> the three B operand arrangements, per chunk [3][32 columns][16 bf16]
       char* const f_s = lds + L::OFF_F;
       for (int i = lt; i < CIN; i += AT) {
         const f4 w = ld4(p.frgb_w + i * 4) * 1.41421356237309515f;             // lrelu_agc's gain (positive) commutes with the leaky relu
         u2v w1, w2, w3, b1, b2, b3;
         split3_bf16(w, w1, w2, w3);
         split3_bf16(f4{p.frgb_b[i] * 1.41421356237309515f, 0.f, 0.f, 0.f}, b1, b2, b3);
-        char* d = f_s + (i >> 5) * (3 * 32 * 16) + (i & 31) * 16;
-        *reinterpret_cast<u4v*>(d) = u4v{w1.x, w1.y, b1.x, 0u};
-        *reinterpret_cast<u4v*>(d + 32 * 16) = u4v{w2.x, w2.y, b2.x, 0u};
-        *reinterpret_cast<u4v*>(d + 2 * 32 * 16) = u4v{w3.x, w3.y, b3.x, 0u};
+        // one 5-slot group [w0 w1 w2 w3 bias] starting at k = 0, the same shifted to k = 5 (its bias slot meets the zero flag slot of x2 / x3:
+        // left 0) and to k = 10
+        auto g0 = [](u2v wq, u2v bq, unsigned (&e)[8]) { e[0] = wq.x; e[1] = wq.y; e[2] |= bq.x & 0xffffu; };
+        auto g1 = [](u2v wq, unsigned (&e)[8]) { e[2] |= wq.x << 16; e[3] = (wq.x >> 16) | (wq.y << 16); e[4] |= wq.y >> 16; };
+        auto g2 = [](u2v wq, unsigned (&e)[8]) { e[5] = wq.x; e[6] = wq.y; };
+        unsigned e1[8] = {0, 0, 0, 0, 0, 0, 0, 0}, e2[8] = {0, 0, 0, 0, 0, 0, 0, 0}, e3[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        g0(w1, b1, e1); g1(w1, e1); g2(w1, e1);
+        g0(w2, b2, e2); g1(w2, e2);
+        g0(w3, b3, e3);
+        char* d = f_s + (i >> 5) * (3 * 32 * 32) + (i & 31) * 32;
+        *reinterpret_cast<u4v*>(d) = u4v{e1[0], e1[1], e1[2], e1[3]};
+        *reinterpret_cast<u4v*>(d + 16) = u4v{e1[4], e1[5], e1[6], e1[7]};
+        *reinterpret_cast<u4v*>(d + 32 * 32) = u4v{e2[0], e2[1], e2[2], e2[3]};
+        *reinterpret_cast<u4v*>(d + 32 * 32 + 16) = u4v{e2[4], e2[5], e2[6], e2[7]};
+        *reinterpret_cast<u4v*>(d + 2 * 32 * 32) = u4v{e3[0], e3[1], e3[2], e3[3]};
+        *reinterpret_cast<u4v*>(d + 2 * 32 * 32 + 16) = u4v{e3[4], e3[5], e3[6], e3[7]};
       }
-      // rows 180..191 of both A-operand buffers (the sixth row block's padding) and the zero slot: written once
+      // rows 180..191 of both A-operand buffers (the sixth row block's padding): written once
       char* const r_s = lds + L::OFF_RGB;
-      for (int i = lt; i < 2 * 3 * 12; i += AT) {
-        const int buf = i / 36, rem = i % 36;
-        *reinterpret_cast<u4v*>(r_s + buf * L::RGB_BUF + (rem / 12) * (192 * 16) + (180 + rem % 12) * 16) = u4v{0u, 0u, 0u, 0u};
-      }
-      if (lt == 0) *reinterpret_cast<u4v*>(r_s + 2 * L::RGB_BUF) = u4v{0u, 0u, 0u, 0u};
+      for (int i = lt; i < 2 * 12 * 2; i += AT)
+        *reinterpret_cast<u4v*>(r_s + (i / 24) * L::RGB_BUF + 180 * 32 + (i % 24) * 16) = u4v{0u, 0u, 0u, 0u};
     }
 
     // ---- 1x1 weight planes (split_weights_kernel: chunk-major [plane][CIN/32][CO][32] fp16) -> LDS, XOR swizzle on the SOURCE side ----
@@ -349,15 +353,15 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(pipe_threads(NA), (NA + kPipeBWaves) / 4) 
       }
       rraw = v;
     };
-    // raw pixel -> the three bf16 pieces of its A-operand row [x0, x1, x2, x3, flag, 0, 0, 0] (flag = 1.0 inside the image: exact in bf16)
+    // raw pixel -> its A-operand row: the three bf16 pieces [x0 x1 x2 x3 flag] (flag = 1.0 inside the image in the first piece: exact in
+    // bf16; 0 in the others) side by side along K
     auto store_raw = [&](int buf) {
       if (lt < NPIX) {
         u2v h1, h2, h3;
         split3_bf16(rraw, h1, h2, h3);
-        char* d = lds + L::OFF_RGB + buf * L::RGB_BUF + lt * 16;
-        *reinterpret_cast<u4v*>(d) = u4v{h1.x, h1.y, rvalid ? 0x3f80u : 0u, 0u};
-        *reinterpret_cast<u4v*>(d + 192 * 16) = u4v{h2.x, h2.y, 0u, 0u};
-        *reinterpret_cast<u4v*>(d + 2 * 192 * 16) = u4v{h3.x, h3.y, 0u, 0u};
+        char* d = lds + L::OFF_RGB + buf * L::RGB_BUF + lt * 32;
+        *reinterpret_cast<u4v*>(d) = u4v{h1.x, h1.y, (rvalid ? 0x3f80u : 0u) | (h2.x << 16), (h2.x >> 16) | (h2.y << 16)};
+        *reinterpret_cast<u4v*>(d + 16) = u4v{h2.y >> 16, h3.x, h3.y, 0u};
       }
     };
 
