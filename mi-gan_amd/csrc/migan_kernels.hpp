@@ -1486,14 +1486,23 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(kWideThreads, 2) sepconv_wide_kernel(const
 
   // ---- prologue: chunk 0 complete in LDS (input, taps, A planes, B planes), chunk 1 input in LDS ----------
   const int nkc = p.CI / KC;
+  // DMA form: a workgroup walks the K chunks starting at a chunk that depends on its tile position in the image (not on the image's place
+  // in the batch: an image stays bit-identical whatever batch it is in), so that the workgroups of an XCD -- which start together --
+  // do not all ask the L2 for the same 32 KB of weight planes at the same moment
+#ifdef MIGAN_NO_KROT
+  const int krot = 0;
+#else
+  const int krot = DMA ? (tx + 3 * ty) % nkc : 0;
+#endif
+  auto kof = [&](int c) { int k = c + krot; if (k >= nkc) k -= nkc; return k * KC; };      // (c < nkc)
   if constexpr (DMA) {
-    dma_in(0, 0);
-    dma_b(0, 0);
-    load_taps(0);
+    dma_in(kof(0), 0);
+    dma_b(kof(0), 0);
+    load_taps(kof(0));
     store_taps(0);
     if (1 < nkc) {
-      dma_in(KC, 1);
-      load_taps(KC);
+      dma_in(kof(1), 1);
+      load_taps(kof(1));
       store_taps(1);
     }
     // every wave waits for ITS OWN DMAs before the barrier that publishes them: gfx950 barriers do not drain the VM counter, and
@@ -1521,10 +1530,10 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(kWideThreads, 2) sepconv_wide_kernel(const
     if constexpr (DMA) {
       // in_s / w_s[c&1] were last read by the depthwise stage of chunk c (previous iteration), b_s[(c+1)&1] by the MFMAs of chunk c-1
       if (c + 2 < nkc) {
-        dma_in((c + 2) * KC, c & 1);
-        load_taps((c + 2) * KC);
+        dma_in(kof(c + 2), c & 1);
+        load_taps(kof(c + 2));
       }
-      if (c + 1 < nkc) dma_b((c + 1) * KC, (c + 1) & 1);
+      if (c + 1 < nkc) dma_b(kof(c + 1), (c + 1) & 1);
       PROF_MARK(pslot + 0);
       return;
     }
