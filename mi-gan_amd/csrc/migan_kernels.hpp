@@ -1486,14 +1486,10 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(kWideThreads, 2) sepconv_wide_kernel(const
 
   // ---- prologue: chunk 0 complete in LDS (input, taps, A planes, B planes), chunk 1 input in LDS ----------
   const int nkc = p.CI / KC;
-  // DMA form: a workgroup walks the K chunks starting at a chunk that depends on its tile position in the image (not on the image's place
-  // in the batch: an image stays bit-identical whatever batch it is in), so that the workgroups of an XCD -- which start together --
-  // do not all ask the L2 for the same 32 KB of weight planes at the same moment
-#ifdef MIGAN_NO_KROT
+  // (Starting the K loop at a tile-position-dependent chunk, so that the workgroups of an XCD do not ask the L2 for the same weight planes
+  // at the same moment, measured -1..-3 % on these layers -- but a layer must sum its K chunks in ONE order in every kernel form, or an image
+  // is no longer bit-identical between a batch that takes this kernel and one that takes the small-launch tiles: not done.)
   const int krot = 0;
-#else
-  const int krot = DMA ? (tx + 3 * ty) % nkc : 0;
-#endif
   auto kof = [&](int c) { int k = c + krot; if (k >= nkc) k -= nkc; return k * KC; };      // (c < nkc)
   if constexpr (DMA) {
     dma_in(kof(0), 0);
