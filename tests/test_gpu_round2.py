@@ -224,7 +224,7 @@ def test_small_launch_tiles_do_not_change_results_across_batch_sizes(pkg, dev):
 # ------------------------------------------------------------------------------------------------ sub-batches on two streams
 def test_batch32_distinct_images_two_streams(pkg, dev):
     """BASELINE configs[2] with 32 DISTINCT images: the two-stream forward (two staggered sub-batches of 16) is bit-identical
-    to the one-stream forward, run-to-run deterministic, and four random images of the batch match the CPU port."""
+    to the one-stream forward, run-to-run deterministic, and ALL 32 images match the CPU port (tolerance 1e-4 on |y| <= ~32)."""
     res, seed = 512, 52
     m, sd = _model(pkg, res, seed, dev)
     x = pkg.synth.make_input(32, res, seed=seed, kind="demo")
@@ -237,9 +237,12 @@ def test_batch32_distinct_images_two_streams(pkg, dev):
         y1 = m(xt)
     torch.cuda.synchronize()
     assert torch.equal(y2, y2b) and torch.equal(y2, y1)
-    idx = sorted(np.random.default_rng(seed).choice(32, size=4, replace=False).tolist())
-    want = torc.generator(x[idx], sd, res)
-    assert float((y2[idx].cpu() - want).abs().max()) <= TOL
+    got = y2.cpu()
+    worst = 0.0
+    for i0 in range(0, 32, 8):                                  # (the port runs ~1 image/s on the host: eight at a time)
+        want = torc.generator(x[i0:i0 + 8], sd, res)
+        worst = max(worst, float((got[i0:i0 + 8] - want).abs().max()))
+    assert worst <= TOL, worst
     # the caller's stream is ordered after both sub-batches: work enqueued behind the forward sees the complete output
     with torch.no_grad():
         m.set_streams(2)
