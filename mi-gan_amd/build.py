@@ -23,6 +23,7 @@ OUT = os.path.join(CSRC, "libmigan_hip.so")
 OBJ = os.path.join(CSRC, "_obj")
 SOURCES = [os.path.join(CSRC, f) for f in ("migan_hip.hip", "migan_k_slice.hip", "migan_k_slice.inc", "migan_table.hpp",
                                             "migan_pipe.hip", "migan_pipe.hpp", "migan_pipe_table.inc",
+                                            "migan_wide2.hip", "migan_wide2.hpp", "migan_wide2_table.inc",
                                             "migan_kernels.hpp", "migan_host.hpp", "migan_rt_hip.h",
                                             "comodgan_kernels.hpp", "comodgan_host.hpp", "migan_pipeline.hpp")] + [
     os.path.join(ROOT, "include", "migan_hip.h"), os.path.join(ROOT, "include", "comodgan_hip.h")]
@@ -46,7 +47,8 @@ def units(extra: Sequence[str] = ()) -> List[Tuple[str, List[str]]]:
     """(object file, command) per translation unit"""
     cc = hipcc()
     out = [(os.path.join(OBJ, "migan_hip.o"), [cc, *FLAGS, *extra, "-c", os.path.join(CSRC, "migan_hip.hip")]),
-           (os.path.join(OBJ, "migan_pipe.o"), [cc, *FLAGS, *extra, "-c", os.path.join(CSRC, "migan_pipe.hip")])]
+           (os.path.join(OBJ, "migan_pipe.o"), [cc, *FLAGS, *extra, "-c", os.path.join(CSRC, "migan_pipe.hip")]),
+           (os.path.join(OBJ, "migan_wide2.o"), [cc, *FLAGS, *extra, "-c", os.path.join(CSRC, "migan_wide2.hip")])]
     for g, s in SLICES:
         out.append((os.path.join(OBJ, f"migan_k_g{g}s{s}.o"),
                     [cc, *FLAGS, *extra, f"-DMIGAN_SLICE_G={g}", f"-DMIGAN_SLICE_S={s}", "-c", os.path.join(CSRC, "migan_k_slice.hip")]))

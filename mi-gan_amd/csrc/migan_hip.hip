@@ -4,6 +4,7 @@
 #include "migan_kernels.hpp"
 #include "migan_table.hpp"
 #include "migan_pipe.hpp"
+#include "migan_wide2.hpp"
 #include "comodgan_kernels.hpp"
 #include "migan_host.hpp"
 #include "comodgan_host.hpp"

@@ -115,6 +115,9 @@ struct Tuning {
                                // run 8 + 8 waves, fused-FromRGB and FIR-up layers 4 + 8: profiles/r04_pipe_layers.txt)
   int pipe_dna = 12;           // depthwise + FIR waves of the fused down=2 kernel: 4 or 8 (+ 8 GEMM / epilogue waves) or 12 (+ 4)
   int pipe_min_tiles = 256;    // launches with fewer tiles keep the one-tile-per-workgroup kernels
+  int w2 = 1;                  // MIGAN_W2=0|1: the 256 / 512-channel plain layers on persistent 256-pixel x 256-channel tiles (sepconv_wide2_kernel, round 5)
+                               // where a launch has at least w2_min_tiles of them (fp32 storage, f16x2 GEMM, whole 16 x 16 tiles)
+  int w2_min_tiles = 256;      // (one tile per CU; below that the 128-pixel one-tile kernel spreads the launch over more CUs)
   int pipe_min_batch = 1;      // smallest batch that takes them (1: a single-image forward runs them on its 512x512 / 256x256 layers too -- 2048 / 512 tiles;
                                // latency_b1 0.70 -> 0.66 ms; its other layers run the latency tiles, so it is not bit-identical to a batched forward either way)
 };
@@ -134,6 +137,7 @@ inline Tuning& tuning() {
     if (const char* e = std::getenv("MIGAN_STREAMS")) v.streams = std::min(4, std::max(1, std::atoi(e)));
     if (const char* e = std::getenv("MIGAN_STAGGER")) v.stagger = std::atoi(e);
     if (const char* e = std::getenv("MIGAN_PIPE")) v.pipe = std::atoi(e);
+    if (const char* e = std::getenv("MIGAN_W2")) v.w2 = std::atoi(e);
     if (const char* e = std::getenv("MIGAN_PIPE_GRID")) v.pipe_grid = std::max(8, std::atoi(e) / 8 * 8);
     return v;
   }();
@@ -343,8 +347,11 @@ inline const char*& last_kernel_ref() {
 // from batch 2 on for the layers that have an instantiation), so an image is bit-identical whatever batch >= 2 it is in.
 PipeSlice pipe_slice();
 inline bool PipeResident(const PipeEntry& e) { return (e.cin / 32) * (2 * e.NT * 64) <= 32 * 1024; }    // all weight planes of a column tile stay in LDS
-inline const PipeEntry* pick_pipe(const Geo& g, int cin, int cout, int batch, bool fused_rgb, bool u8) {
+inline const PipeEntry* pick_pipe(const Geo& g, int cin, int cout, int batch, bool fused_rgb, bool u8, bool has_skip = false) {
   const int bit = g.fromrgb ? 2 : (g.mode == MODE_UP ? 4 : 1);
+  // the plain epilogue of the pipelined kernels has no skip add (no layer of the generator needs one there: its only plain + skip layer is the
+  // 512-channel synthesis.b4.conv1); a plain SeparableConv2d with a skip tensor through migan_sepconv_forward keeps the one-tile kernels
+  if (g.mode == MODE_NORMAL && has_skip) return nullptr;
   // (pipe bit 32, experiment, off: the 256 / 512-channel plain layers -- sepconv_wide_kernel's -- as 128-column chunks of the pipelined kernel:
   // encoder.b128.conv1 0.379 -> 0.373 ms, the 512-channel layers 0.30 -> 0.37 (depthwise recomputed per chunk): profiles/LOG.md)
   const bool wide_as_chunks = g.wide && (tuning().pipe & 32) && !fused_rgb && g.mode == MODE_NORMAL;
@@ -387,6 +394,17 @@ inline const DownEntry* pick_pipedown(int cin, int cout, int h_in, int w_in, int
     if (best && best->na == na) break;
   }
   return best;
+}
+// sepconv_wide2_kernel (migan_wide2.hpp): persistent 16 x 16-pixel x 256-channel tiles for the plain layers the 128 x 256 wide tile serves, where
+// the launch fills the chip with them.  The choice depends on the batch (tiles per image: 64 at 128 x 128, 16 at 64 x 64): the two forms sum
+// a layer's K chunks in the same order with the same operand split, so an image does not depend on which one ran (tests compare them bit for bit).
+SepKernelFn wide2_fn();
+constexpr const char* kWide2Name = "migan::sepconv_wide2_kernel<0>";
+inline bool use_wide2(const Geo& g, int cin, int cout, int batch, bool fused_rgb, bool has_skip, bool u8) {
+  if (!tuning().w2 || !g.wide || g.mode != MODE_NORMAL || g.stv != 0 || g.gemmv != 2 || g.fromrgb || fused_rgb || has_skip || u8) return false;
+  const int h = g.tiles_y * 8, w = g.tiles_x * 16;               // (wide tiles are whole 8 x 16 tiles)
+  if (h % 16 != 0 || w % 16 != 0 || cin % 64 != 0 || cout % 256 != 0) return false;
+  return (h / 16) * (w / 16) * (cout / 256) * batch >= tuning().w2_min_tiles;
 }
 inline const char* kernel_name(const Geo& g);
 inline const KernelEntry& pick_kernel(const Geo& g) {
@@ -487,6 +505,7 @@ inline void prepare_kernels() {
       }
       if (sv == 0) rt_check(rt::allow_dynamic_lds((const void*)wide_fn(t != 0, 0, false, true, true), 160 * 1024), "hipFuncSetAttribute");
       if (sv == 0 && t == 0) rt_check(rt::allow_dynamic_lds((const void*)wide_up_fn(), 160 * 1024), "hipFuncSetAttribute");
+      if (sv == 0 && t == 0) rt_check(rt::allow_dynamic_lds((const void*)wide2_fn(), 160 * 1024), "hipFuncSetAttribute");
       rt_check(rt::allow_dynamic_lds((const void*)dwfir_fn(t != 0, sv), 96 * 1024), "hipFuncSetAttribute");
       if (sv) rt_check(rt::allow_dynamic_lds((const void*)dwfir_fn(t != 0, sv + 2), 96 * 1024), "hipFuncSetAttribute");
     }
@@ -565,7 +584,7 @@ inline const char* launched_kernel_name(Geo g, int cin, int cout, int batch, boo
 inline void launch_sepconv(Geo g, const SepArgs& a, rt::stream_t stream) {
   prepare_kernels();
   const bool fused_rgb = a.trgb_w != nullptr;
-  if (const PipeEntry* pe = pick_pipe(g, a.CI, a.CO, a.B, fused_rgb, a.u8_img != nullptr)) {
+  if (const PipeEntry* pe = pick_pipe(g, a.CI, a.CO, a.B, fused_rgb, a.u8_img != nullptr, a.skip != nullptr)) {
     MIGAN_CHECK(a.wsplit != nullptr, MIGAN_EINVAL, "internal: the pipelined kernel needs the fp16 weight planes");
     SepArgs ap = a;
     ap.nchunks = a.CO / pe->NT;                          // (FIR-up: 64-column chunks, see pick_pipe)
@@ -573,6 +592,16 @@ inline void launch_sepconv(Geo g, const SepArgs& a, rt::stream_t stream) {
     const unsigned grid = std::min(tiles, (unsigned)tuning().pipe_grid);
     rt_check(rt::launch(pe->fn, ap, grid, (unsigned)pipe_threads(pe->na), pe->lds_bytes, stream), pe->name);
     last_kernel_ref() = pe->name;
+    return;
+  }
+  if (use_wide2(g, a.CI, a.CO, a.B, fused_rgb, a.skip != nullptr, a.u8_img != nullptr)) {
+    MIGAN_CHECK(a.wsplit != nullptr, MIGAN_EINVAL, "internal: the 256 x 256 tile kernel needs the fp16 weight planes");
+    SepArgs aw = a;
+    aw.tiles_x = a.W / 16; aw.tiles_y = a.H / 16; aw.nchunks = a.CO / 256;
+    aw.sy = 16; aw.sx = 16; aw.off = 0;
+    const unsigned tiles = (unsigned)(aw.tiles_x * aw.tiles_y * aw.nchunks * a.B);
+    rt_check(rt::launch(wide2_fn(), aw, std::min(tiles, (unsigned)tuning().pipe_grid), (unsigned)kW2Threads, (size_t)W2Lds::TOTAL, stream), kWide2Name);
+    last_kernel_ref() = kWide2Name;
     return;
   }
   g.persist = use_persistent(g, a.B, fused_rgb);
@@ -593,6 +622,7 @@ inline void launch_sepconv(Geo g, const SepArgs& a, rt::stream_t stream) {
 
 inline const char* launched_kernel_name(Geo g, int cin, int cout, int batch, bool fused_rgb) {
   if (const PipeEntry* pe = pick_pipe(g, cin, cout, batch, fused_rgb, false)) return pe->name;
+  if (use_wide2(g, cin, cout, batch, fused_rgb, false, false)) return kWide2Name;
   g.persist = use_persistent(g, batch, fused_rgb);
   g.torgb = fused_rgb;
   return kernel_name(g);
@@ -1771,6 +1801,8 @@ int migan_set_tuning(const char* key, int value) {
   else if (k == "pipe_dna") t.pipe_dna = value;
   else if (k == "pipe_min_tiles") t.pipe_min_tiles = std::max(1, value);
   else if (k == "pipe_min_batch") t.pipe_min_batch = std::max(1, value);
+  else if (k == "w2") t.w2 = value;
+  else if (k == "w2_min_tiles") t.w2_min_tiles = std::max(1, value);
   else throw Error(MIGAN_EINVAL, "unknown tuning key: " + k);
   MIGAN_API_END
 }

@@ -98,6 +98,17 @@ __device__ __forceinline__ MIGAN_BUF migan_make_buf(const void* p, unsigned byte
 // buffer_load_dword ... lds: 4 bytes per lane, LDS destination ldsp + 4 * lane
 #define MIGAN_LDS_DMA4(buf, voff, soff, ldsp) \
   __builtin_amdgcn_raw_ptr_buffer_load_lds((buf), (__attribute__((address_space(3))) void*)(ldsp), 4, (int)(voff), (int)(soff), 0, 0)
+// the same under a lane predicate (every wave must keep at least one active lane, so that all waves of a group issue the same number of
+// vector-memory instructions and one counted s_waitcnt holds for all of them; the CPU emulator, which counts per lane, records a null
+// operation for the inactive lanes)
+#define MIGAN_LDS_DMA16_IF(cond, buf, voff, soff, ldsp) do { if (cond) MIGAN_LDS_DMA16((buf), (voff), (soff), (ldsp)); } while (0)
+#define MIGAN_LDS_DMA4_IF(cond, buf, voff, soff, ldsp) do { if (cond) MIGAN_LDS_DMA4((buf), (voff), (soff), (ldsp)); } while (0)
+// value of lane `src` (0..63, any lane function) of this wave: ds_bpermute_b32
+#define MIGAN_SHFL(v, src) __shfl((v), (src))
+// value of lane k (compile-time constant) of this wave, in a scalar register: v_readlane_b32
+#define MIGAN_READLANE(v, k) __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, (v)), (k)))
+// optimisation barrier on a wave-uniform integer (stays in a scalar register)
+#define MIGAN_OPAQUE_S(x) asm volatile("" : "+s"(x))
 
 // ---- hand-placed synchronisation of the LDS-DMA pipelines (sepconv_pipe_kernel, sepconv_wide_kernel<..., DMA>) --------------------
 // s_waitcnt vmcnt(n): at most n of this wave's vector-memory operations (LDS-DMAs, loads, stores: issue order) still outstanding.

@@ -17,6 +17,8 @@ SOURCES = [
     os.path.join(ROOT, "mi-gan_amd", "csrc", "migan_pipeline.hpp"),
     os.path.join(ROOT, "mi-gan_amd", "csrc", "migan_pipe.hpp"),
     os.path.join(ROOT, "mi-gan_amd", "csrc", "migan_pipe_table.inc"),
+    os.path.join(ROOT, "mi-gan_amd", "csrc", "migan_wide2.hpp"),
+    os.path.join(ROOT, "mi-gan_amd", "csrc", "migan_wide2_table.inc"),
     os.path.join(ROOT, "mi-gan_amd", "csrc", "migan_k_slice.inc"),
     os.path.join(ROOT, "include", "migan_hip.h"),
     os.path.join(ROOT, "mi-gan_amd", "csrc", "comodgan_kernels.hpp"),

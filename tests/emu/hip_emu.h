@@ -170,6 +170,19 @@ inline float __shfl_xor(float v, int mask) {
   return r;
 }
 
+inline float hipemu_shfl(float v, int src) {
+  hipemu::Block* b = hipemu::tl_blk;
+  const int w = b->cur >> 6, l = b->cur & 63;
+  b->xa[w][l] = v;
+  hipemu::wave_barrier();
+  const float r = b->xa[w][src & 63];
+  hipemu::wave_barrier();
+  return r;
+}
+#define MIGAN_SHFL(v, src) hipemu_shfl((v), (src))
+#define MIGAN_READLANE(v, k) hipemu_shfl((v), (k))
+#define MIGAN_OPAQUE_S(x) asm volatile("" : "+r"(x))
+
 inline bool __all(bool pred) {
   hipemu::Block* b = hipemu::tl_blk;
   const int w = b->cur >> 6, l = b->cur & 63;
@@ -318,13 +331,25 @@ inline void hipemu_lds_dma4(MIGAN_BUF b, unsigned voff, unsigned soff, float* wa
   blk->lanes[blk->cur].dma.push_back(op);
 }
 #define MIGAN_LDS_DMA4(buf, voff, soff, ldsp) hipemu_lds_dma4((buf), (voff), (soff), (ldsp))
+// predicated forms: the hardware counts vector-memory operations per WAVE, this emulator per lane -- an inactive lane records an
+// operation that writes nothing, so that a counted wait means the same on both
+inline void hipemu_lds_dma_null() {
+  hipemu::Block* blk = hipemu::tl_blk;
+  hipemu::DmaOp op;
+  op.bytes = 0;
+  op.dst = nullptr;
+  blk->lanes[blk->cur].dma.push_back(op);
+}
+#define MIGAN_LDS_DMA16_IF(cond, buf, voff, soff, ldsp) do { if (cond) hipemu_lds_dma16((buf), (voff), (soff), (ldsp)); else hipemu_lds_dma_null(); } while (0)
+#define MIGAN_LDS_DMA4_IF(cond, buf, voff, soff, ldsp) do { if (cond) hipemu_lds_dma4((buf), (voff), (soff), (ldsp)); else hipemu_lds_dma_null(); } while (0)
 inline void hipemu_wait_vmcnt(int n) {
   hipemu::Block* blk = hipemu::tl_blk;
   std::vector<hipemu::DmaOp>& q = blk->lanes[blk->cur].dma;
   const size_t keep = (size_t)(n < 0 ? 0 : n);
   if (q.size() <= keep) return;
   const size_t done = q.size() - keep;
-  for (size_t i = 0; i < done; ++i) std::memcpy(q[i].dst, q[i].data, (size_t)q[i].bytes);
+  for (size_t i = 0; i < done; ++i)
+    if (q[i].bytes) std::memcpy(q[i].dst, q[i].data, (size_t)q[i].bytes);
   q.erase(q.begin(), q.begin() + (long)done);
 }
 #define MIGAN_WAIT_VMCNT(n) hipemu_wait_vmcnt(n)

@@ -7,6 +7,8 @@
 #include "../../mi-gan_amd/csrc/migan_table.hpp"
 #include "../../mi-gan_amd/csrc/migan_pipe.hpp"
 #include "../../mi-gan_amd/csrc/migan_pipe_table.inc"
+#include "../../mi-gan_amd/csrc/migan_wide2.hpp"
+#include "../../mi-gan_amd/csrc/migan_wide2_table.inc"
 // every slice of the sepconv_kernel table (the product compiles one translation unit per slice)
 #define MIGAN_SLICE_G 0
 #define MIGAN_SLICE_S 0

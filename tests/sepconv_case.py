@@ -142,3 +142,4 @@ def run_sepconv_case(lib, pkg, mem, *, cin, cout, h, w=None, batch, down=1, up=1
         if storage != "f32":     # an activation that rounded the other way moves a pixel's RGB by one storage step x its ToRGB weight
             atol += 3.0 * float(storage_ulp(np.abs(want).max(), storage)) * float(np.abs(tw).max())
         np.testing.assert_allclose(mem.get(img_out), want_img, rtol=0, atol=atol)
+    return got

@@ -67,6 +67,14 @@ def test_fir_up_128_to_64(lib, pkg, h, w, batch, noise, skip):
     assert lib.last_kernel().startswith(PIPE + "2, 64, 128, false, false"), lib.last_kernel()
 
 
+def test_plain_layer_with_a_skip_tensor_keeps_the_one_tile_kernel(lib, pkg):
+    """the pipelined plain epilogue has no skip add: such a call through the operator ABI must not take it"""
+    run_sepconv_case(lib, pkg, HostMem(), cin=64, cout=64, h=16, w=32, batch=2, noise=True, skip=True, seed=3)
+    assert lib.last_kernel().startswith("migan::sepconv_kernel<"), lib.last_kernel()
+    run_sepconv_case(lib, pkg, HostMem(), cin=128, cout=128, h=16, w=32, batch=2, noise=True, skip=True, seed=3)
+    assert lib.last_kernel().startswith("migan::sepconv_kernel<"), lib.last_kernel()
+
+
 def test_pipe_off_takes_the_one_tile_kernels(lib, pkg):
     lib.set_tuning("pipe", 0)
     run_sepconv_case(lib, pkg, HostMem(), cin=64, cout=64, h=16, w=32, batch=2, noise=True, seed=3)

@@ -1,0 +1,72 @@
+"""sepconv_wide2_kernel (mi-gan_amd/csrc/migan_wide2.hpp: persistent 16 x 16-pixel x 256-channel tiles for the 256 / 512-channel plain
+layers) on the CPU fiber emulator, against the numpy oracle, through the C ABI entry migan_sepconv_forward.  The emulator defers every
+LDS-DMA until the issuing lane's MIGAN_WAIT_VMCNT, so a mis-counted wait of the three rings (input tiles, weight planes, taps) leaves
+NaN-poisoned LDS behind and fails these cases."""
+import importlib
+
+import numpy as np
+import pytest
+
+from tests.emu_util import emu_lib
+from tests.sepconv_case import HostMem, run_sepconv_case
+
+W2 = "migan::sepconv_wide2_kernel<0>"
+
+
+@pytest.fixture(scope="module")
+def lib():
+    return emu_lib()
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    return importlib.import_module("mi-gan_amd")
+
+
+@pytest.fixture(autouse=True)
+def small_grids(lib):
+    lib.set_tuning("w2_min_tiles", 1)
+    lib.set_tuning("pipe_grid", 8)
+    yield
+    lib.set_tuning("w2_min_tiles", 256)
+    lib.set_tuning("pipe_grid", 256)
+    lib.set_tuning("w2", 1)
+
+
+# 8 workgroups: 1, 2 or 3 tiles each (first / steady-state / last tile), border and interior tiles, one and two column chunks
+@pytest.mark.parametrize("cin,cout,h,w,batch", [(256, 256, 16, 16, 2), (256, 256, 32, 48, 2), (512, 512, 16, 32, 3), (64, 256, 48, 48, 1),
+                                                (256, 512, 16, 16, 5)])
+@pytest.mark.parametrize("noise", [False, True])
+def test_plain_layers(lib, pkg, cin, cout, h, w, batch, noise):
+    run_sepconv_case(lib, pkg, HostMem(), cin=cin, cout=cout, h=h, w=w, batch=batch, noise=noise, seed=23)
+    assert lib.last_kernel() == W2, lib.last_kernel()
+
+
+def test_off_or_too_few_tiles_keeps_the_128_pixel_tile(lib, pkg):
+    lib.set_tuning("w2", 0)
+    run_sepconv_case(lib, pkg, HostMem(), cin=256, cout=256, h=16, w=16, batch=2, noise=True, seed=23)
+    assert lib.last_kernel().startswith("migan::sepconv_wide_kernel<"), lib.last_kernel()
+    lib.set_tuning("w2", 1)
+    lib.set_tuning("w2_min_tiles", 256)
+    run_sepconv_case(lib, pkg, HostMem(), cin=256, cout=256, h=16, w=16, batch=2, noise=True, seed=23)
+    assert lib.last_kernel().startswith("migan::sepconv_wide_kernel<"), lib.last_kernel()
+
+
+def test_not_for_ragged_sizes_skip_or_torgb(lib, pkg):
+    run_sepconv_case(lib, pkg, HostMem(), cin=256, cout=256, h=24, w=16, batch=2, seed=23)          # 24 rows: no whole 16 x 16 tiles
+    assert lib.last_kernel().startswith("migan::sepconv_wide_kernel<"), lib.last_kernel()
+    run_sepconv_case(lib, pkg, HostMem(), cin=256, cout=256, h=16, w=16, batch=2, skip=True, seed=23)
+    assert lib.last_kernel().startswith("migan::sepconv_wide_kernel<"), lib.last_kernel()
+    run_sepconv_case(lib, pkg, HostMem(), cin=256, cout=256, h=16, w=16, batch=2, noise=True, torgb=True, with_prev=True, seed=23)
+    assert lib.last_kernel() != W2, lib.last_kernel()
+
+
+@pytest.mark.parametrize("cin,cout,h,w", [(256, 256, 32, 32), (512, 512, 16, 16)])
+def test_bit_identical_to_the_128_pixel_tile(lib, pkg, cin, cout, h, w):
+    """same operand split, same order of the K chunks and of the three products: which tile form ran must not be visible in the result"""
+    a = run_sepconv_case(lib, pkg, HostMem(), cin=cin, cout=cout, h=h, w=w, batch=2, noise=True, seed=29)
+    assert lib.last_kernel() == W2
+    lib.set_tuning("w2", 0)
+    b = run_sepconv_case(lib, pkg, HostMem(), cin=cin, cout=cout, h=h, w=w, batch=2, noise=True, seed=29)
+    assert lib.last_kernel().startswith("migan::sepconv_wide_kernel<")
+    assert np.array_equal(a, b)

@@ -55,6 +55,12 @@ def test_plain(lib, pkg, dev, h, w, batch, grid, noise):
     assert lib.last_kernel().startswith(PIPE + "0, 64, 64, false, false"), lib.last_kernel()
 
 
+def test_plain_layer_with_a_skip_tensor_keeps_the_one_tile_kernel(lib, pkg, dev):
+    """the pipelined plain epilogue has no skip add: default tuning, enough tiles for the pipelined form"""
+    run_sepconv_case(lib, pkg, CudaMem(dev), cin=64, cout=64, h=64, w=64, batch=8, noise=True, skip=True, seed=3)
+    assert lib.last_kernel().startswith("migan::sepconv_kernel<"), lib.last_kernel()
+
+
 @pytest.mark.parametrize("h,w,batch,grid", GRIDS)
 @pytest.mark.parametrize("prev", [False, True])
 def test_plain_with_fused_torgb(lib, pkg, dev, h, w, batch, grid, prev):

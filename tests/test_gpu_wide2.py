@@ -1,0 +1,62 @@
+"""sepconv_wide2_kernel (persistent 16 x 16-pixel x 256-channel tiles, mi-gan_amd/csrc/migan_wide2.hpp) on the MI355X, through the C ABI
+entry migan_sepconv_forward: against the numpy oracle at the layer sizes of migan-512 / migan-256, and bit for bit against the
+128-pixel tile kernel it replaces (same operand split, same summation order)."""
+import numpy as np
+import pytest
+
+from tests.sepconv_case import CudaMem, run_sepconv_case
+
+pytestmark = pytest.mark.gpu
+W2 = "migan::sepconv_wide2_kernel<0>"
+
+
+@pytest.fixture(scope="module")
+def lib(pkg):
+    return pkg.load_library()
+
+
+@pytest.fixture(scope="module")
+def mem():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("gpu tests need an MI355X (torch.cuda.is_available() is False)")
+    return CudaMem(torch.device("cuda", 0))
+
+
+@pytest.fixture(autouse=True)
+def restore(lib):
+    yield
+    lib.set_tuning("w2", 1)
+    lib.set_tuning("w2_min_tiles", 256)
+    lib.set_tuning("pipe_grid", 256)
+
+
+# (cin, cout, h, w, batch): encoder.b128.conv1 / synthesis.b64.conv2 / encoder.b32.conv1 of migan-512 at batch 4..32, a non-square size,
+# a launch with fewer tiles than workgroups and one where the workgroups walk 1..3 tiles each
+@pytest.mark.parametrize("cin,cout,h,w,batch", [(256, 256, 128, 128, 4), (512, 512, 64, 64, 8), (512, 512, 32, 32, 32), (256, 512, 48, 80, 3),
+                                                (256, 256, 64, 64, 9)])
+@pytest.mark.parametrize("noise", [False, True])
+def test_plain_layers(lib, pkg, mem, cin, cout, h, w, batch, noise):
+    lib.set_tuning("w2_min_tiles", 1)
+    run_sepconv_case(lib, pkg, mem, cin=cin, cout=cout, h=h, w=w, batch=batch, noise=noise, seed=31)
+    assert lib.last_kernel() == W2, lib.last_kernel()
+
+
+@pytest.mark.parametrize("grid", [8, 64, 256])
+def test_any_number_of_tiles_per_workgroup(lib, pkg, mem, grid):
+    lib.set_tuning("w2_min_tiles", 1)
+    lib.set_tuning("pipe_grid", grid)
+    run_sepconv_case(lib, pkg, mem, cin=256, cout=256, h=64, w=64, batch=5, noise=True, seed=33)
+    assert lib.last_kernel() == W2, lib.last_kernel()
+
+
+@pytest.mark.parametrize("cin,cout,h,batch", [(256, 256, 128, 8), (512, 512, 64, 16)])
+def test_bit_identical_to_the_128_pixel_tile_and_run_to_run(lib, pkg, mem, cin, cout, h, batch):
+    a = run_sepconv_case(lib, pkg, mem, cin=cin, cout=cout, h=h, w=h, batch=batch, noise=True, seed=35)
+    assert lib.last_kernel() == W2, lib.last_kernel()
+    a2 = run_sepconv_case(lib, pkg, mem, cin=cin, cout=cout, h=h, w=h, batch=batch, noise=True, seed=35)
+    assert np.array_equal(a, a2)
+    lib.set_tuning("w2", 0)
+    b = run_sepconv_case(lib, pkg, mem, cin=cin, cout=cout, h=h, w=h, batch=batch, noise=True, seed=35)
+    assert lib.last_kernel().startswith("migan::sepconv_wide_kernel<"), lib.last_kernel()
+    assert np.array_equal(a, b)

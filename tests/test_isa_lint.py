@@ -123,3 +123,15 @@ def test_pipelined_kernels_fit_their_workgroup(tmp_path):
             waves = targs[-1] + 8 if table is pipe else targs[-2] + targs[-1]
             cap = 168 if waves == 12 else 128
             assert v["vgpr_count"] + v["agpr_count"] <= cap and v["private_segment_fixed_size"] == 0 and v["vgpr_spill_count"] == 0, (targs, v)
+
+
+@pytest.mark.skipif(not os.path.exists(f"{LLVM}/llvm-readelf"), reason="needs the ROCm LLVM tools")
+def test_wide2_kernel_fits_its_workgroup(tmp_path):
+    """sepconv_wide2_kernel: one 12-wave workgroup per CU, 128 accumulator registers per MFMA wave -- it must stay inside the 168
+    registers three waves per SIMD leave, without scratch (the first form spilled 200 registers around the accumulator blocks)."""
+    pkg = importlib.import_module("mi-gan_amd")
+    res = kernel_resources(pkg.library_path(), str(tmp_path))
+    w2 = {k: v for k, v in res.items() if "sepconv_wide2_kernel" in k}
+    assert len(w2) >= 1
+    for k, v in w2.items():
+        assert v["vgpr_count"] + v["agpr_count"] <= 168 and v["private_segment_fixed_size"] == 0 and v["vgpr_spill_count"] == 0, (k, v)
