@@ -398,8 +398,12 @@ inline const DownEntry* pick_pipedown(int cin, int cout, int h_in, int w_in, int
 // sepconv_wide2_kernel (migan_wide2.hpp): persistent 16 x 16-pixel x 256-channel tiles for the plain layers the 128 x 256 wide tile serves, where
 // the launch fills the chip with them.  The choice depends on the batch (tiles per image: 64 at 128 x 128, 16 at 64 x 64): the two forms sum
 // a layer's K chunks in the same order with the same operand split, so an image does not depend on which one ran (tests compare them bit for bit).
-SepKernelFn wide2_fn();
-constexpr const char* kWide2Name = "migan::sepconv_wide2_kernel<0>";
+SepKernelFn wide2_fn(int variant);
+inline int wide2_variant() { return (tuning().w2 - 1) & 3; }      // tuning().w2 = 1 + variant (bit 0: 16-byte stores after a quad transpose; bit 1: plain instead of nontemporal stores)
+inline const char* wide2_name() {
+  static const char* n[4] = {"migan::sepconv_wide2_kernel<0>", "migan::sepconv_wide2_kernel<1>", "migan::sepconv_wide2_kernel<2>", "migan::sepconv_wide2_kernel<3>"};
+  return n[wide2_variant()];
+}
 inline bool use_wide2(const Geo& g, int cin, int cout, int batch, bool fused_rgb, bool has_skip, bool u8) {
   if (!tuning().w2 || !g.wide || g.mode != MODE_NORMAL || g.stv != 0 || g.gemmv != 2 || g.fromrgb || fused_rgb || has_skip || u8) return false;
   const int h = g.tiles_y * 8, w = g.tiles_x * 16;               // (wide tiles are whole 8 x 16 tiles)
@@ -505,7 +509,8 @@ inline void prepare_kernels() {
       }
       if (sv == 0) rt_check(rt::allow_dynamic_lds((const void*)wide_fn(t != 0, 0, false, true, true), 160 * 1024), "hipFuncSetAttribute");
       if (sv == 0 && t == 0) rt_check(rt::allow_dynamic_lds((const void*)wide_up_fn(), 160 * 1024), "hipFuncSetAttribute");
-      if (sv == 0 && t == 0) rt_check(rt::allow_dynamic_lds((const void*)wide2_fn(), 160 * 1024), "hipFuncSetAttribute");
+      if (sv == 0 && t == 0)
+        for (int v = 0; v < 4; ++v) rt_check(rt::allow_dynamic_lds((const void*)wide2_fn(v), 160 * 1024), "hipFuncSetAttribute");
       rt_check(rt::allow_dynamic_lds((const void*)dwfir_fn(t != 0, sv), 96 * 1024), "hipFuncSetAttribute");
       if (sv) rt_check(rt::allow_dynamic_lds((const void*)dwfir_fn(t != 0, sv + 2), 96 * 1024), "hipFuncSetAttribute");
     }
@@ -600,8 +605,8 @@ inline void launch_sepconv(Geo g, const SepArgs& a, rt::stream_t stream) {
     aw.tiles_x = a.W / 16; aw.tiles_y = a.H / 16; aw.nchunks = a.CO / 256;
     aw.sy = 16; aw.sx = 16; aw.off = 0;
     const unsigned tiles = (unsigned)(aw.tiles_x * aw.tiles_y * aw.nchunks * a.B);
-    rt_check(rt::launch(wide2_fn(), aw, std::min(tiles, (unsigned)tuning().pipe_grid), (unsigned)kW2Threads, (size_t)W2Lds::TOTAL, stream), kWide2Name);
-    last_kernel_ref() = kWide2Name;
+    rt_check(rt::launch(wide2_fn(wide2_variant()), aw, std::min(tiles, (unsigned)tuning().pipe_grid), (unsigned)kW2Threads, (size_t)W2Lds::TOTAL, stream), wide2_name());
+    last_kernel_ref() = wide2_name();
     return;
   }
   g.persist = use_persistent(g, a.B, fused_rgb);
@@ -622,7 +627,7 @@ inline void launch_sepconv(Geo g, const SepArgs& a, rt::stream_t stream) {
 
 inline const char* launched_kernel_name(Geo g, int cin, int cout, int batch, bool fused_rgb) {
   if (const PipeEntry* pe = pick_pipe(g, cin, cout, batch, fused_rgb, false)) return pe->name;
-  if (use_wide2(g, cin, cout, batch, fused_rgb, false, false)) return kWide2Name;
+  if (use_wide2(g, cin, cout, batch, fused_rgb, false, false)) return wide2_name();
   g.persist = use_persistent(g, batch, fused_rgb);
   g.torgb = fused_rgb;
   return kernel_name(g);

@@ -4,5 +4,6 @@
 #define MIGAN_TEMPLATE_KERNELS_ONLY
 #include "migan_kernels.hpp"
 #include "migan_table.hpp"
+#include "migan_pipe.hpp"
 #include "migan_wide2.hpp"
 #include "migan_wide2_table.inc"

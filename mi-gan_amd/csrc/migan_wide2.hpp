@@ -45,7 +45,9 @@ MIGAN_DEVICE MIGAN_INLINE float act1g(float v, float gain) {      // act1 with t
   return MIGAN_CLAMP(t, -256.0f, 256.0f);
 }
 
-// V: variant (0 = plain layer; a template so that the translation units that only need W2Lds do not emit the kernel)
+// V: epilogue variant -- bit 0: 16-byte stores (4 x 4 transposes among the quads of lanes: 32 store instructions per wave and tile instead of
+// 128, i.e. fewer than the 63 the vmcnt counter can hold, so a wave is never held at the counter and the stores drain under the next tile);
+// bit 1: plain instead of nontemporal stores.  (A template also so that translation units that only need W2Lds do not emit the kernel.)
 template <int V>
 MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(kW2Threads, 3) sepconv_wide2_kernel(const SepArgs p) {
   typedef W2Lds L;
@@ -71,6 +73,9 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(kW2Threads, 3) sepconv_wide2_kernel(const 
   const int T = tl0 < tcnt ? (tcnt - tl0 + tstep - 1) / tstep : 0;    // my tiles
   if (T == 0) return;                                                  // (uniform: the whole workgroup leaves)
   const int G = T * nks;                                               // my sub-steps
+  // phase profile (-DMIGAN_PHASE_PROF builds): group A -> slots 0..3 [DMA issue, depthwise, vmcnt wait, barrier], group B -> 4 MFMAs (with their
+  // fragment reads), 5 epilogue, 6 barrier; slot 8 counts workgroups
+  PPROF_BEGIN();
   struct TileCur {
     int n, x, y, b;
   };
@@ -260,12 +265,17 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(kW2Threads, 3) sepconv_wide2_kernel(const 
       // depthwise stage of sub-step g + 1
       const bool more = g + 3 < G;
       issue();                                             // sub-step g + 3
+      PPROF_MARK(0);
       if (g + 1 < G) depthwise(dslot, dtap, (g + 1) & 1);
+      PPROF_MARK(1);
       dslot = dslot + 1 == L::R_IN ? 0 : dslot + 1;
       dtap = dtap + 1 == L::R_T ? 0 : dtap + 1;
       if (more) MIGAN_WAIT_VMCNT(16); else MIGAN_WAIT_VMCNT(0);
+      PPROF_MARK(2);
       MIGAN_BARRIER_LDS();
+      PPROF_MARK(3);
     }
+    PPROF_END(AT);
     return;
   }
 
@@ -323,6 +333,14 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(kW2Threads, 3) sepconv_wide2_kernel(const 
   auto request_noise = [&]() {
     if (has_noise) nzl = p.noise[(unsigned)((ctc.y * 16 + wm * 4 + (lane >> 4)) * p.W + ctc.x * 16 + (lane & 15))];
   };
+  auto store1 = [&](float* q, float v) {
+    if constexpr ((V & 2) != 0) *q = v; else MIGAN_STORE_NT(q, v);
+  };
+  auto store4 = [&](float* q, f4 v) {
+    if constexpr ((V & 2) != 0) *reinterpret_cast<f4*>(q) = v; else MIGAN_STORE_NT(reinterpret_cast<f4*>(q), v);
+  };
+  const bool odd1 = (lane & 1) != 0, odd2 = (lane & 2) != 0;
+  const unsigned lane_off4 = (unsigned)(((lane & 3) + 4 * half) * p.CO + wn * 128 + (l31 & ~3)) * 4u;
   auto epilogue = [&](auto hn_) {
     constexpr bool HN = decltype(hn_)::value;
     // (opaque copies: the 32 row addresses below are functions of W and CO only -- left visible, the compiler hoists all of them out of the
@@ -332,6 +350,41 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(kW2Threads, 3) sepconv_wide2_kernel(const 
     const size_t px_bytes = (size_t)CO_ * 4;
     const char* yt = reinterpret_cast<char*>(p.y) + (size_t)ctc.b * img_out_bytes +
                      ((size_t)((ctc.y * 16 + wm * 4) * W_ + ctc.x * 16) * (size_t)CO_ + (size_t)(ctc.n * 256)) * 4;
+    if constexpr ((V & 1) != 0) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          // registers 4 k .. 4 k + 3 of a block: rows 8 k + 4 half + {0, 1, 2, 3} of the 32-row block (tile row 2 i + (k >> 1), columns
+          // 8 (k & 1) + 4 half + t), column l31.  After the transpose lane (lane & 3) = t holds row t, columns (l31 & ~3) .. + 3.
+          float nsn[4] = {0.f, 0.f, 0.f, 0.f};
+          if constexpr (HN) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+              const float nlo = MIGAN_READLANE(nzl, i * 32 + 8 * k + t), nhi = MIGAN_READLANE(nzl, i * 32 + 8 * k + t + 4);
+              nsn[t] = MIGAN_FMUL_RN(half ? nhi : nlo, ns);
+            }
+          }
+          char* yr = const_cast<char*>(yt) + (size_t)((2 * i + (k >> 1)) * W_ + 8 * (k & 1)) * px_bytes;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            float a[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+              const float v = acc[i][j][4 * k + t];
+              if constexpr (HN) a[t] = act1(v * acc_scale + nsn[t]);
+              else a[t] = act1g(v, gain_s);
+            }
+            // 4 x 4 transpose over (register t, lane & 3): bit 0, then bit 1
+            const float x0 = MIGAN_QUAD_XOR1(a[0]), x1 = MIGAN_QUAD_XOR1(a[1]), x2 = MIGAN_QUAD_XOR1(a[2]), x3 = MIGAN_QUAD_XOR1(a[3]);
+            const float b0 = odd1 ? x1 : a[0], b1 = odd1 ? a[1] : x0, b2 = odd1 ? x3 : a[2], b3 = odd1 ? a[3] : x2;
+            const float y0 = MIGAN_QUAD_XOR2(b0), y1 = MIGAN_QUAD_XOR2(b1), y2 = MIGAN_QUAD_XOR2(b2), y3 = MIGAN_QUAD_XOR2(b3);
+            const f4 o = {odd2 ? y2 : b0, odd2 ? y3 : b1, odd2 ? b2 : y0, odd2 ? b3 : y1};
+            if (!MIGAN_ABL(1)) store4(at_bytes(reinterpret_cast<float*>(yr + j * 128), lane_off4), o);
+          }
+        }
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -348,7 +401,7 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(kW2Threads, 3) sepconv_wide2_kernel(const 
           float v = acc[i][j][r];
           if constexpr (HN) v = act1(v * acc_scale + nsn);
           else v = act1g(v, gain_s);
-          if (!MIGAN_ABL(1)) MIGAN_STORE_NT(at_bytes(reinterpret_cast<float*>(yr + j * 128), lane_off), v);
+          if (!MIGAN_ABL(1)) store1(at_bytes(reinterpret_cast<float*>(yr + j * 128), lane_off), v);
         }
       }
   };
@@ -359,21 +412,31 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(kW2Threads, 3) sepconv_wide2_kernel(const 
   for (int t = 0; t < T; ++t) {
     for (int c = 0; c < nks; c += 4) {
       mfma_step(0, 0);
+      PPROF_MARK(4);
       MIGAN_BARRIER_LDS();
+      PPROF_MARK(6);
       mfma_step(1, 1);
+      PPROF_MARK(4);
       MIGAN_BARRIER_LDS();
+      PPROF_MARK(6);
       if (c + 4 == nks) request_noise();                        // (one interval ahead of its use)
       mfma_step(0, 2);
+      PPROF_MARK(4);
       MIGAN_BARRIER_LDS();
+      PPROF_MARK(6);
       mfma_step(1, 3);
+      PPROF_MARK(4);
       if (c + 4 == nks) {
         if (!MIGAN_ABL(2)) { if (has_noise) epilogue(TrueT{}); else epilogue(FalseT{}); }
         zero_acc();
         if (t + 1 < T) tile_next(ctc);
+        PPROF_MARK(5);
       }
       MIGAN_BARRIER_LDS();
+      PPROF_MARK(6);
     }
   }
+  PPROF_END(AT);
 }
 
 }  // namespace migan

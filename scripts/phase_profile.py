@@ -39,6 +39,11 @@ for i, (L, t) in enumerate(zip(launches, ms)):
     if lib.migan_prof_layer(i, out) != 0:
         continue
     n = max(1, out[8])
+    if "wide2" in L["kernel"]:
+        cyc = [out[k] / n / 1000.0 for k in range(16)]
+        print(f"{L['layer']:26s} {t:8.3f} {out[8]:7d}  wide2 kcycles/WG A[issue {cyc[0]:.1f} depthwise {cyc[1]:.1f} vmcnt {cyc[2]:.1f} barrier {cyc[3]:.1f}]"
+              f" B[mfma {cyc[4]:.1f} epilogue {cyc[5]:.1f} barrier {cyc[6]:.1f}]")
+        continue
     if "pipe" in L["kernel"]:
         cyc = [out[k] / n / 1000.0 for k in range(16)]
         print(f"{L['layer']:26s} {t:8.3f} {out[8]:7d}  pipe kcycles/WG A[issue {cyc[0]:.0f} depthwise {cyc[1]:.0f} vmcnt {cyc[2]:.0f} barrier {cyc[3]:.0f}]"

@@ -7,7 +7,7 @@ import pytest
 from tests.sepconv_case import CudaMem, run_sepconv_case
 
 pytestmark = pytest.mark.gpu
-W2 = "migan::sepconv_wide2_kernel<0>"
+W2 = "migan::sepconv_wide2_kernel<"
 
 
 @pytest.fixture(scope="module")
@@ -23,10 +23,13 @@ def mem():
     return CudaMem(torch.device("cuda", 0))
 
 
-@pytest.fixture(autouse=True)
-def restore(lib):
+# epilogue variants (tuning w2 = 1 + variant): dword stores / 16-byte stores after a quad transpose, nontemporal / plain
+@pytest.fixture(autouse=True, params=[1, 2, 3, 4])
+def restore(request, lib):
+    default = lib.get_tuning("w2") if hasattr(lib, "get_tuning") else 1
+    lib.set_tuning("w2", request.param)
     yield
-    lib.set_tuning("w2", 1)
+    lib.set_tuning("w2", default)
     lib.set_tuning("w2_min_tiles", 256)
     lib.set_tuning("pipe_grid", 256)
 
@@ -39,7 +42,7 @@ def restore(lib):
 def test_plain_layers(lib, pkg, mem, cin, cout, h, w, batch, noise):
     lib.set_tuning("w2_min_tiles", 1)
     run_sepconv_case(lib, pkg, mem, cin=cin, cout=cout, h=h, w=w, batch=batch, noise=noise, seed=31)
-    assert lib.last_kernel() == W2, lib.last_kernel()
+    assert lib.last_kernel().startswith(W2), lib.last_kernel()
 
 
 @pytest.mark.parametrize("grid", [8, 64, 256])
@@ -47,13 +50,13 @@ def test_any_number_of_tiles_per_workgroup(lib, pkg, mem, grid):
     lib.set_tuning("w2_min_tiles", 1)
     lib.set_tuning("pipe_grid", grid)
     run_sepconv_case(lib, pkg, mem, cin=256, cout=256, h=64, w=64, batch=5, noise=True, seed=33)
-    assert lib.last_kernel() == W2, lib.last_kernel()
+    assert lib.last_kernel().startswith(W2), lib.last_kernel()
 
 
 @pytest.mark.parametrize("cin,cout,h,batch", [(256, 256, 128, 8), (512, 512, 64, 16)])
 def test_bit_identical_to_the_128_pixel_tile_and_run_to_run(lib, pkg, mem, cin, cout, h, batch):
     a = run_sepconv_case(lib, pkg, mem, cin=cin, cout=cout, h=h, w=h, batch=batch, noise=True, seed=35)
-    assert lib.last_kernel() == W2, lib.last_kernel()
+    assert lib.last_kernel().startswith(W2), lib.last_kernel()
     a2 = run_sepconv_case(lib, pkg, mem, cin=cin, cout=cout, h=h, w=h, batch=batch, noise=True, seed=35)
     assert np.array_equal(a, a2)
     lib.set_tuning("w2", 0)
