@@ -399,10 +399,20 @@ inline const DownEntry* pick_pipedown(int cin, int cout, int h_in, int w_in, int
 // the launch fills the chip with them.  The choice depends on the batch (tiles per image: 64 at 128 x 128, 16 at 64 x 64): the two forms sum
 // a layer's K chunks in the same order with the same operand split, so an image does not depend on which one ran (tests compare them bit for bit).
 SepKernelFn wide2_fn(int variant);
-inline int wide2_variant() { return (tuning().w2 - 1) & 3; }      // tuning().w2 = 1 + variant (bit 0: 16-byte stores after a quad transpose; bit 1: plain instead of nontemporal stores)
+// tuning().w2 = 1 + variant: bit 0 = 16-byte stores after a quad transpose, bit 2 = loader-wave form of group A, bit 3 = DMA lookahead of two
+// sub-steps instead of three (variants 0, 1, 4, 8, 9 exist)
+inline int wide2_variant() {
+  const int v = (tuning().w2 - 1) & 15;
+  return (v == 1 || v == 4 || v == 8 || v == 9) ? v : 0;
+}
 inline const char* wide2_name() {
-  static const char* n[4] = {"migan::sepconv_wide2_kernel<0>", "migan::sepconv_wide2_kernel<1>", "migan::sepconv_wide2_kernel<2>", "migan::sepconv_wide2_kernel<3>"};
-  return n[wide2_variant()];
+  switch (wide2_variant()) {
+    case 1: return "migan::sepconv_wide2_kernel<1>";
+    case 4: return "migan::sepconv_wide2_kernel<4>";
+    case 8: return "migan::sepconv_wide2_kernel<8>";
+    case 9: return "migan::sepconv_wide2_kernel<9>";
+    default: return "migan::sepconv_wide2_kernel<0>";
+  }
 }
 inline bool use_wide2(const Geo& g, int cin, int cout, int batch, bool fused_rgb, bool has_skip, bool u8) {
   if (!tuning().w2 || !g.wide || g.mode != MODE_NORMAL || g.stv != 0 || g.gemmv != 2 || g.fromrgb || fused_rgb || has_skip || u8) return false;
@@ -510,7 +520,7 @@ inline void prepare_kernels() {
       if (sv == 0) rt_check(rt::allow_dynamic_lds((const void*)wide_fn(t != 0, 0, false, true, true), 160 * 1024), "hipFuncSetAttribute");
       if (sv == 0 && t == 0) rt_check(rt::allow_dynamic_lds((const void*)wide_up_fn(), 160 * 1024), "hipFuncSetAttribute");
       if (sv == 0 && t == 0)
-        for (int v = 0; v < 4; ++v) rt_check(rt::allow_dynamic_lds((const void*)wide2_fn(v), 160 * 1024), "hipFuncSetAttribute");
+        for (int v : {0, 1, 4, 8, 9}) rt_check(rt::allow_dynamic_lds((const void*)wide2_fn(v), 160 * 1024), "hipFuncSetAttribute");
       rt_check(rt::allow_dynamic_lds((const void*)dwfir_fn(t != 0, sv), 96 * 1024), "hipFuncSetAttribute");
       if (sv) rt_check(rt::allow_dynamic_lds((const void*)dwfir_fn(t != 0, sv + 2), 96 * 1024), "hipFuncSetAttribute");
     }

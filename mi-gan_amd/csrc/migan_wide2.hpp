@@ -39,6 +39,8 @@ struct W2Lds {
   static_assert(TOTAL <= 160 * 1024, "LDS budget");
 };
 
+template <int N> struct W2Int { static constexpr int value = N; };
+
 MIGAN_DEVICE MIGAN_INLINE float act1g(float v, float gain) {      // act1 with the gain pre-multiplied by a power of two (see act4g)
   float t = fmaxf(v, v * 0.2f);
   t = t * gain;
@@ -101,9 +103,166 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(kW2Threads, 3) sepconv_wide2_kernel(const 
     c.b += st_b + carry;
   };
 
+  if constexpr ((V & 4) != 0) {
+  if (groupA) {
+    // ======================= group A, loader-wave form: wave 3 issues EVERY DMA (and runs one depthwise row), waves 0..2 five rows each ==========
+    // The phase profile of the first form (profiles/r05_wide2.md) has a group-A wave 1.5k cycles per sub-step inside its twelve DMA instructions:
+    // the input tiles stream from HBM at the chip's 6.2 TB/s = 11.7 B/clk per CU, the queue of the CU's memory pipeline is full, and a wave
+    // that issues into a full queue waits -- in order -- for HBM before it may run its depthwise rows (1.6k cycles).  Here the wave that waits
+    // for HBM is a different one from those that compute: 41 DMA instructions per sub-step (21 input, 4 taps, 16 weight planes; at most 57 in
+    // flight at a counted wait, under the 63 of the vmcnt counter) on wave 3, which otherwise only has row 15 of the tile to do.
+    const bool loader = wave_u == 3;
+    // ---- input tile: unit u = 64 j + lane (j = 0..20, the last with 16 lanes) = halo pixel u >> 2, channel quad u & 3 ----
+    unsigned dgoff[21], tile_soff = 0;
+    auto make_dgoff = [&](int gy0_, int gx0_) {
+      const bool interior = gy0_ >= 1 && gy0_ + 17 <= p.H && gx0_ >= 1 && gx0_ + 17 <= p.W;
+      tile_soff = interior ? (unsigned)(((gy0_ - 1) * p.W + (gx0_ - 1)) * CI) * 4u : 0u;
+      const int oy = interior ? 0 : gy0_ - 1, ox = interior ? 0 : gx0_ - 1;
+#pragma unroll
+      for (int j = 0; j < 21; ++j) {
+        const int i = j * 64 + lane;
+        unsigned g = 0xfffff000u;
+        if (i < NITEMS) {
+          const int c4 = i & 3, pix = i >> 2;
+          const int yy = oy + pix / IGW, xx = ox + pix % IGW;
+          if (interior || (yy >= 0 && yy < p.H && xx >= 0 && xx < p.W)) g = (unsigned)((yy * p.W + xx) * CI + c4 * 4) * 4u;
+        }
+        dgoff[j] = g;
+      }
+    };
+    const unsigned img_bytes = (unsigned)(p.H * p.W * CI) * 4u;
+    const MIGAN_BUF tbuf = MIGAN_MAKE_BUF(p.wdw, (unsigned)(CI * 9) * 4u);
+    const MIGAN_BUF bbuf = MIGAN_MAKE_BUF(p.bdw, (unsigned)CI * 4u);
+    const MIGAN_BUF wbuf = MIGAN_MAKE_BUF(p.wsplit, (unsigned)(2 * p.CO * CI) * 2u);
+    const unsigned tap_voff = (unsigned)((lane & 15) * 9 + (lane >> 4)) * 4u;          // unit 64 k + lane = tap 4 k + (lane >> 4), channel lane & 15
+    const unsigned b_voff = (unsigned)((lane >> 1) * 32 + (((lane & 1) ^ ((lane >> 4) & 1)) * 8)) * 2u;     // unit 64 j + lane: row 32 (j & 7) + (lane >> 1), slot lane & 1
+    const unsigned plane_bytes = (unsigned)(p.CO * CI) * 2u;
+    int is = 0, ic = 0, ik = 0, islot = 0, tslot = 0;
+    TileCur itc = tile0;
+    int in0 = itc.n * 256, ib0 = itc.b;
+    if (loader) make_dgoff(itc.y * 16, itc.x * 16);
+    auto issue = [&]() {                                   // everything of the sub-step at the cursor: input (21), taps (4), weight planes (16)
+      if (is >= G) return;
+      {
+        float* in_s = reinterpret_cast<float*>(lds + L::OFF_IN + islot * L::IN_SLOT);
+        const MIGAN_BUF xbuf = MIGAN_MAKE_BUF(reinterpret_cast<const char*>(p.x) + (size_t)ib0 * img_bytes, img_bytes);
+        const unsigned soff = tile_soff + (unsigned)(ic * KS) * 4u;
+        if (!MIGAN_ABL(16)) {
+#pragma unroll
+          for (int j = 0; j < 20; ++j) MIGAN_LDS_DMA16(xbuf, dgoff[j], soff, in_s + j * 256);
+          MIGAN_LDS_DMA16_IF(lane < 16, xbuf, dgoff[20], soff, in_s + 20 * 256);
+        }
+      }
+      {
+        float* w_s = reinterpret_cast<float*>(lds + L::OFF_W + tslot * L::TAP_SLOT);
+        const unsigned soff = (unsigned)(ic * KS * 9) * 4u;
+        MIGAN_LDS_DMA4(tbuf, tap_voff, soff, w_s);
+        MIGAN_LDS_DMA4(tbuf, tap_voff + 16u, soff, w_s + 64);
+        MIGAN_LDS_DMA4_IF(lane < 16, tbuf, tap_voff + 32u, soff, w_s + 128);
+        MIGAN_LDS_DMA4_IF(lane < 16, bbuf, (unsigned)lane * 4u, (unsigned)(ic * KS) * 4u, w_s + 144);
+      }
+      if (!MIGAN_ABL(32)) {
+        float* bb = reinterpret_cast<float*>(lds + L::OFF_B + (is & 3) * L::B_SLOT);
+        const unsigned soff = (unsigned)(((ic >> 1) * p.CO + in0) * 32 + (ic & 1) * 16) * 2u;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) MIGAN_LDS_DMA16(wbuf, b_voff, soff + (unsigned)(j >> 3) * plane_bytes + (unsigned)((j & 7) * 32 * 32) * 2u, bb + j * 256);
+      }
+      ++is;
+      islot = islot + 1 == L::R_IN ? 0 : islot + 1;
+      tslot = tslot + 1 == L::R_T ? 0 : tslot + 1;
+      if (++ic == nks) {
+        ic = 0;
+        if (++ik < T) {
+          tile_next(itc);
+          in0 = itc.n * 256; ib0 = itc.b;
+          make_dgoff(itc.y * 16, itc.x * 16);
+        }
+      }
+    };
+    // ---- depthwise 3x3 + bias + act (x 2^7) + fp16 hi/lo split: SEGH rows x 4 channels per thread (a wave = 16 columns x 4 channel quads) ----
+    auto depthwise = [&](int slot, int dtslot, int abuf, int r0, auto segh_) {
+      constexpr int SEGH = decltype(segh_)::value;
+      if (MIGAN_ABL(4)) return;
+      const float* in_s = reinterpret_cast<const float*>(lds + L::OFF_IN + slot * L::IN_SLOT);
+      const float* wc = reinterpret_cast<const float*>(lds + L::OFF_W + dtslot * L::TAP_SLOT);
+      char* a_b = lds + L::OFF_A + abuf * L::A_BUF;
+      const int c4 = lane & 3;
+      const int gx = lane >> 2;
+      f4 w[9];
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) w[tap] = ld4(wc + tap * KS + c4 * 4);
+      const f4 bias = ld4(wc + 144 + c4 * 4);
+      const float* ip = in_s + (r0 * IGW + gx) * KS + c4 * 4;
+      f4 win[3][3], nxt[3];
+#pragma unroll
+      for (int rr = 0; rr < 2; ++rr) {
+        win[rr][0] = ld4(ip); win[rr][1] = ld4(ip + KS); win[rr][2] = ld4(ip + 2 * KS);
+        ip += IGW * KS;
+      }
+      nxt[0] = ld4(ip); nxt[1] = ld4(ip + KS); nxt[2] = ld4(ip + 2 * KS);
+      ip += IGW * KS;
+#pragma unroll
+      for (int o = 0; o < SEGH; ++o) {
+        const int nr = (o + 2) % 3;
+        win[nr][0] = nxt[0]; win[nr][1] = nxt[1]; win[nr][2] = nxt[2];
+        if (o + 1 < SEGH) {
+          nxt[0] = ld4(ip); nxt[1] = ld4(ip + KS); nxt[2] = ld4(ip + 2 * KS);
+          ip += IGW * KS;
+        }
+        MIGAN_SCHED_FENCE();
+        f4 sacc = bias;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+          for (int kx = 0; kx < 3; ++kx) sacc += w[ky * 3 + kx] * win[(o + ky) % 3][kx];
+        const int m = ((r0 + o) << 4) + gx;
+        char* d = a_b + m * 32 + (((c4 >> 1) ^ ((m >> 3) & 1)) << 4) + ((c4 & 1) << 3);
+        u2v h1, h2;
+        split2_f16(act4_scaled<7>(sacc), h1, h2);
+        *reinterpret_cast<u2v*>(d) = h1;
+        *reinterpret_cast<u2v*>(d + 256 * 32) = h2;
+      }
+    };
+    auto dw_share = [&](int slot, int dtslot, int abuf) {
+      if (loader) depthwise(slot, dtslot, abuf, 15, W2Int<1>{});
+      else depthwise(slot, dtslot, abuf, wave_u * 5, W2Int<5>{});
+    };
+    // Counted waits (wave 3 only; the other waves of the group issue no vector-memory operation): before the barrier that ends interval g the
+    // input and taps of sub-step g + 2 and the weight planes of g + 1 must have landed; the planes of g + 2 (16) and all of g + 3 (41) may fly.
+    if (loader) {
+      issue(); issue();
+      MIGAN_WAIT_VMCNT(57);                                // input + taps of sub-step 0 (its planes and sub-step 1 may fly)
+    }
+    MIGAN_BARRIER_LDS();                                   // P1
+    if (loader) issue();
+    dw_share(0, 0, 0);
+    if (loader) MIGAN_WAIT_VMCNT(57);                      // planes of 0, input + taps of 1
+    MIGAN_BARRIER_LDS();                                   // barrier 0
+    int dslot = 1, dtap = 1;
+    for (int g = 0; g < G; ++g) {
+      const bool more = g + 3 < G;
+      if (loader) issue();                                 // sub-step g + 3
+      PPROF_MARK(0);
+      if (g + 1 < G) dw_share(dslot, dtap, (g + 1) & 1);
+      PPROF_MARK(1);
+      dslot = dslot + 1 == L::R_IN ? 0 : dslot + 1;
+      dtap = dtap + 1 == L::R_T ? 0 : dtap + 1;
+      if (loader) { if (more) MIGAN_WAIT_VMCNT(57); else MIGAN_WAIT_VMCNT(0); }
+      PPROF_MARK(2);
+      MIGAN_BARRIER_LDS();
+      PPROF_MARK(3);
+    }
+#ifdef MIGAN_PHASE_PROF
+    if (p.prof && tid == 192) { for (int i_ = 0; i_ < 4; ++i_) MIGAN_ATOMIC_ADD_U64(p.prof + i_, (unsigned long long)pprof_acc[i_]); MIGAN_ATOMIC_ADD_U64(p.prof + 8, 1ull); }
+    if (p.prof && tid == 0) { MIGAN_ATOMIC_ADD_U64(p.prof + 12, (unsigned long long)pprof_acc[1]); MIGAN_ATOMIC_ADD_U64(p.prof + 13, (unsigned long long)(pprof_acc[3] + pprof_acc[2] + pprof_acc[0])); }
+#endif
+    return;
+  }
+  }
   if (groupA) {
     // =============================================== group A: every DMA + the depthwise stage ========================================
     const int lt = tid;
+    constexpr int LA = (V & 8) != 0 ? 2 : 3;              // lookahead of the DMA requests in sub-steps = input / tap ring slots in use
     if (MIGAN_ABL(64)) MIGAN_SETPRIO(2);                   // (measurement builds: the depthwise group ahead of the MFMA waves at issue)
     // ---- input tile of one sub-chunk -> ring slot: 1296 units of 16 bytes = 5 per thread + 4 lanes of every wave (so that each wave
     // issues the same six instructions and one vmcnt count holds for all of them).  The image is a buffer descriptor: a halo pixel
@@ -234,12 +393,16 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(kW2Threads, 3) sepconv_wide2_kernel(const 
     make_dgoff(itc.y * 16, itc.x * 16);
     auto issue = [&]() {
       if (is >= G) return;
+      PPROF_MARK(14);
       dma_in(ib0, ic, islot);
+      PPROF_MARK(0);
       dma_taps(ic, tslot);
+      PPROF_MARK(9);
       dma_b(in0, ic, is & 3);
+      PPROF_MARK(10);
       ++is;
-      islot = islot + 1 == L::R_IN ? 0 : islot + 1;
-      tslot = tslot + 1 == L::R_T ? 0 : tslot + 1;
+      islot = islot + 1 == LA ? 0 : islot + 1;
+      tslot = tslot + 1 == LA ? 0 : tslot + 1;
       if (++ic == nks) {
         ic = 0;
         if (++ik < T) {
@@ -252,25 +415,30 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(kW2Threads, 3) sepconv_wide2_kernel(const 
     // One sub-step = 6 input + 2 tap + 4 weight-plane instructions per wave, in that order.  Before the barrier that ends interval g the
     // input and taps of sub-step g+2 (for the depthwise stage of interval g+1) and the weight planes of sub-step g+1 (for its MFMAs) must
     // have landed; the weight planes of g+2 and everything of g+3 may stay in flight: 4 + 12 = 16 operations.
-    issue(); issue(); issue();
-    MIGAN_WAIT_VMCNT(28);                                  // input + taps of sub-step 0 (28 = its weight planes + two whole sub-steps)
+    // LA = 2 (variant bit 3): one sub-step less of lookahead -- two of the three input / tap slots, three of the four weight-plane slots.  The
+    // phase profile of the LA = 3 form has its waves 1.5k cycles per sub-step INSIDE the twelve DMA instructions: the CU's memory pipeline
+    // admits about one and a half sub-steps of input tiles in flight, a wave that issues into the full queue waits there, in order, ahead of
+    // its depthwise rows.  With the request for sub-step g + 2 issued at the top of interval g, the queue has room, the depthwise stage of
+    // g + 1 runs while the tile is on its way, and what is left of the flight is waited for after it.
+    issue(); issue();
+    if constexpr (LA == 3) { issue(); MIGAN_WAIT_VMCNT(28); } else MIGAN_WAIT_VMCNT(16);      // input + taps of sub-step 0
     MIGAN_BARRIER_LDS();                                   // P1
     depthwise(0, 0, 0);
-    MIGAN_WAIT_VMCNT(16);
+    if constexpr (LA == 3) MIGAN_WAIT_VMCNT(16); else MIGAN_WAIT_VMCNT(4);                    // planes of 0, input + taps of 1
     MIGAN_BARRIER_LDS();                                   // barrier 0: A planes + weight planes of sub-step 0, input + taps of sub-step 1
     int dslot = 1, dtap = 1;
     for (int g = 0; g < G; ++g) {
       // interval g: group B runs the MFMAs of sub-step g.  Input slot g % 3 and tap slot g % 3 (read by the depthwise stage of sub-step g,
       // an interval ago) and weight slot (g + 3) & 3 (read by the MFMAs of sub-step g - 1) are free: refill them, then run the
       // depthwise stage of sub-step g + 1
-      const bool more = g + 3 < G;
-      issue();                                             // sub-step g + 3
-      PPROF_MARK(0);
+      const bool more = g + LA < G;
+      issue();                                             // sub-step g + LA
+      PPROF_MARK(14);
       if (g + 1 < G) depthwise(dslot, dtap, (g + 1) & 1);
       PPROF_MARK(1);
-      dslot = dslot + 1 == L::R_IN ? 0 : dslot + 1;
-      dtap = dtap + 1 == L::R_T ? 0 : dtap + 1;
-      if (more) MIGAN_WAIT_VMCNT(16); else MIGAN_WAIT_VMCNT(0);
+      dslot = dslot + 1 == LA ? 0 : dslot + 1;
+      dtap = dtap + 1 == LA ? 0 : dtap + 1;
+      if (more) { if constexpr (LA == 3) MIGAN_WAIT_VMCNT(16); else MIGAN_WAIT_VMCNT(4); } else MIGAN_WAIT_VMCNT(0);
       PPROF_MARK(2);
       MIGAN_BARRIER_LDS();
       PPROF_MARK(3);

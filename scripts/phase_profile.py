@@ -41,7 +41,7 @@ for i, (L, t) in enumerate(zip(launches, ms)):
     n = max(1, out[8])
     if "wide2" in L["kernel"]:
         cyc = [out[k] / n / 1000.0 for k in range(16)]
-        print(f"{L['layer']:26s} {t:8.3f} {out[8]:7d}  wide2 kcycles/WG A[issue {cyc[0]:.1f} depthwise {cyc[1]:.1f} vmcnt {cyc[2]:.1f} barrier {cyc[3]:.1f}]"
+        print(f"{L['layer']:26s} {t:8.3f} {out[8]:7d}  wide2 kcycles/WG A[issue in {cyc[0]:.1f} taps {cyc[9]:.1f} planes {cyc[10]:.1f} other {cyc[14]:.1f} depthwise {cyc[1]:.1f} vmcnt {cyc[2]:.1f} barrier {cyc[3]:.1f}]"
               f" B[mfma {cyc[4]:.1f} epilogue {cyc[5]:.1f} barrier {cyc[6]:.1f}]")
         continue
     if "pipe" in L["kernel"]:

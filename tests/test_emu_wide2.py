@@ -23,8 +23,8 @@ def pkg():
     return importlib.import_module("mi-gan_amd")
 
 
-# epilogue variants (tuning w2 = 1 + variant): dword stores / 16-byte stores after a quad transpose, nontemporal / plain
-@pytest.fixture(autouse=True, params=[1, 2, 3, 4])
+# kernel variants (tuning w2 = 1 + variant): dword stores / 16-byte stores after a quad transpose; every wave of group A issuing DMAs / a loader wave
+@pytest.fixture(autouse=True, params=[1, 2, 5, 9, 10])
 def small_grids(request, lib):
     lib.set_tuning("w2", request.param)
     lib.set_tuning("w2_min_tiles", 1)

@@ -23,8 +23,8 @@ def mem():
     return CudaMem(torch.device("cuda", 0))
 
 
-# epilogue variants (tuning w2 = 1 + variant): dword stores / 16-byte stores after a quad transpose, nontemporal / plain
-@pytest.fixture(autouse=True, params=[1, 2, 3, 4])
+# kernel variants (tuning w2 = 1 + variant): dword stores / 16-byte stores after a quad transpose; every wave of group A issuing DMAs / a loader wave
+@pytest.fixture(autouse=True, params=[1, 2, 5, 9, 10])
 def restore(request, lib):
     default = lib.get_tuning("w2") if hasattr(lib, "get_tuning") else 1
     lib.set_tuning("w2", request.param)
