@@ -92,6 +92,10 @@ def parse(argv=None):
                     help="threads of the CPU baseline (0 = all logical cores); 16 is the fastest setting measured for this\n"
                          "graph of small oneDNN convs on the 256-thread GPU-box host (8: 1.04, 16: 0.94, 32: 1.07, 64: 1.72, 128: 4.4 s/img)")
     ap.add_argument("--dump-layers", type=str, default="", help="write per-launch hipEvent durations to this JSON file")
+    ap.add_argument("--pmc-pass", type=int, default=0, metavar="N",
+                    help="counter-collection pass (run under rocprofv3 --pmc): ONLY N + 2 per-launch-timed forwards -- the launches the roofline "
+                         "table times, one per layer on the whole batch, in the kernel forms of the throughput run -- then exit; "
+                         "scripts/pmc_traffic.py turns the two passes into bytes per forward and per launch of every kernel symbol")
     ap.add_argument("--tune", action="append", default=[], metavar="KEY=VALUE",
                     help="experiments: migan_set_tuning(KEY, VALUE) before the model is planned (the line records it in config.tuning)")
     ap.add_argument("--backend", type=str, default="nccl", choices=["nccl", "gloo"], help="gloo: only with --dry (CPU box)")
@@ -215,19 +219,40 @@ def attach_traffic(roof, path_rel, applies):
     meta = table.get("_meta", {})
     roof["traffic_stale"] = meta.get("kernel_source_sha") != kernel_source_sha()
     roof["traffic_measured_on"] = meta.get("kernel_source_sha")
-    for k, v in roof.get("per_kernel", {}).items():          # every kernel of the primary: ms, algorithmic bytes, PMC bytes, fraction of the HBM peak
+    # Like for like: the table holds, per kernel symbol, the bytes and the dispatch count of ONE forward of exactly the
+    # launches timed here (bench.py --pmc-pass); a symbol whose launch count differs from this run's is reported, not compared.
+    for k, v in roof.get("per_kernel", {}).items():
         t = table.get(k)
-        if t:
+        if not t:
+            continue
+        per_fwd = t.get("hbm_bytes_per_forward")
+        if per_fwd is None:                                   # (a table of rounds 1-4: average per dispatch of another launch mix)
             v["pmc_bytes_per_launch"] = round(t["hbm_bytes_per_launch"])
-            if v.get("alg_bytes_per_launch"):
-                v["pmc_over_alg"] = round(t["hbm_bytes_per_launch"] / v["alg_bytes_per_launch"], 3)
+            v["pmc_note"] = "old table format: average per dispatch, launch mix unknown"
+            continue
+        v["pmc_bytes_per_forward"] = round(per_fwd)
+        v["pmc_launches_per_forward"] = t.get("launches_per_forward")
+        if t.get("launches_per_forward") == v.get("launches") and v.get("alg_bytes_per_launch"):
+            v["pmc_over_alg"] = round(per_fwd / (v["alg_bytes_per_launch"] * v["launches"]), 3)
+        else:
+            v["pmc_note"] = f"launch count differs: table {t.get('launches_per_forward')}, this run {v.get('launches')}"
     t = table.get(roof["kernel"])
     if not t:
         roof["traffic_note"] = f"kernel symbol not in {path_rel} (stale PMC file: re-run the `pmc` step of scripts/gpu_visit.sh); symbols there: {len(table)}"
         print(f"bench.py: warning: dominant kernel {roof['kernel']} has no entry in {path_rel}", file=sys.stderr)
         return
-    roof["traffic"] = round(t["hbm_bytes_per_launch"])
-    roof["traffic_source"] = f"{path_rel} (rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE, avg per launch)"
+    if t.get("hbm_bytes_per_forward") is not None and t.get("launches_per_forward") == roof["launches"]:
+        roof["traffic"] = round(t["hbm_bytes_per_forward"] / roof["launches"])
+        roof["traffic_over_alg"] = round(t["hbm_bytes_per_forward"] / (roof["alg_per_launch"]["bytes"] * roof["launches"]), 3)
+        roof["traffic_source"] = (f"{path_rel} (rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE over the same {roof['launches']} launches per forward, "
+                                  "divided by that count)")
+    else:
+        roof["traffic"] = round(t["hbm_bytes_per_launch"])
+        roof["traffic_source"] = f"{path_rel} (rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE, avg per dispatch; launch mix of the table differs from this run)"
+    tot = sum(t2.get("hbm_bytes_per_forward", 0.0) for k2, t2 in table.items() if k2 != "_meta" and k2 in roof.get("per_kernel", {}))
+    if tot and all(k2 in table for k2 in roof.get("per_kernel", {})):
+        roof["whole_forward"]["pmc_bytes"] = round(tot)
+        roof["whole_forward"]["pmc_over_alg"] = round(tot / roof["whole_forward"]["alg_bytes"], 3)
 
 
 # ------------------------------------------------------------------------------------------------------------------------
@@ -432,6 +457,14 @@ def run_workload(args, rank, local_rank, world, dist, dev):
             el = float(t.item())
         return el, y
 
+    if args.pmc_pass:
+        with torch.no_grad():
+            for _ in range(args.pmc_pass + 2):
+                wl["timed"]()
+        torch.cuda.synchronize()
+        if rank == 0:
+            print(json.dumps({"pmc_pass": True, "forwards": args.pmc_pass + 2, "launches_per_forward": len(wl["launches"]())}))
+        return None
     with torch.no_grad():
         for _ in range(args.warmup):
             step()
@@ -468,6 +501,8 @@ def run_workload(args, rank, local_rank, world, dist, dev):
                 rounds.append(ms)
     launches = wl["launches"]()
     roof = roofline_from_launches(launches, rounds, batch, wl["gemm"])
+    # Sum of algorithmic bytes / sum of launch durations over ALL launches (the dominant symbol is one group of layers; this is the whole forward)
+    roof["time_weighted_hbm_frac"] = roof["whole_forward"]["hbm_frac"]
     roof["whole_forward"]["ms_per_step"] = round(ms_per_step, 4)
     roof["whole_forward"]["hbm_frac_of_timed_step"] = round(roof["whole_forward"]["alg_bytes"] / (ms_per_step * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)
     attach_traffic(roof, *wl["traffic"])

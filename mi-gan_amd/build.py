@@ -117,7 +117,21 @@ def build(force: bool = False, verbose: bool = False, extra: Sequence[str] = (),
 STRICT_NAN_OUT = os.path.join(CSRC, "libmigan_hip_strictnan.so")
 
 
-def build_variant(name: str, extra: Sequence[str], force: bool = False, verbose: bool = False) -> str:
+def _lint_or_reject(path: str) -> None:
+    """the packed-fp32 op_sel hazard cannot be expressed in the source: a library that contains it is moved aside, never stamped"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("migan_isa_lint", os.path.join(HERE, "isa_lint.py"))
+    isa_lint = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(isa_lint)
+    if isa_lint.available():
+        try:
+            isa_lint.check(path)
+        except RuntimeError:
+            os.replace(path, path + ".rejected")
+            raise
+
+
+def build_variant(name: str, extra: Sequence[str], force: bool = False, verbose: bool = False, lint: bool = False) -> str:
     """another build of the same library under libmigan_hip_<name>.so (objects in csrc/_obj_<name>/): the NaN-propagating variant
     (-DMIGAN_STRICT_NAN) and the measurement builds (scripts/build_variant.py)"""
     out = os.path.join(CSRC, f"libmigan_hip_{name}.so")
@@ -146,6 +160,10 @@ def build_variant(name: str, extra: Sequence[str], force: bool = False, verbose:
                        stderr=subprocess.PIPE, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"link failed ({r.returncode}):\n{r.stderr[-4000:]}")
+    if os.path.exists(stamp):
+        os.remove(stamp)
+    if lint:
+        _lint_or_reject(out)                  # (before the stamp: a rejected library is neither stamped nor left under its name)
     with open(stamp, "w") as f:
         f.write(flags_digest(extra) + "\n")
     return out
@@ -153,14 +171,7 @@ def build_variant(name: str, extra: Sequence[str], force: bool = False, verbose:
 
 def build_strict_nan(force: bool = False, verbose: bool = False) -> str:
     """libmigan_hip_strictnan.so: the same library with Tensor.clamp's NaN propagation (Generator(nan_policy="propagate"))"""
-    out = build_variant("strictnan", ["-DMIGAN_STRICT_NAN"], force=force, verbose=verbose)
-    import importlib.util
-    spec = importlib.util.spec_from_file_location("migan_isa_lint", os.path.join(HERE, "isa_lint.py"))
-    isa_lint = importlib.util.module_from_spec(spec)
-    spec.loader.exec_module(isa_lint)
-    if isa_lint.available():
-        isa_lint.check(out)
-    return out
+    return build_variant("strictnan", ["-DMIGAN_STRICT_NAN"], force=force, verbose=verbose, lint=True)
 
 
 if __name__ == "__main__":

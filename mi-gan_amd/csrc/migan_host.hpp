@@ -115,7 +115,7 @@ struct Tuning {
                                // run 8 + 8 waves, fused-FromRGB and FIR-up layers 4 + 8: profiles/r04_pipe_layers.txt)
   int pipe_dna = 12;           // depthwise + FIR waves of the fused down=2 kernel: 4 or 8 (+ 8 GEMM / epilogue waves) or 12 (+ 4)
   int pipe_min_tiles = 256;    // launches with fewer tiles keep the one-tile-per-workgroup kernels
-  int w2 = 1;                  // MIGAN_W2=0|1: the 256 / 512-channel plain layers on persistent 256-pixel x 256-channel tiles (sepconv_wide2_kernel, round 5)
+  int w2 = 2;                  // MIGAN_W2=0|1|2: the 256 / 512-channel plain layers on persistent 256-pixel x 256-channel tiles (sepconv_wide2_kernel, round 5)
                                // where a launch has at least w2_min_tiles of them (fp32 storage, f16x2 GEMM, whole 16 x 16 tiles)
   int w2_min_tiles = 256;      // (one tile per CU; below that the 128-pixel one-tile kernel spreads the launch over more CUs)
   int pipe_min_batch = 1;      // smallest batch that takes them (1: a single-image forward runs them on its 512x512 / 256x256 layers too -- 2048 / 512 tiles;
@@ -399,21 +399,9 @@ inline const DownEntry* pick_pipedown(int cin, int cout, int h_in, int w_in, int
 // the launch fills the chip with them.  The choice depends on the batch (tiles per image: 64 at 128 x 128, 16 at 64 x 64): the two forms sum
 // a layer's K chunks in the same order with the same operand split, so an image does not depend on which one ran (tests compare them bit for bit).
 SepKernelFn wide2_fn(int variant);
-// tuning().w2 = 1 + variant: bit 0 = 16-byte stores after a quad transpose, bit 2 = loader-wave form of group A, bit 3 = DMA lookahead of two
-// sub-steps instead of three (variants 0, 1, 4, 8, 9 exist)
-inline int wide2_variant() {
-  const int v = (tuning().w2 - 1) & 15;
-  return (v == 1 || v == 4 || v == 8 || v == 9) ? v : 0;
-}
-inline const char* wide2_name() {
-  switch (wide2_variant()) {
-    case 1: return "migan::sepconv_wide2_kernel<1>";
-    case 4: return "migan::sepconv_wide2_kernel<4>";
-    case 8: return "migan::sepconv_wide2_kernel<8>";
-    case 9: return "migan::sepconv_wide2_kernel<9>";
-    default: return "migan::sepconv_wide2_kernel<0>";
-  }
-}
+// tuning().w2: 0 off | 1 weight planes DMA'd as 16-channel halves (four 16 KB slots) | 2 (default) as whole 32-channel chunks (two 32 KB slots)
+inline int wide2_variant() { return tuning().w2 == 1 ? 0 : 1; }
+inline const char* wide2_name() { return wide2_variant() ? "migan::sepconv_wide2_kernel<1>" : "migan::sepconv_wide2_kernel<0>"; }
 inline bool use_wide2(const Geo& g, int cin, int cout, int batch, bool fused_rgb, bool has_skip, bool u8) {
   if (!tuning().w2 || !g.wide || g.mode != MODE_NORMAL || g.stv != 0 || g.gemmv != 2 || g.fromrgb || fused_rgb || has_skip || u8) return false;
   const int h = g.tiles_y * 8, w = g.tiles_x * 16;               // (wide tiles are whole 8 x 16 tiles)
@@ -520,7 +508,7 @@ inline void prepare_kernels() {
       if (sv == 0) rt_check(rt::allow_dynamic_lds((const void*)wide_fn(t != 0, 0, false, true, true), 160 * 1024), "hipFuncSetAttribute");
       if (sv == 0 && t == 0) rt_check(rt::allow_dynamic_lds((const void*)wide_up_fn(), 160 * 1024), "hipFuncSetAttribute");
       if (sv == 0 && t == 0)
-        for (int v : {0, 1, 4, 8, 9}) rt_check(rt::allow_dynamic_lds((const void*)wide2_fn(v), 160 * 1024), "hipFuncSetAttribute");
+        for (int v : {0, 1}) rt_check(rt::allow_dynamic_lds((const void*)wide2_fn(v), 160 * 1024), "hipFuncSetAttribute");
       rt_check(rt::allow_dynamic_lds((const void*)dwfir_fn(t != 0, sv), 96 * 1024), "hipFuncSetAttribute");
       if (sv) rt_check(rt::allow_dynamic_lds((const void*)dwfir_fn(t != 0, sv + 2), 96 * 1024), "hipFuncSetAttribute");
     }
@@ -596,10 +584,13 @@ inline unsigned grid_of(const Geo& g, int batch, bool fused_rgb = false) {
 // name of the kernel launch_sepconv runs for this geometry and batch
 inline const char* launched_kernel_name(Geo g, int cin, int cout, int batch, bool fused_rgb);
 
-inline void launch_sepconv(Geo g, const SepArgs& a, rt::stream_t stream) {
+// n_decide: the batch the kernel FORM is chosen for (0 = a.B).  The per-launch timing run launches the whole batch at once but must time the
+// forms the production forward -- sub-batches on staggered streams -- launches.
+inline void launch_sepconv(Geo g, const SepArgs& a, rt::stream_t stream, int n_decide = 0) {
   prepare_kernels();
   const bool fused_rgb = a.trgb_w != nullptr;
-  if (const PipeEntry* pe = pick_pipe(g, a.CI, a.CO, a.B, fused_rgb, a.u8_img != nullptr, a.skip != nullptr)) {
+  const int nd = n_decide > 0 ? n_decide : a.B;
+  if (const PipeEntry* pe = pick_pipe(g, a.CI, a.CO, nd, fused_rgb, a.u8_img != nullptr, a.skip != nullptr)) {
     MIGAN_CHECK(a.wsplit != nullptr, MIGAN_EINVAL, "internal: the pipelined kernel needs the fp16 weight planes");
     SepArgs ap = a;
     ap.nchunks = a.CO / pe->NT;                          // (FIR-up: 64-column chunks, see pick_pipe)
@@ -609,7 +600,7 @@ inline void launch_sepconv(Geo g, const SepArgs& a, rt::stream_t stream) {
     last_kernel_ref() = pe->name;
     return;
   }
-  if (use_wide2(g, a.CI, a.CO, a.B, fused_rgb, a.skip != nullptr, a.u8_img != nullptr)) {
+  if (use_wide2(g, a.CI, a.CO, nd, fused_rgb, a.skip != nullptr, a.u8_img != nullptr)) {
     MIGAN_CHECK(a.wsplit != nullptr, MIGAN_EINVAL, "internal: the 256 x 256 tile kernel needs the fp16 weight planes");
     SepArgs aw = a;
     aw.tiles_x = a.W / 16; aw.tiles_y = a.H / 16; aw.nchunks = a.CO / 256;
@@ -619,7 +610,7 @@ inline void launch_sepconv(Geo g, const SepArgs& a, rt::stream_t stream) {
     last_kernel_ref() = wide2_name();
     return;
   }
-  g.persist = use_persistent(g, a.B, fused_rgb);
+  g.persist = use_persistent(g, a.B, fused_rgb);      // (grid size: the batch actually launched)
   g.torgb = fused_rgb;
   MIGAN_CHECK(!fused_rgb || (g.mode == MODE_NORMAL && !g.fromrgb && g.nchunks == 1), MIGAN_EINVAL,
               "ToRGB can only be fused into a plain layer whose output channels fit one column tile");
@@ -1103,15 +1094,18 @@ inline void migan_handle::run_range(const migan::Plan& P, const float* x, float*
     if (timed) rt_check(rt::event_record(events[2 * li], stream), "hipEventRecord");
     // a down=2 layer is two plan entries (depthwise + FIR-down, pointwise GEMM); where the fused kernel applies, the first entry launches
     // nothing and the second launches sepconv_pipedown_kernel on the first one's input
+    // (nd: the sub-batch size the production forward launches with -- the per-launch timing run covers the whole batch in one launch but
+    // must time the kernel forms the throughput run uses)
+    const int nd = n_geo > 0 ? n_geo : n;
     const bool dw_fused = L.is_dwfir && li + 1 < P.launches.size() &&
-                          pick_pipedown(L.cin, P.launches[li + 1].cout, L.hin, L.win, n, stv, gemm) != nullptr;
+                          pick_pipedown(L.cin, P.launches[li + 1].cout, L.hin, L.win, nd, stv, gemm) != nullptr;
     const bool pw_fused = !L.is_dwfir && !L.is_rgb && L.g.mode == MODE_PW && li >= 1 && P.launches[li - 1].is_dwfir &&
-                          pick_pipedown(L.cin, L.cout, P.launches[li - 1].hin, P.launches[li - 1].win, n, stv, gemm) != nullptr;
+                          pick_pipedown(L.cin, L.cout, P.launches[li - 1].hin, P.launches[li - 1].win, nd, stv, gemm) != nullptr;
     if (dw_fused) {
-      L.kernel_last = pick_pipedown(L.cin, P.launches[li + 1].cout, L.hin, L.win, n, stv, gemm)->name;      // (its bytes belong to that launch)
+      L.kernel_last = pick_pipedown(L.cin, P.launches[li + 1].cout, L.hin, L.win, nd, stv, gemm)->name;      // (its bytes belong to that launch)
     } else if (pw_fused) {
       const Launch& D = P.launches[li - 1];
-      const DownEntry* de = pick_pipedown(L.cin, L.cout, D.hin, D.win, n, stv, gemm);
+      const DownEntry* de = pick_pipedown(L.cin, L.cout, D.hin, D.win, nd, stv, gemm);
       SepArgs a{};
       a.x = bptr(D.in_buf); a.y = bptr(L.out_buf);
       a.wdw = wptr(D.w_dw); a.bdw = wptr(D.b_dw); a.wpw = wptr(L.w_pw);
@@ -1151,16 +1145,13 @@ inline void migan_handle::run_range(const migan::Plan& P, const float* x, float*
       for (const Geo& gs : L.g_small) {
         // K-split tiles sum K in another order than every other tile (four partial sums): single-image forwards only, so that an
         // image of a batch of two or more is bit-identical whatever the batch size and the sub-batch grouping
-        // (n_geo: the sub-batch size the production forward launches with -- the per-launch timing run covers the whole batch in one
-        // launch but must time the kernels the throughput run uses)
-        const int ng = n_geo > 0 ? n_geo : n;
-        if (gs.NT == 32 && ng != 1) continue;
-        if ((int)tiles_of(gs, ng) <= tuning().small_max_wgs) { Gp = &gs; break; }
+        if (gs.NT == 32 && nd != 1) continue;
+        if ((int)tiles_of(gs, nd) <= tuning().small_max_wgs) { Gp = &gs; break; }
       }
       const Geo& G = *Gp;
       fill_geo(a, G);
-      launch_sepconv(G, a, stream);
-      L.kernel_last = launched_kernel_name(G, L.cin, L.cout, n, a.trgb_w != nullptr);
+      launch_sepconv(G, a, stream, nd);
+      L.kernel_last = launched_kernel_name(G, L.cin, L.cout, nd, a.trgb_w != nullptr);
     }
     if (timed) rt_check(rt::event_record(events[2 * li + 1], stream), "hipEventRecord");
     if (!timed && (int)li == mid_after) rt_check(rt::event_record(ev_mid[part], stream), "hipEventRecord");

@@ -47,9 +47,11 @@ MIGAN_DEVICE MIGAN_INLINE float act1g(float v, float gain) {      // act1 with t
   return MIGAN_CLAMP(t, -256.0f, 256.0f);
 }
 
-// V: epilogue variant -- bit 0: 16-byte stores (4 x 4 transposes among the quads of lanes: 32 store instructions per wave and tile instead of
-// 128, i.e. fewer than the 63 the vmcnt counter can hold, so a wave is never held at the counter and the stores drain under the next tile);
-// bit 1: plain instead of nontemporal stores.  (A template also so that translation units that only need W2Lds do not emit the kernel.)
+// V bit 0: the weight planes arrive as whole 32-channel chunks (two slots of 32 KB, eight DMA instructions per wave every other sub-step), V = 0:
+// as 16-channel halves (four slots of 16 KB, four instructions per sub-step).  The planes are stored chunk-major [plane][CI/32][CO][32], a
+// row = 64 bytes: a DMA of half rows touches 32 rows x 32 bytes = sixteen half-used cache lines per instruction and measured 195 cycles at
+// issue (profiles/r05_wide2.md), one of whole rows sixteen rows x 64 bytes = eight full lines.  (A template also so that translation units
+// that only need W2Lds do not emit the kernel.)
 template <int V>
 MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(kW2Threads, 3) sepconv_wide2_kernel(const SepArgs p) {
   typedef W2Lds L;
@@ -103,166 +105,11 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(kW2Threads, 3) sepconv_wide2_kernel(const 
     c.b += st_b + carry;
   };
 
-  if constexpr ((V & 4) != 0) {
-  if (groupA) {
-    // ======================= group A, loader-wave form: wave 3 issues EVERY DMA (and runs one depthwise row), waves 0..2 five rows each ==========
-    // The phase profile of the first form (profiles/r05_wide2.md) has a group-A wave 1.5k cycles per sub-step inside its twelve DMA instructions:
-    // the input tiles stream from HBM at the chip's 6.2 TB/s = 11.7 B/clk per CU, the queue of the CU's memory pipeline is full, and a wave
-    // that issues into a full queue waits -- in order -- for HBM before it may run its depthwise rows (1.6k cycles).  Here the wave that waits
-    // for HBM is a different one from those that compute: 41 DMA instructions per sub-step (21 input, 4 taps, 16 weight planes; at most 57 in
-    // flight at a counted wait, under the 63 of the vmcnt counter) on wave 3, which otherwise only has row 15 of the tile to do.
-    const bool loader = wave_u == 3;
-    // ---- input tile: unit u = 64 j + lane (j = 0..20, the last with 16 lanes) = halo pixel u >> 2, channel quad u & 3 ----
-    unsigned dgoff[21], tile_soff = 0;
-    auto make_dgoff = [&](int gy0_, int gx0_) {
-      const bool interior = gy0_ >= 1 && gy0_ + 17 <= p.H && gx0_ >= 1 && gx0_ + 17 <= p.W;
-      tile_soff = interior ? (unsigned)(((gy0_ - 1) * p.W + (gx0_ - 1)) * CI) * 4u : 0u;
-      const int oy = interior ? 0 : gy0_ - 1, ox = interior ? 0 : gx0_ - 1;
-#pragma unroll
-      for (int j = 0; j < 21; ++j) {
-        const int i = j * 64 + lane;
-        unsigned g = 0xfffff000u;
-        if (i < NITEMS) {
-          const int c4 = i & 3, pix = i >> 2;
-          const int yy = oy + pix / IGW, xx = ox + pix % IGW;
-          if (interior || (yy >= 0 && yy < p.H && xx >= 0 && xx < p.W)) g = (unsigned)((yy * p.W + xx) * CI + c4 * 4) * 4u;
-        }
-        dgoff[j] = g;
-      }
-    };
-    const unsigned img_bytes = (unsigned)(p.H * p.W * CI) * 4u;
-    const MIGAN_BUF tbuf = MIGAN_MAKE_BUF(p.wdw, (unsigned)(CI * 9) * 4u);
-    const MIGAN_BUF bbuf = MIGAN_MAKE_BUF(p.bdw, (unsigned)CI * 4u);
-    const MIGAN_BUF wbuf = MIGAN_MAKE_BUF(p.wsplit, (unsigned)(2 * p.CO * CI) * 2u);
-    const unsigned tap_voff = (unsigned)((lane & 15) * 9 + (lane >> 4)) * 4u;          // unit 64 k + lane = tap 4 k + (lane >> 4), channel lane & 15
-    const unsigned b_voff = (unsigned)((lane >> 1) * 32 + (((lane & 1) ^ ((lane >> 4) & 1)) * 8)) * 2u;     // unit 64 j + lane: row 32 (j & 7) + (lane >> 1), slot lane & 1
-    const unsigned plane_bytes = (unsigned)(p.CO * CI) * 2u;
-    int is = 0, ic = 0, ik = 0, islot = 0, tslot = 0;
-    TileCur itc = tile0;
-    int in0 = itc.n * 256, ib0 = itc.b;
-    if (loader) make_dgoff(itc.y * 16, itc.x * 16);
-    auto issue = [&]() {                                   // everything of the sub-step at the cursor: input (21), taps (4), weight planes (16)
-      if (is >= G) return;
-      {
-        float* in_s = reinterpret_cast<float*>(lds + L::OFF_IN + islot * L::IN_SLOT);
-        const MIGAN_BUF xbuf = MIGAN_MAKE_BUF(reinterpret_cast<const char*>(p.x) + (size_t)ib0 * img_bytes, img_bytes);
-        const unsigned soff = tile_soff + (unsigned)(ic * KS) * 4u;
-        if (!MIGAN_ABL(16)) {
-#pragma unroll
-          for (int j = 0; j < 20; ++j) MIGAN_LDS_DMA16(xbuf, dgoff[j], soff, in_s + j * 256);
-          MIGAN_LDS_DMA16_IF(lane < 16, xbuf, dgoff[20], soff, in_s + 20 * 256);
-        }
-      }
-      {
-        float* w_s = reinterpret_cast<float*>(lds + L::OFF_W + tslot * L::TAP_SLOT);
-        const unsigned soff = (unsigned)(ic * KS * 9) * 4u;
-        MIGAN_LDS_DMA4(tbuf, tap_voff, soff, w_s);
-        MIGAN_LDS_DMA4(tbuf, tap_voff + 16u, soff, w_s + 64);
-        MIGAN_LDS_DMA4_IF(lane < 16, tbuf, tap_voff + 32u, soff, w_s + 128);
-        MIGAN_LDS_DMA4_IF(lane < 16, bbuf, (unsigned)lane * 4u, (unsigned)(ic * KS) * 4u, w_s + 144);
-      }
-      if (!MIGAN_ABL(32)) {
-        float* bb = reinterpret_cast<float*>(lds + L::OFF_B + (is & 3) * L::B_SLOT);
-        const unsigned soff = (unsigned)(((ic >> 1) * p.CO + in0) * 32 + (ic & 1) * 16) * 2u;
-#pragma unroll
-        for (int j = 0; j < 16; ++j) MIGAN_LDS_DMA16(wbuf, b_voff, soff + (unsigned)(j >> 3) * plane_bytes + (unsigned)((j & 7) * 32 * 32) * 2u, bb + j * 256);
-      }
-      ++is;
-      islot = islot + 1 == L::R_IN ? 0 : islot + 1;
-      tslot = tslot + 1 == L::R_T ? 0 : tslot + 1;
-      if (++ic == nks) {
-        ic = 0;
-        if (++ik < T) {
-          tile_next(itc);
-          in0 = itc.n * 256; ib0 = itc.b;
-          make_dgoff(itc.y * 16, itc.x * 16);
-        }
-      }
-    };
-    // ---- depthwise 3x3 + bias + act (x 2^7) + fp16 hi/lo split: SEGH rows x 4 channels per thread (a wave = 16 columns x 4 channel quads) ----
-    auto depthwise = [&](int slot, int dtslot, int abuf, int r0, auto segh_) {
-      constexpr int SEGH = decltype(segh_)::value;
-      if (MIGAN_ABL(4)) return;
-      const float* in_s = reinterpret_cast<const float*>(lds + L::OFF_IN + slot * L::IN_SLOT);
-      const float* wc = reinterpret_cast<const float*>(lds + L::OFF_W + dtslot * L::TAP_SLOT);
-      char* a_b = lds + L::OFF_A + abuf * L::A_BUF;
-      const int c4 = lane & 3;
-      const int gx = lane >> 2;
-      f4 w[9];
-#pragma unroll
-      for (int tap = 0; tap < 9; ++tap) w[tap] = ld4(wc + tap * KS + c4 * 4);
-      const f4 bias = ld4(wc + 144 + c4 * 4);
-      const float* ip = in_s + (r0 * IGW + gx) * KS + c4 * 4;
-      f4 win[3][3], nxt[3];
-#pragma unroll
-      for (int rr = 0; rr < 2; ++rr) {
-        win[rr][0] = ld4(ip); win[rr][1] = ld4(ip + KS); win[rr][2] = ld4(ip + 2 * KS);
-        ip += IGW * KS;
-      }
-      nxt[0] = ld4(ip); nxt[1] = ld4(ip + KS); nxt[2] = ld4(ip + 2 * KS);
-      ip += IGW * KS;
-#pragma unroll
-      for (int o = 0; o < SEGH; ++o) {
-        const int nr = (o + 2) % 3;
-        win[nr][0] = nxt[0]; win[nr][1] = nxt[1]; win[nr][2] = nxt[2];
-        if (o + 1 < SEGH) {
-          nxt[0] = ld4(ip); nxt[1] = ld4(ip + KS); nxt[2] = ld4(ip + 2 * KS);
-          ip += IGW * KS;
-        }
-        MIGAN_SCHED_FENCE();
-        f4 sacc = bias;
-#pragma unroll
-        for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-          for (int kx = 0; kx < 3; ++kx) sacc += w[ky * 3 + kx] * win[(o + ky) % 3][kx];
-        const int m = ((r0 + o) << 4) + gx;
-        char* d = a_b + m * 32 + (((c4 >> 1) ^ ((m >> 3) & 1)) << 4) + ((c4 & 1) << 3);
-        u2v h1, h2;
-        split2_f16(act4_scaled<7>(sacc), h1, h2);
-        *reinterpret_cast<u2v*>(d) = h1;
-        *reinterpret_cast<u2v*>(d + 256 * 32) = h2;
-      }
-    };
-    auto dw_share = [&](int slot, int dtslot, int abuf) {
-      if (loader) depthwise(slot, dtslot, abuf, 15, W2Int<1>{});
-      else depthwise(slot, dtslot, abuf, wave_u * 5, W2Int<5>{});
-    };
-    // Counted waits (wave 3 only; the other waves of the group issue no vector-memory operation): before the barrier that ends interval g the
-    // input and taps of sub-step g + 2 and the weight planes of g + 1 must have landed; the planes of g + 2 (16) and all of g + 3 (41) may fly.
-    if (loader) {
-      issue(); issue();
-      MIGAN_WAIT_VMCNT(57);                                // input + taps of sub-step 0 (its planes and sub-step 1 may fly)
-    }
-    MIGAN_BARRIER_LDS();                                   // P1
-    if (loader) issue();
-    dw_share(0, 0, 0);
-    if (loader) MIGAN_WAIT_VMCNT(57);                      // planes of 0, input + taps of 1
-    MIGAN_BARRIER_LDS();                                   // barrier 0
-    int dslot = 1, dtap = 1;
-    for (int g = 0; g < G; ++g) {
-      const bool more = g + 3 < G;
-      if (loader) issue();                                 // sub-step g + 3
-      PPROF_MARK(0);
-      if (g + 1 < G) dw_share(dslot, dtap, (g + 1) & 1);
-      PPROF_MARK(1);
-      dslot = dslot + 1 == L::R_IN ? 0 : dslot + 1;
-      dtap = dtap + 1 == L::R_T ? 0 : dtap + 1;
-      if (loader) { if (more) MIGAN_WAIT_VMCNT(57); else MIGAN_WAIT_VMCNT(0); }
-      PPROF_MARK(2);
-      MIGAN_BARRIER_LDS();
-      PPROF_MARK(3);
-    }
-#ifdef MIGAN_PHASE_PROF
-    if (p.prof && tid == 192) { for (int i_ = 0; i_ < 4; ++i_) MIGAN_ATOMIC_ADD_U64(p.prof + i_, (unsigned long long)pprof_acc[i_]); MIGAN_ATOMIC_ADD_U64(p.prof + 8, 1ull); }
-    if (p.prof && tid == 0) { MIGAN_ATOMIC_ADD_U64(p.prof + 12, (unsigned long long)pprof_acc[1]); MIGAN_ATOMIC_ADD_U64(p.prof + 13, (unsigned long long)(pprof_acc[3] + pprof_acc[2] + pprof_acc[0])); }
-#endif
-    return;
-  }
-  }
   if (groupA) {
     // =============================================== group A: every DMA + the depthwise stage ========================================
     const int lt = tid;
-    constexpr int LA = (V & 8) != 0 ? 2 : 3;              // lookahead of the DMA requests in sub-steps = input / tap ring slots in use
+    constexpr int LA = 3;                                  // lookahead of the DMA requests in sub-steps = input / tap ring slots
+    constexpr bool B32 = (V & 1) != 0;
     if (MIGAN_ABL(64)) MIGAN_SETPRIO(2);                   // (measurement builds: the depthwise group ahead of the MFMA waves at issue)
     // ---- input tile of one sub-chunk -> ring slot: 1296 units of 16 bytes = 5 per thread + 4 lanes of every wave (so that each wave
     // issues the same six instructions and one vmcnt count holds for all of them).  The image is a buffer descriptor: a halo pixel
@@ -326,19 +173,33 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(kW2Threads, 3) sepconv_wide2_kernel(const 
     // contiguous bytes of a row; LDS image [plane][256 rows][2 slots of 16 bytes], the slots of a row swapped where (row >> 3) & 1 (on
     // the SOURCE side: the LDS destination of a DMA is linear in the lane) so that the fragment reads are conflict-free ----
     const MIGAN_BUF wbuf = MIGAN_MAKE_BUF(p.wsplit, (unsigned)(2 * p.CO * CI) * 2u);
-    unsigned dboff[4];
+    // B32: LDS image of a chunk [plane][256 rows][4 slots of 16 bytes], slot s of row n holding source slot s ^ ((n >> 2) & 3) (the swizzle of
+    // the other kernels; on the SOURCE side, the LDS destination of a DMA is linear in the lane): 8 instructions of 16 rows per wave
+    unsigned dboff[B32 ? 8 : 4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < (B32 ? 8 : 4); ++j) {
       const int i = lt + j * AT;                          // 16-byte unit of the LDS image
-      const int plane = i >> 9, n = (i >> 1) & 255, sp = i & 1;
-      dboff[j] = (unsigned)(plane * p.CO * CI + n * 32 + ((sp ^ ((n >> 3) & 1)) * 8)) * 2u;
+      if constexpr (B32) {
+        const int plane = i >> 10, n = (i >> 2) & 255, sp = i & 3;
+        dboff[j] = (unsigned)(plane * p.CO * CI + n * 32 + ((sp ^ ((n >> 2) & 3)) * 8)) * 2u;
+      } else {
+        const int plane = i >> 9, n = (i >> 1) & 255, sp = i & 1;
+        dboff[j] = (unsigned)(plane * p.CO * CI + n * 32 + ((sp ^ ((n >> 3) & 1)) * 8)) * 2u;
+      }
     }
     auto dma_b = [&](int n0_, int ks, int slot) {
       if (MIGAN_ABL(32)) return;
-      float* bb = reinterpret_cast<float*>(lds + L::OFF_B + slot * L::B_SLOT);
-      const unsigned soff = (unsigned)(((ks >> 1) * p.CO + n0_) * 32 + (ks & 1) * 16) * 2u;
+      if constexpr (B32) {                                 // the whole 32-channel chunk ks >> 1
+        float* bb = reinterpret_cast<float*>(lds + L::OFF_B + slot * (2 * L::B_SLOT));
+        const unsigned soff = (unsigned)(((ks >> 1) * p.CO + n0_) * 32) * 2u;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) MIGAN_LDS_DMA16(wbuf, dboff[j], soff, bb + (j * AT + wave_u * 64) * 4);
+        for (int j = 0; j < 8; ++j) MIGAN_LDS_DMA16(wbuf, dboff[j], soff, bb + (j * AT + wave_u * 64) * 4);
+      } else {
+        float* bb = reinterpret_cast<float*>(lds + L::OFF_B + slot * L::B_SLOT);
+        const unsigned soff = (unsigned)(((ks >> 1) * p.CO + n0_) * 32 + (ks & 1) * 16) * 2u;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) MIGAN_LDS_DMA16(wbuf, dboff[j], soff, bb + (j * AT + wave_u * 64) * 4);
+      }
     };
 
     // ---- depthwise 3x3 + bias + act (x 2^7) + fp16 hi/lo split of one sub-chunk: one 4-row strip x 4 channels per thread ------------
@@ -398,7 +259,10 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(kW2Threads, 3) sepconv_wide2_kernel(const 
       PPROF_MARK(0);
       dma_taps(ic, tslot);
       PPROF_MARK(9);
-      dma_b(in0, ic, is & 3);
+      // B32: the chunk that holds this sub-step rides with its ODD sub-step -- requested at interval is - 3, first read by the MFMAs of the even
+      // sub-step is - 1, i.e. two intervals later; its slot (chunk parity) was last read by the MFMAs of sub-step is - 4, an interval before
+      if constexpr (B32) { if (ic & 1) dma_b(in0, ic, (is >> 1) & 1); }
+      else dma_b(in0, ic, is & 3);
       PPROF_MARK(10);
       ++is;
       islot = islot + 1 == LA ? 0 : islot + 1;
@@ -415,16 +279,15 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(kW2Threads, 3) sepconv_wide2_kernel(const 
     // One sub-step = 6 input + 2 tap + 4 weight-plane instructions per wave, in that order.  Before the barrier that ends interval g the
     // input and taps of sub-step g+2 (for the depthwise stage of interval g+1) and the weight planes of sub-step g+1 (for its MFMAs) must
     // have landed; the weight planes of g+2 and everything of g+3 may stay in flight: 4 + 12 = 16 operations.
-    // LA = 2 (variant bit 3): one sub-step less of lookahead -- two of the three input / tap slots, three of the four weight-plane slots.  The
-    // phase profile of the LA = 3 form has its waves 1.5k cycles per sub-step INSIDE the twelve DMA instructions: the CU's memory pipeline
-    // admits about one and a half sub-steps of input tiles in flight, a wave that issues into the full queue waits there, in order, ahead of
-    // its depthwise rows.  With the request for sub-step g + 2 issued at the top of interval g, the queue has room, the depthwise stage of
-    // g + 1 runs while the tile is on its way, and what is left of the flight is waited for after it.
+    // B32: a sub-step is 8 instructions (even) or 8 + 8 (odd, with its chunk behind the input and the taps).  An even interval g issued an
+    // odd sub-step: its 16 operations may fly, everything older has landed (the previous interval's input and taps); an odd interval issued 8,
+    // and the chunk issued the interval before is needed next: only those 8 may fly.
     issue(); issue();
-    if constexpr (LA == 3) { issue(); MIGAN_WAIT_VMCNT(28); } else MIGAN_WAIT_VMCNT(16);      // input + taps of sub-step 0
+    issue();
+    MIGAN_WAIT_VMCNT(B32 ? 24 : 28);                       // input + taps of sub-step 0 (everything issued after them may fly)
     MIGAN_BARRIER_LDS();                                   // P1
     depthwise(0, 0, 0);
-    if constexpr (LA == 3) MIGAN_WAIT_VMCNT(16); else MIGAN_WAIT_VMCNT(4);                    // planes of 0, input + taps of 1
+    MIGAN_WAIT_VMCNT(B32 ? 8 : 16);                        // planes of sub-step 0 (of chunk 0), input + taps of sub-step 1
     MIGAN_BARRIER_LDS();                                   // barrier 0: A planes + weight planes of sub-step 0, input + taps of sub-step 1
     int dslot = 1, dtap = 1;
     for (int g = 0; g < G; ++g) {
@@ -438,7 +301,9 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(kW2Threads, 3) sepconv_wide2_kernel(const 
       PPROF_MARK(1);
       dslot = dslot + 1 == LA ? 0 : dslot + 1;
       dtap = dtap + 1 == LA ? 0 : dtap + 1;
-      if (more) { if constexpr (LA == 3) MIGAN_WAIT_VMCNT(16); else MIGAN_WAIT_VMCNT(4); } else MIGAN_WAIT_VMCNT(0);
+      if (!more) MIGAN_WAIT_VMCNT(0);
+      else if (B32 && (g & 1)) MIGAN_WAIT_VMCNT(8);        // (the chunk issued an interval ago, behind that interval's input tile, is needed next)
+      else MIGAN_WAIT_VMCNT(16);
       PPROF_MARK(2);
       MIGAN_BARRIER_LDS();
       PPROF_MARK(3);
@@ -465,10 +330,15 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(kW2Threads, 3) sepconv_wide2_kernel(const 
   };
   // (one code path for every sub-step: a "first product of the tile reads C = 0" variant made the register allocator copy whole
   // accumulator blocks around the join and spill; the 128 v_mov_b32 per tile are noise beside 384+ MFMAs per wave)
-  auto mfma_step = [&](int abuf, int bslot) {
+  constexpr bool B32 = (V & 1) != 0;
+  // B32: weight-plane rows of 64 bytes, 16-byte slot (2 ks + half) ^ ((row >> 2) & 3) (ks = sub-step parity inside the chunk)
+  const int foffb = l31 * 64 + ((half ^ ((l31 >> 2) & 3)) << 4);
+  auto mfma_step = [&](int abuf, int bidx) {               // bidx = sub-step & 3: the weight-plane slot (B32: chunk slot bidx >> 1, half bidx & 1)
     if (MIGAN_ABL(8)) return;
     const char* ab = lds + L::OFF_A + abuf * L::A_BUF + (wm * 64) * 32 + foff;
-    const char* bb = lds + L::OFF_B + bslot * L::B_SLOT + (wn * 128) * 32 + foff;
+    const char* bb = B32 ? lds + L::OFF_B + (bidx >> 1) * (2 * L::B_SLOT) + (wn * 128) * 64 + (foffb ^ ((bidx & 1) << 5))
+                         : lds + L::OFF_B + bidx * L::B_SLOT + (wn * 128) * 32 + foff;
+    constexpr int BROW = B32 ? 64 : 32;
     f4 av[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -477,8 +347,8 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(kW2Threads, 3) sepconv_wide2_kernel(const 
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const f4 b0v = ld4(reinterpret_cast<const float*>(bb + j * 32 * 32));
-      const f4 b1v = ld4(reinterpret_cast<const float*>(bb + j * 32 * 32 + 256 * 32));
+      const f4 b0v = ld4(reinterpret_cast<const float*>(bb + j * 32 * BROW));
+      const f4 b1v = ld4(reinterpret_cast<const float*>(bb + j * 32 * BROW + 256 * BROW));
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         // smallest products first (the order of every f16x2 kernel of the library: a layer's K chunks are summed identically)
@@ -499,60 +369,23 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(kW2Threads, 3) sepconv_wide2_kernel(const 
   float nzl = 0.0f;                                              // noise_const of pixel `lane` of this wave's 64 rows (tile rows 4 wm .. 4 wm + 3)
   TileCur ctc = tile0;
   auto request_noise = [&]() {
-    if (has_noise) nzl = p.noise[(unsigned)((ctc.y * 16 + wm * 4 + (lane >> 4)) * p.W + ctc.x * 16 + (lane & 15))];
+    if (has_noise) {
+      int ln = lane;
+      MIGAN_OPAQUE(ln);                                          // (recomputed per tile: hoisted out of the persistent loop these lane terms cost registers the MFMA steps need)
+      nzl = p.noise[(unsigned)((ctc.y * 16 + wm * 4 + (ln >> 4)) * p.W + ctc.x * 16 + (ln & 15))];
+    }
   };
-  auto store1 = [&](float* q, float v) {
-    if constexpr ((V & 2) != 0) *q = v; else MIGAN_STORE_NT(q, v);
-  };
-  auto store4 = [&](float* q, f4 v) {
-    if constexpr ((V & 2) != 0) *reinterpret_cast<f4*>(q) = v; else MIGAN_STORE_NT(reinterpret_cast<f4*>(q), v);
-  };
-  const bool odd1 = (lane & 1) != 0, odd2 = (lane & 2) != 0;
-  const unsigned lane_off4 = (unsigned)(((lane & 3) + 4 * half) * p.CO + wn * 128 + (l31 & ~3)) * 4u;
   auto epilogue = [&](auto hn_) {
     constexpr bool HN = decltype(hn_)::value;
     // (opaque copies: the 32 row addresses below are functions of W and CO only -- left visible, the compiler hoists all of them out of the
     // persistent loop and spills them)
     int W_ = p.W, CO_ = p.CO;
     MIGAN_OPAQUE_S(W_); MIGAN_OPAQUE_S(CO_);
+    unsigned lo = lane_off;
+    MIGAN_OPAQUE(lo);                                            // (a 32-bit value across the K loop, not its zero-extended pair)
     const size_t px_bytes = (size_t)CO_ * 4;
     const char* yt = reinterpret_cast<char*>(p.y) + (size_t)ctc.b * img_out_bytes +
                      ((size_t)((ctc.y * 16 + wm * 4) * W_ + ctc.x * 16) * (size_t)CO_ + (size_t)(ctc.n * 256)) * 4;
-    if constexpr ((V & 1) != 0) {
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          // registers 4 k .. 4 k + 3 of a block: rows 8 k + 4 half + {0, 1, 2, 3} of the 32-row block (tile row 2 i + (k >> 1), columns
-          // 8 (k & 1) + 4 half + t), column l31.  After the transpose lane (lane & 3) = t holds row t, columns (l31 & ~3) .. + 3.
-          float nsn[4] = {0.f, 0.f, 0.f, 0.f};
-          if constexpr (HN) {
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-              const float nlo = MIGAN_READLANE(nzl, i * 32 + 8 * k + t), nhi = MIGAN_READLANE(nzl, i * 32 + 8 * k + t + 4);
-              nsn[t] = MIGAN_FMUL_RN(half ? nhi : nlo, ns);
-            }
-          }
-          char* yr = const_cast<char*>(yt) + (size_t)((2 * i + (k >> 1)) * W_ + 8 * (k & 1)) * px_bytes;
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            float a[4];
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-              const float v = acc[i][j][4 * k + t];
-              if constexpr (HN) a[t] = act1(v * acc_scale + nsn[t]);
-              else a[t] = act1g(v, gain_s);
-            }
-            // 4 x 4 transpose over (register t, lane & 3): bit 0, then bit 1
-            const float x0 = MIGAN_QUAD_XOR1(a[0]), x1 = MIGAN_QUAD_XOR1(a[1]), x2 = MIGAN_QUAD_XOR1(a[2]), x3 = MIGAN_QUAD_XOR1(a[3]);
-            const float b0 = odd1 ? x1 : a[0], b1 = odd1 ? a[1] : x0, b2 = odd1 ? x3 : a[2], b3 = odd1 ? a[3] : x2;
-            const float y0 = MIGAN_QUAD_XOR2(b0), y1 = MIGAN_QUAD_XOR2(b1), y2 = MIGAN_QUAD_XOR2(b2), y3 = MIGAN_QUAD_XOR2(b3);
-            const f4 o = {odd2 ? y2 : b0, odd2 ? y3 : b1, odd2 ? b2 : y0, odd2 ? b3 : y1};
-            if (!MIGAN_ABL(1)) store4(at_bytes(reinterpret_cast<float*>(yr + j * 128), lane_off4), o);
-          }
-        }
-      return;
-    }
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -569,7 +402,7 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(kW2Threads, 3) sepconv_wide2_kernel(const 
           float v = acc[i][j][r];
           if constexpr (HN) v = act1(v * acc_scale + nsn);
           else v = act1g(v, gain_s);
-          if (!MIGAN_ABL(1)) store1(at_bytes(reinterpret_cast<float*>(yr + j * 128), lane_off), v);
+          if (!MIGAN_ABL(1)) MIGAN_STORE_NT(at_bytes(reinterpret_cast<float*>(yr + j * 128), lo), v);
         }
       }
   };

@@ -11,6 +11,8 @@ from __future__ import annotations
 
 from typing import Callable, Optional, Tuple
 
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -108,25 +110,61 @@ class OutputGather:
             self.result(slot)
 
 
-def cu_masked_stream(device, reserve_cus: int, total_cus: int = 256, xcds: int = 8):
+def _hip_runtime():
+    """the HIP runtime torch itself has loaded (a second copy opened by its bare name would hand out stream handles torch cannot use)"""
+    import ctypes
+    lib_dir = os.path.join(os.path.dirname(torch.__file__), "lib")
+    for name in ("libamdhip64.so", "libamdhip64.so.7", "libamdhip64.so.6"):
+        path = os.path.join(lib_dir, name)
+        if os.path.exists(path):
+            return ctypes.CDLL(path)
+    return ctypes.CDLL("libamdhip64.so")      # (a system ROCm build of torch links the system runtime)
+
+
+class MaskedStream:
+    """torch.cuda.ExternalStream over a stream made by hipExtStreamCreateWithCUMask; destroyed with the object (or close())"""
+
+    def __init__(self, hip, handle: int, device):
+        self._hip, self._handle = hip, handle
+        self.stream = torch.cuda.ExternalStream(handle, device=device)
+
+    def close(self) -> None:
+        if self._handle:
+            import ctypes
+            self._hip.hipStreamDestroy(ctypes.c_void_p(self._handle))
+            self._handle = 0
+
+    def __del__(self):   # pragma: no cover - interpreter shutdown order
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def cu_masked_stream(device, reserve_cus: int, total_cus: int = 0, xcds: int = 8):
     """A HIP stream restricted to total_cus - reserve_cus compute units (hipExtStreamCreateWithCUMask), wrapped as a
     torch.cuda.ExternalStream: kernels launched on it leave ``reserve_cus`` CUs (reserve_cus / xcds on every XCD) to whatever else
     is running -- here the RCCL kernels of the overlapped output all-gather, which otherwise queue behind layers that fill all
-    256 CUs of an MI355X.  CU i of the mask is bit i (logical CU numbering: XCD = i % xcds, as workgroups are dealt)."""
+    256 CUs of an MI355X.  CU i of the mask is bit i (logical CU numbering: XCD = i % xcds, as workgroups are dealt).
+    total_cus = 0: the device's multiprocessor count.  The returned stream keeps its owner alive (``stream.owner.close()`` destroys it)."""
     import ctypes
+    device = torch.device(device)
+    if total_cus <= 0:
+        total_cus = int(torch.cuda.get_device_properties(device).multi_processor_count)
     if reserve_cus <= 0 or reserve_cus % xcds or reserve_cus >= total_cus:
         raise ValueError(f"reserve_cus must be a positive multiple of {xcds} below {total_cus}")
-    device = torch.device(device)
     per_xcd = reserve_cus // xcds
     words = [0] * ((total_cus + 31) // 32)
     for cu in range(total_cus):
         if cu // xcds >= per_xcd:                      # the first per_xcd CUs of every XCD stay free
             words[cu // 32] |= 1 << (cu % 32)
-    hip = ctypes.CDLL("libamdhip64.so")
+    hip = _hip_runtime()
     stream = ctypes.c_void_p()
     mask = (ctypes.c_uint32 * len(words))(*words)
     with torch.cuda.device(device):
         rc = hip.hipExtStreamCreateWithCUMask(ctypes.byref(stream), ctypes.c_uint32(len(words)), mask)
     if rc != 0:
         raise RuntimeError(f"hipExtStreamCreateWithCUMask failed with {rc}")
-    return torch.cuda.ExternalStream(stream.value, device=device)
+    owner = MaskedStream(hip, stream.value, device)
+    owner.stream.owner = owner
+    return owner.stream

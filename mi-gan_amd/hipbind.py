@@ -102,7 +102,11 @@ class MiganLib:
         # build (-DMIGAN_ABLATE / -DMIGAN_PHASE_PROF) left under this name would otherwise be picked up silently
         if os.path.abspath(self.path) == os.path.abspath(os.path.join(_HERE, "csrc", _LIBNAME)):
             stamp = self.path + ".flags"
-            if os.path.exists(stamp):
+            if not os.path.exists(stamp):
+                import warnings
+                warnings.warn(f"{self.path} has no build stamp ({stamp}): it was not produced by mi-gan_amd/build.py (or its ISA lint never "
+                              f"passed); rebuild with `python -c 'import __graft_entry__ as g; g.build()'`", RuntimeWarning)
+            else:
                 from . import build as _build
                 if open(stamp).read().strip() != _build.flags_digest(()):
                     raise MiganError(f"{self.path} was not built with the product flags (stamp {stamp} differs): rebuild with "

@@ -82,6 +82,8 @@ class MIGAN_Pipeline(torch.nn.Module):
             self._scratch = {}
         buf = self._scratch.get(key)
         if buf is None or buf.numel() < need:
+            if len(self._scratch) >= 8:                    # (stream handles come and go: keep the cache bounded)
+                self._scratch.clear()
             buf = torch.empty(need, dtype=torch.uint8, device=device)
             self._scratch[key] = buf
         return buf

@@ -27,23 +27,31 @@ def kernel_source_sha():
     return h.hexdigest()[:16]
 
 
-def avg_by_kernel(path, counter):
+def sum_by_kernel(path, counter):
     acc = collections.OrderedDict()
     for r in csv.DictReader(open(path)):
         if r["Counter_Name"] == counter and "migan" in r["Kernel_Name"]:
             name = r["Kernel_Name"].replace("void ", "").split("(")[0]
-            acc.setdefault(name, []).append(float(r["Counter_Value"]))
-    return {k: (sum(v) / len(v), len(v)) for k, v in acc.items()}
+            a = acc.setdefault(name, [0.0, 0])
+            a[0] += float(r["Counter_Value"])
+            a[1] += 1
+    return acc
 
 
-fetch = avg_by_kernel(sys.argv[1], "FETCH_SIZE")
-write = avg_by_kernel(sys.argv[2], "WRITE_SIZE")
-out = {"_meta": {"kernel_source_sha": kernel_source_sha(),
-                 "note": "bench.py compares this digest with the sources of the library it runs and reports roofline.traffic_stale"}}
-for k in fetch:
-    f, n = fetch[k]
+fetch = sum_by_kernel(sys.argv[1], "FETCH_SIZE")
+write = sum_by_kernel(sys.argv[2], "WRITE_SIZE")
+# `bench.py --pmc-pass N` dispatches nothing but N + 2 identical forwards, one launch per layer: a kernel symbol that serves exactly one
+# layer has as many dispatches as there were forwards
+conv = [n for k, (_, n) in fetch.items() if "sepconv" in k or "cm_conv" in k]
+forwards = min(conv) if conv else 1
+out = {"_meta": {"kernel_source_sha": kernel_source_sha(), "forwards": forwards,
+                 "note": "per forward of `bench.py --pmc-pass` (the launches the roofline table times); bench.py compares the digest with the "
+                         "sources of the library it runs and reports roofline.traffic_stale"}}
+for k, (f, n) in fetch.items():
     w = write.get(k, (0.0, 0))[0]
-    out[k] = {"fetch_bytes_per_launch": 2.0 * f * 1024.0, "write_bytes_per_launch": w * 1024.0,
-              "hbm_bytes_per_launch": 2.0 * f * 1024.0 + w * 1024.0, "dispatches_sampled": n,
+    per_fwd = (2.0 * f + w) * 1024.0 / forwards
+    out[k] = {"hbm_bytes_per_forward": per_fwd, "launches_per_forward": n / forwards if n % forwards else n // forwards,
+              "fetch_bytes_per_forward": 2.0 * f * 1024.0 / forwards, "write_bytes_per_forward": w * 1024.0 / forwards,
+              "hbm_bytes_per_launch": (2.0 * f + w) * 1024.0 / n, "dispatches_sampled": n,
               "note": "FETCH_SIZE doubled (gfx950 wide-read correction), counters in KiB"}
 json.dump(out, sys.stdout, indent=1)

@@ -23,8 +23,8 @@ def pkg():
     return importlib.import_module("mi-gan_amd")
 
 
-# kernel variants (tuning w2 = 1 + variant): dword stores / 16-byte stores after a quad transpose; every wave of group A issuing DMAs / a loader wave
-@pytest.fixture(autouse=True, params=[1, 2, 5, 9, 10])
+# both forms of the weight-plane ring (tuning w2 = 1: 16-channel halves, 2: whole 32-channel chunks, the default)
+@pytest.fixture(autouse=True, params=[1, 2])
 def small_grids(request, lib):
     lib.set_tuning("w2", request.param)
     lib.set_tuning("w2_min_tiles", 1)
@@ -32,7 +32,7 @@ def small_grids(request, lib):
     yield request.param
     lib.set_tuning("w2_min_tiles", 256)
     lib.set_tuning("pipe_grid", 256)
-    lib.set_tuning("w2", 1)
+    lib.set_tuning("w2", 2)
 
 
 # 8 workgroups: 1, 2 or 3 tiles each (first / steady-state / last tile), border and interior tiles, one and two column chunks
