@@ -117,6 +117,7 @@ struct Tuning {
   int pipe_min_tiles = 256;    // launches with fewer tiles keep the one-tile-per-workgroup kernels
   int w2 = 2;                  // MIGAN_W2=0|1|2: the 256 / 512-channel plain layers on persistent 256-pixel x 256-channel tiles (sepconv_wide2_kernel, round 5)
                                // where a launch has at least w2_min_tiles of them (fp32 storage, f16x2 GEMM, whole 16 x 16 tiles)
+  int w2_pw = 1;               // ... and the pointwise GEMM of the un-fused down=2 layers (Cout = 512) on the same tile
   int w2_min_tiles = 256;      // (one tile per CU; below that the 128-pixel one-tile kernel spreads the launch over more CUs)
   int pipe_min_batch = 1;      // smallest batch that takes them (1: a single-image forward runs them on its 512x512 / 256x256 layers too -- 2048 / 512 tiles;
                                // latency_b1 0.70 -> 0.66 ms; its other layers run the latency tiles, so it is not bit-identical to a batched forward either way)
@@ -408,6 +409,14 @@ inline bool use_wide2(const Geo& g, int cin, int cout, int batch, bool fused_rgb
   if (h % 16 != 0 || w % 16 != 0 || cin % 64 != 0 || cout % 256 != 0) return false;
   return (h / 16) * (w / 16) * (cout / 256) * batch >= tuning().w2_min_tiles;
 }
+// ... and its pointwise form for the second half of a down=2 layer that is not fused (Cout = 512: encoder.b128 / b64 .conv2 of migan-512): the
+// 128-column pointwise tiles re-read their A operand per column chunk (measured traffic 1.70x algorithmic), this one reads it once per 256
+constexpr const char* kWide2PwName = "migan::sepconv_wide2_kernel<3>";
+inline bool use_wide2_pw(const Geo& g, int cin, int cout, int h, int w, int batch, bool has_skip) {
+  if (!tuning().w2 || !tuning().w2_pw || g.mode != MODE_PW || !g.maing || g.stv != 0 || g.gemmv != 2 || has_skip) return false;
+  if (h % 16 != 0 || w % 16 != 0 || cin % 64 != 0 || cout % 256 != 0) return false;
+  return (h / 16) * (w / 16) * (cout / 256) * batch >= tuning().w2_min_tiles;
+}
 inline const char* kernel_name(const Geo& g);
 inline const KernelEntry& pick_kernel(const Geo& g) {
   for (const auto& e : kernel_table())
@@ -508,7 +517,7 @@ inline void prepare_kernels() {
       if (sv == 0) rt_check(rt::allow_dynamic_lds((const void*)wide_fn(t != 0, 0, false, true, true), 160 * 1024), "hipFuncSetAttribute");
       if (sv == 0 && t == 0) rt_check(rt::allow_dynamic_lds((const void*)wide_up_fn(), 160 * 1024), "hipFuncSetAttribute");
       if (sv == 0 && t == 0)
-        for (int v : {0, 1}) rt_check(rt::allow_dynamic_lds((const void*)wide2_fn(v), 160 * 1024), "hipFuncSetAttribute");
+        for (int v : {0, 1, 3}) rt_check(rt::allow_dynamic_lds((const void*)wide2_fn(v), 160 * 1024), "hipFuncSetAttribute");
       rt_check(rt::allow_dynamic_lds((const void*)dwfir_fn(t != 0, sv), 96 * 1024), "hipFuncSetAttribute");
       if (sv) rt_check(rt::allow_dynamic_lds((const void*)dwfir_fn(t != 0, sv + 2), 96 * 1024), "hipFuncSetAttribute");
     }
@@ -610,6 +619,16 @@ inline void launch_sepconv(Geo g, const SepArgs& a, rt::stream_t stream, int n_d
     last_kernel_ref() = wide2_name();
     return;
   }
+  if (use_wide2_pw(g, a.CI, a.CO, a.H, a.W, nd, a.skip != nullptr)) {
+    MIGAN_CHECK(a.wsplit != nullptr, MIGAN_EINVAL, "internal: the 256 x 256 tile kernel needs the fp16 weight planes");
+    SepArgs aw = a;
+    aw.tiles_x = a.W / 16; aw.tiles_y = a.H / 16; aw.nchunks = a.CO / 256;
+    aw.sy = 16; aw.sx = 16; aw.off = 0;
+    const unsigned tiles = (unsigned)(aw.tiles_x * aw.tiles_y * aw.nchunks * a.B);
+    rt_check(rt::launch(wide2_fn(3), aw, std::min(tiles, (unsigned)tuning().pipe_grid), (unsigned)kW2Threads, (size_t)W2Lds::TOTAL, stream), kWide2PwName);
+    last_kernel_ref() = kWide2PwName;
+    return;
+  }
   g.persist = use_persistent(g, a.B, fused_rgb);      // (grid size: the batch actually launched)
   g.torgb = fused_rgb;
   MIGAN_CHECK(!fused_rgb || (g.mode == MODE_NORMAL && !g.fromrgb && g.nchunks == 1), MIGAN_EINVAL,
@@ -629,6 +648,7 @@ inline void launch_sepconv(Geo g, const SepArgs& a, rt::stream_t stream, int n_d
 inline const char* launched_kernel_name(Geo g, int cin, int cout, int batch, bool fused_rgb) {
   if (const PipeEntry* pe = pick_pipe(g, cin, cout, batch, fused_rgb, false)) return pe->name;
   if (use_wide2(g, cin, cout, batch, fused_rgb, false, false)) return wide2_name();
+  if (use_wide2_pw(g, cin, cout, g.tiles_y * g.sy, g.tiles_x * g.sx, batch, false)) return kWide2PwName;      // (maing: whole 8 x 16 tiles)
   g.persist = use_persistent(g, batch, fused_rgb);
   g.torgb = fused_rgb;
   return kernel_name(g);
@@ -1809,6 +1829,7 @@ int migan_set_tuning(const char* key, int value) {
   else if (k == "pipe_min_batch") t.pipe_min_batch = std::max(1, value);
   else if (k == "w2") t.w2 = value;
   else if (k == "w2_min_tiles") t.w2_min_tiles = std::max(1, value);
+  else if (k == "w2_pw") t.w2_pw = value;
   else throw Error(MIGAN_EINVAL, "unknown tuning key: " + k);
   MIGAN_API_END
 }

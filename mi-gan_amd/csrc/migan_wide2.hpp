@@ -47,6 +47,8 @@ MIGAN_DEVICE MIGAN_INLINE float act1g(float v, float gain) {      // act1 with t
   return MIGAN_CLAMP(t, -256.0f, 256.0f);
 }
 
+// V bit 1: the pointwise GEMM of a down=2 layer (reference :155-163 after Downsample2d: the 1x1 on dwfir_kernel's half-resolution output) -- the
+// same ring and MFMA / epilogue code, a 16 x 16 input tile without halo, and x 2^7 + fp16 split in place of the depthwise stage.
 // V bit 0: the weight planes arrive as whole 32-channel chunks (two slots of 32 KB, eight DMA instructions per wave every other sub-step), V = 0:
 // as 16-channel halves (four slots of 16 KB, four instructions per sub-step).  The planes are stored chunk-major [plane][CI/32][CO][32], a
 // row = 64 bytes: a DMA of half rows touches 32 rows x 32 bytes = sixteen half-used cache lines per instruction and measured 195 cycles at
@@ -110,6 +112,8 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(kW2Threads, 3) sepconv_wide2_kernel(const 
     const int lt = tid;
     constexpr int LA = 3;                                  // lookahead of the DMA requests in sub-steps = input / tap ring slots
     constexpr bool B32 = (V & 1) != 0;
+    constexpr bool PW = (V & 2) != 0;                      // pointwise GEMM: no halo, no depthwise stage (second half of a down=2 layer)
+    static_assert(!PW || B32, "the pointwise form is built on the 32-channel-chunk weight ring");
     if (MIGAN_ABL(64)) MIGAN_SETPRIO(2);                   // (measurement builds: the depthwise group ahead of the MFMA waves at issue)
     // ---- input tile of one sub-chunk -> ring slot: 1296 units of 16 bytes = 5 per thread + 4 lanes of every wave (so that each wave
     // issues the same six instructions and one vmcnt count holds for all of them).  The image is a buffer descriptor: a halo pixel
@@ -122,12 +126,20 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(kW2Threads, 3) sepconv_wide2_kernel(const 
     for (int j = 0; j < 6; ++j) {
       const int i = unit_of(j);
       drel[j] = 0xfffff000u;
-      if (i < NITEMS) {
+      if constexpr (PW) {                                  // 1024 units: the tile's 256 pixels x 4 channel quads, four per thread, no padding anywhere
+        if (j < 4) drel[j] = (unsigned)((((i >> 2) >> 4) * p.W + ((i >> 2) & 15)) * CI + (i & 3) * 4) * 4u;
+      } else if (i < NITEMS) {
         const int c4 = i & 3, pix = i >> 2;
         drel[j] = (unsigned)(((pix / IGW) * p.W + (pix % IGW)) * CI + c4 * 4) * 4u;
       }
     }
     auto make_dgoff = [&](int gy0_, int gx0_) {
+      if constexpr (PW) {
+#pragma unroll
+        for (int j = 0; j < 6; ++j) dgoff[j] = drel[j];
+        tile_soff = (unsigned)((gy0_ * p.W + gx0_) * CI) * 4u;
+        return;
+      }
       if (gy0_ >= 1 && gy0_ + 17 <= p.H && gx0_ >= 1 && gx0_ + 17 <= p.W) {
 #pragma unroll
         for (int j = 0; j < 6; ++j) dgoff[j] = drel[j];
@@ -154,8 +166,8 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(kW2Threads, 3) sepconv_wide2_kernel(const 
       const MIGAN_BUF xbuf = MIGAN_MAKE_BUF(reinterpret_cast<const char*>(p.x) + (size_t)b0_ * img_bytes, img_bytes);
       const unsigned soff = tile_soff + (unsigned)(ks * KS) * 4u;
 #pragma unroll
-      for (int j = 0; j < 5; ++j) MIGAN_LDS_DMA16(xbuf, dgoff[j], soff, in_s + (j * AT + wave_u * 64) * 4);
-      MIGAN_LDS_DMA16_IF(tail_lane, xbuf, dgoff[5], soff, in_s + (1280 + wave_u * 4) * 4);
+      for (int j = 0; j < (PW ? 4 : 5); ++j) MIGAN_LDS_DMA16(xbuf, dgoff[j], soff, in_s + (j * AT + wave_u * 64) * 4);
+      if constexpr (!PW) MIGAN_LDS_DMA16_IF(tail_lane, xbuf, dgoff[5], soff, in_s + (1280 + wave_u * 4) * 4);
     };
     // ---- depthwise taps + bias of one sub-chunk: conv1.weight [CI][9], conv1.bias [CI] -> tap-major [9][16] + [16]: 4-byte DMAs (a
     // gather through the lane offsets), 36 + 4 lanes of every wave ----
@@ -165,6 +177,7 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(kW2Threads, 3) sepconv_wide2_kernel(const 
     const unsigned tap_voff = (unsigned)((((wave_u * 36 + lane) & 15) * 9) + ((wave_u * 36 + lane) >> 4)) * 4u;     // unit u = tap * 16 + channel
     const unsigned bias_voff = (unsigned)(wave_u * 4 + lane) * 4u;
     auto dma_taps = [&](int ks, int slot) {
+      if constexpr (PW) return;
       float* w_s = reinterpret_cast<float*>(lds + L::OFF_W + slot * L::TAP_SLOT);
       MIGAN_LDS_DMA4_IF(tap_lane, tbuf, tap_voff, (unsigned)(ks * KS * 9) * 4u, w_s + wave_u * 36);
       MIGAN_LDS_DMA4_IF(tail_lane, bbuf, bias_voff, (unsigned)(ks * KS) * 4u, w_s + 144 + wave_u * 4);
@@ -205,6 +218,21 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(kW2Threads, 3) sepconv_wide2_kernel(const 
     // ---- depthwise 3x3 + bias + act (x 2^7) + fp16 hi/lo split of one sub-chunk: one 4-row strip x 4 channels per thread ------------
     auto depthwise = [&](int slot, int tslot, int abuf) {
       if (MIGAN_ABL(4)) return;
+      if constexpr (PW) {
+        // the input pixels ARE the A operand rows (dwfir_kernel's output: activated, FIR-filtered, fp32): x 2^7, fp16 hi / lo split
+        const float* in_s = reinterpret_cast<const float*>(lds + L::OFF_IN + slot * L::IN_SLOT);
+        char* a_b = lds + L::OFF_A + abuf * L::A_BUF;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int i = lt + j * AT, m = i >> 2, c4 = i & 3;
+          char* d = a_b + m * 32 + (((c4 >> 1) ^ ((m >> 3) & 1)) << 4) + ((c4 & 1) << 3);
+          u2v h1, h2;
+          split2_f16(ld4(in_s + i * 4) * kF16AScale, h1, h2);
+          *reinterpret_cast<u2v*>(d) = h1;
+          *reinterpret_cast<u2v*>(d + 256 * 32) = h2;
+        }
+        return;
+      }
       const float* in_s = reinterpret_cast<const float*>(lds + L::OFF_IN + slot * L::IN_SLOT);
       const float* wc = reinterpret_cast<const float*>(lds + L::OFF_W + tslot * L::TAP_SLOT);
       char* a_b = lds + L::OFF_A + abuf * L::A_BUF;
@@ -282,12 +310,13 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(kW2Threads, 3) sepconv_wide2_kernel(const 
     // B32: a sub-step is 8 instructions (even) or 8 + 8 (odd, with its chunk behind the input and the taps).  An even interval g issued an
     // odd sub-step: its 16 operations may fly, everything older has landed (the previous interval's input and taps); an odd interval issued 8,
     // and the chunk issued the interval before is needed next: only those 8 may fly.
+    constexpr int NEVEN = PW ? 4 : 8, NODD = NEVEN + 8;    // B32: operations of an even / odd sub-step (input [+ taps] [+ the chunk])
     issue(); issue();
     issue();
-    MIGAN_WAIT_VMCNT(B32 ? 24 : 28);                       // input + taps of sub-step 0 (everything issued after them may fly)
+    MIGAN_WAIT_VMCNT(B32 ? NODD + NEVEN : 28);             // input + taps of sub-step 0 (everything issued after them may fly)
     MIGAN_BARRIER_LDS();                                   // P1
     depthwise(0, 0, 0);
-    MIGAN_WAIT_VMCNT(B32 ? 8 : 16);                        // planes of sub-step 0 (of chunk 0), input + taps of sub-step 1
+    MIGAN_WAIT_VMCNT(B32 ? NEVEN : 16);                    // planes of sub-step 0 (of chunk 0), input + taps of sub-step 1
     MIGAN_BARRIER_LDS();                                   // barrier 0: A planes + weight planes of sub-step 0, input + taps of sub-step 1
     int dslot = 1, dtap = 1;
     for (int g = 0; g < G; ++g) {
@@ -302,8 +331,8 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(kW2Threads, 3) sepconv_wide2_kernel(const 
       dslot = dslot + 1 == LA ? 0 : dslot + 1;
       dtap = dtap + 1 == LA ? 0 : dtap + 1;
       if (!more) MIGAN_WAIT_VMCNT(0);
-      else if (B32 && (g & 1)) MIGAN_WAIT_VMCNT(8);        // (the chunk issued an interval ago, behind that interval's input tile, is needed next)
-      else MIGAN_WAIT_VMCNT(16);
+      else if (B32 && (g & 1)) MIGAN_WAIT_VMCNT(NEVEN);    // (the chunk issued an interval ago, behind that interval's input tile, is needed next)
+      else MIGAN_WAIT_VMCNT(B32 ? NODD : 16);
       PPROF_MARK(2);
       MIGAN_BARRIER_LDS();
       PPROF_MARK(3);

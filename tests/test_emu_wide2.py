@@ -72,3 +72,19 @@ def test_bit_identical_to_the_128_pixel_tile(lib, pkg, cin, cout, h, w):
     b = run_sepconv_case(lib, pkg, HostMem(), cin=cin, cout=cout, h=h, w=w, batch=2, noise=True, seed=29)
     assert lib.last_kernel().startswith("migan::sepconv_wide_kernel<")
     assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("cin,cout,h,w,batch", [(256, 512, 32, 32, 2), (512, 512, 32, 64, 3), (64, 256, 32, 32, 5)])
+def test_pointwise_half_of_a_down2_layer(lib, pkg, cin, cout, h, w, batch):
+    """down=2 through the two-kernel form (Cout = 512 has no fused kernel): dwfir_kernel, then the pointwise GEMM on the 256 x 256 tile"""
+    lib.set_tuning("pipe", 7)                       # (no fused down=2 kernel: the 64 -> 256 case would otherwise take it)
+    try:
+        a = run_sepconv_case(lib, pkg, HostMem(), cin=cin, cout=cout, h=h, w=w, batch=batch, down=2, seed=37)
+        assert lib.last_kernel() == "migan::sepconv_wide2_kernel<3>", lib.last_kernel()
+        lib.set_tuning("w2_pw", 0)
+        b = run_sepconv_case(lib, pkg, HostMem(), cin=cin, cout=cout, h=h, w=w, batch=batch, down=2, seed=37)
+        assert lib.last_kernel().startswith("migan::sepconv_kernel<3,"), lib.last_kernel()
+        assert np.array_equal(a, b)
+    finally:
+        lib.set_tuning("pipe", 15)
+        lib.set_tuning("w2_pw", 1)

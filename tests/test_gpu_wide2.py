@@ -63,3 +63,18 @@ def test_bit_identical_to_the_128_pixel_tile_and_run_to_run(lib, pkg, mem, cin, 
     b = run_sepconv_case(lib, pkg, mem, cin=cin, cout=cout, h=h, w=h, batch=batch, noise=True, seed=35)
     assert lib.last_kernel().startswith("migan::sepconv_wide_kernel<"), lib.last_kernel()
     assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("cin,cout,h,batch", [(256, 512, 128, 8), (512, 512, 64, 32)])
+def test_pointwise_half_of_a_down2_layer(lib, pkg, mem, cin, cout, h, batch):
+    """encoder.b128.conv2 / b64.conv2 of migan-512 (down=2, Cout = 512: dwfir_kernel + pointwise GEMM): the 256 x 256 tile against the oracle
+    and bit for bit against the 128-column pointwise tiles"""
+    a = run_sepconv_case(lib, pkg, mem, cin=cin, cout=cout, h=h, w=h, batch=batch, down=2, seed=39)
+    assert lib.last_kernel() == "migan::sepconv_wide2_kernel<3>", lib.last_kernel()
+    lib.set_tuning("w2_pw", 0)
+    try:
+        b = run_sepconv_case(lib, pkg, mem, cin=cin, cout=cout, h=h, w=h, batch=batch, down=2, seed=39)
+        assert lib.last_kernel().startswith("migan::sepconv_kernel<3,"), lib.last_kernel()
+    finally:
+        lib.set_tuning("w2_pw", 1)
+    assert np.array_equal(a, b)
