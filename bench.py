@@ -653,8 +653,17 @@ def rccl_world1(wl, pkg, batch, dev, steps):
             pipe.drain()
             torch.cuda.synchronize()
             el = time.perf_counter() - t0
+            # the same steps without the collective, back to back on the same clocks: what the gather of step i, queued behind the persistent
+            # one-workgroup-per-CU kernels of step i + 1, adds to a step
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                wl["step"]()
+            torch.cuda.synchronize()
+            el0 = time.perf_counter() - t0
         return {"backend": dist.get_backend(), "ranks": dist.get_world_size(), "gathered_equals_forward": same,
                 "ms_per_step": round(el / steps * 1e3, 4), "steps": steps,
+                "ms_per_step_without_gather": round(el0 / steps * 1e3, 4), "gather_exposed_ms": round((el - el0) / steps * 1e3, 4),
+                "gather_mb_per_step": round(float(np.prod(wl["out_shape"])) * torch.empty((), dtype=wl.get("out_dtype", torch.float32)).element_size() / 1e6, 2),
                 "what": "init_process_group('nccl', world_size=1, device_id=...) + OutputGather.submit per step (all_gather_into_tensor on RCCL's stream)"}
     finally:
         if created:

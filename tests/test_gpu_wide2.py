@@ -78,3 +78,27 @@ def test_pointwise_half_of_a_down2_layer(lib, pkg, mem, cin, cout, h, batch):
     finally:
         lib.set_tuning("w2_pw", 1)
     assert np.array_equal(a, b)
+
+
+def test_generator_any_size_with_and_without_the_256_pixel_tile(lib, pkg):
+    """migan-512 at 384 x 640 (forward_any_size), twelve images = two sub-batches of six: the 96 x 160 and 48 x 80 layers have enough 16 x 16
+    tiles for sepconv_wide2_kernel; the images must be the bits a batch of two gives (which runs the 128-pixel tiles) and, with the kernel
+    switched off, the same again"""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("gpu tests need an MI355X (torch.cuda.is_available() is False)")
+    dev = torch.device("cuda", 0)
+    res, seed = 512, 93
+    sd = pkg.synth.make_state_dict(res, seed=seed, regime="export")
+    m = pkg.Generator(resolution=res)
+    m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd.items()}, strict=True)
+    m = m.to(dev).eval()
+    x2 = torch.from_numpy((pkg.synth.normal((2, 4, 384, 640), seed, "xhw") * 0.7).astype(np.float32)).to(dev)
+    with torch.no_grad():                                 # (default threshold: 60 tiles x 6 images >= 256 > 60 x 2)
+        y2 = m.forward_any_size(x2)
+        y12 = m.forward_any_size(x2.repeat(6, 1, 1, 1))
+        lib.set_tuning("w2", 0)
+        y12_off = m.forward_any_size(x2.repeat(6, 1, 1, 1))
+    assert bool(torch.isfinite(y12).all())
+    assert torch.equal(y12, y2.repeat(6, 1, 1, 1))
+    assert torch.equal(y12, y12_off)
