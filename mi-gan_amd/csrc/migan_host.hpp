@@ -103,7 +103,8 @@ struct Tuning {
   int streams = 2;             // MIGAN_STREAMS=1|2: default of migan_set_streams
   int stagger = -1;            // MIGAN_STAGGER: launch index of the first half after which the second half starts (-1: plan default)
   int debug_split = 0;         // diagnostics: keep the two-sub-batch execution in keep-intermediates mode
-  int stagger_pct = 22;        // MIGAN_STAGGER_PCT: the next sub-batch starts after this share of a forward's launches
+  int stagger_pct = 15;        // MIGAN_STAGGER_PCT: the next sub-batch starts after this share of a forward's launches (round 5 sweep, two runs each:
+                               // 5 .. 18 % 3680 - 3693 images/s, 22 % (rounds 2 - 4) 3655 - 3663, 30 % 3655, 40 % 3638)
   int pipe = 15;               // MIGAN_PIPE bit mask: software-pipelined persistent kernels (sepconv_pipe_kernel; fp32 storage, f16x2 GEMM) for
                                // 1 plain (+ fused ToRGB) layers, 2 the fused-FromRGB layer, 4 FIR-up layers, 8 down=2 layers as one fused launch, 16 (off) FIR-up
                                // layers with more than 64 output channels as 64-column chunks, 32 (off) the 256 / 512-channel plain layers as 128-column chunks
