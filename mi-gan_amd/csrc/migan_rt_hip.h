@@ -103,15 +103,8 @@ __device__ __forceinline__ MIGAN_BUF migan_make_buf(const void* p, unsigned byte
 // operation for the inactive lanes)
 #define MIGAN_LDS_DMA16_IF(cond, buf, voff, soff, ldsp) do { if (cond) MIGAN_LDS_DMA16((buf), (voff), (soff), (ldsp)); } while (0)
 #define MIGAN_LDS_DMA4_IF(cond, buf, voff, soff, ldsp) do { if (cond) MIGAN_LDS_DMA4((buf), (voff), (soff), (ldsp)); } while (0)
-// value of lane `src` (0..63, any lane function) of this wave: ds_bpermute_b32
-#define MIGAN_SHFL(v, src) __shfl((v), (src))
 // value of lane k (compile-time constant) of this wave, in a scalar register: v_readlane_b32
 #define MIGAN_READLANE(v, k) __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, (v)), (k)))
-// value of lane (lane ^ 1) / (lane ^ 2): v_mov_b32_dpp quad_perm [1,0,3,2] / [2,3,0,1] (VALU only)
-#define MIGAN_QUAD_XOR1(v) migan_dpp_get<0xB1>(v)
-#define MIGAN_QUAD_XOR2(v) migan_dpp_get<0x4E>(v)
-// s_sleep: this wave yields its issue slots for about 64 n cycles (n a constant, <= 127)
-#define MIGAN_SLEEP(n) __builtin_amdgcn_s_sleep(n)
 // optimisation barrier on a wave-uniform integer (stays in a scalar register)
 #define MIGAN_OPAQUE_S(x) asm volatile("" : "+s"(x))
 

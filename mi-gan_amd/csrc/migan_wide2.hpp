@@ -3,22 +3,27 @@
 // 256-pixel x 256-channel tiles (round 5).  Same arithmetic, operand split and summation order as sepconv_wide_kernel (128 x 256
 // tiles, one tile per workgroup), which it replaces wherever a launch has enough 16 x 16-pixel tiles to fill the chip.
 //
-// Why another tile.  The 128 x 256 kernel is bound by what one CU can pull through its vector-memory pipe: per 32-channel K chunk a
-// workgroup DMAs 23 KB of input tile and 32 KB of weight planes, every byte with ONE chunk period of flight (the double-buffered
-// 145 KB of LDS leave no room for a third slot), and each tile pays its own prologue and a compute-then-store epilogue
-// (profiles/r04_pipe_layers.txt (d), (k): 3.6k cycles per chunk against 1.5k of MFMA time, 8.5 us per tile outside the K loop).  Here:
+// Why another tile.  The 128 x 256 kernel is bound by what one CU can pull through its vector-memory pipeline (one in-order queue of about
+// 48 - 64 KB of requests that drains at the CU's share of HBM while input tiles stream, L2-resident weight planes queueing behind the misses:
+// profiles/r05_wide2.md): per 32-channel K chunk a workgroup DMAs 23 KB of input tile and 32 KB of weight planes, every byte with ONE chunk
+// period of flight (the double-buffered 145 KB of LDS leave no room for a third slot), and each tile pays its own prologue and a
+// compute-then-store epilogue (profiles/r04_pipe_layers.txt (d), (k): 3.6k cycles per chunk against 1.5k of MFMA time, 8.5 us per tile
+// outside the K loop).  Here:
 //   * 16 x 16 pixels per tile: the weight planes -- 58 % of the bytes above -- are streamed once per 256 pixels instead of once per
 //     128, and the halo shrinks from 1.41x to 1.27x: 37 KB per (256 pixels x 16 channels) instead of 55 KB for the same MACs;
-//   * K in sub-chunks of 16 channels: input ring of three slots, weight-plane ring of four, taps ring of three -- every DMA has
-//     TWO to THREE barrier intervals of flight under a counted s_waitcnt vmcnt, with the same MFMA work between barriers as before
-//     (eight MFMA waves x 24 v_mfma_f32_32x32x16_f16 = 1536 cycles per SIMD);
+//   * K in sub-chunks of 16 channels: input ring of three slots, 64 KB of weight-plane ring (two whole 32-channel chunks: whole 64-byte rows
+//     = full cache lines; or four 16-channel halves), taps ring of three -- every DMA has TWO to THREE barrier intervals of flight under a
+//     counted s_waitcnt vmcnt, with the same MFMA work between barriers as before (eight MFMA waves x 24 v_mfma_f32_32x32x16_f16 = 1536
+//     cycles per SIMD);
 //   * one persistent workgroup per CU, 4 depthwise waves (group A, which also issues every DMA) + 8 MFMA waves (group B: 4 row
 //     blocks x 2 column halves, 64 x 128 accumulators = 128 registers each): the ring runs on across tile boundaries (group A is
 //     three sub-chunks ahead with the loads and one ahead with the depthwise stage), so a tile has no prologue of its own;
 //   * the epilogue runs straight from the accumulator registers of group B (C layout: a lane owns one output channel of 16
 //     pixels; per accumulator register the two half-waves store one 128-byte line each) -- no result tile in LDS, no barrier, and
 //     group A's next depthwise stage runs beside it.
-// LDS: 3 x 20.25 KB input + 4 x 16 KB weight planes + 2 x 16 KB A planes + 3 x 640 B taps = 159.1 KB.  fp32 storage, f16x2 GEMM.
+// LDS: 3 x 20.25 KB input + 64 KB weight planes + 2 x 16 KB A planes + 3 x 640 B taps = 159.1 KB.  fp32 storage, f16x2 GEMM.
+// Measured: -22 .. -24 % per layer against the 128 x 256 tile; what bounds it now and the variants that were built, measured and dropped
+// (loader wave, DMAs on the MFMA waves, 16-byte stores, activation + split on the MFMA waves, lookahead 2, stagger): profiles/r05_wide2.md.
 #pragma once
 
 namespace migan {

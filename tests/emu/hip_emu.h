@@ -179,11 +179,7 @@ inline float hipemu_shfl(float v, int src) {
   hipemu::wave_barrier();
   return r;
 }
-#define MIGAN_SHFL(v, src) hipemu_shfl((v), (src))
 #define MIGAN_READLANE(v, k) hipemu_shfl((v), (k))
-#define MIGAN_SLEEP(n) do {} while (0)
-#define MIGAN_QUAD_XOR1(v) __shfl_xor((v), 1)
-#define MIGAN_QUAD_XOR2(v) __shfl_xor((v), 2)
 #define MIGAN_OPAQUE_S(x) asm volatile("" : "+r"(x))
 
 inline bool __all(bool pred) {
