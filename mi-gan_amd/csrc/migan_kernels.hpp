@@ -1876,6 +1876,7 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, 3) dwfir_kernel(const DwFirArgs p) {
       const int xim = xim0 + dx;
       const bool colin = xim >= 0 && xim < p.W;
       float* dp = d_s + (((img * DH + dy0) * DW) + dx) * KC + c4 * 4;
+      f4 dv[2];
 #pragma unroll
       for (int o = 0; o < 2; ++o) {
         f4 sacc = bias;
@@ -1884,13 +1885,16 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, 3) dwfir_kernel(const DwFirArgs p) {
 #pragma unroll
           for (int kx = 0; kx < 3; ++kx) sacc += w[ky * 3 + kx] * win[o + ky][kx];
         const int yim = yim0 + dy0 + o;
-        f4 d = {0.f, 0.f, 0.f, 0.f};                          // FIR zero padding outside the image (reference :67)
-        if (colin && yim >= 0 && yim < p.H) d = act4(sacc);
-        st4(dp + o * DW * KC, d);
+        dv[o] = f4{0.f, 0.f, 0.f, 0.f};                       // FIR zero padding outside the image (reference :67)
+        if (colin && yim >= 0 && yim < p.H) dv[o] = act4(sacc);
       }
+      // separable FIR, vertical half here (round 5; same order as sepconv_pipedown_kernel): row slot dy0 = (1, 3)/8 partial sum of this row
+      // pair (for the output whose window starts with it), row slot dy0 + 1 = (3, 1)/8 (for the output whose window ends with it)
+      st4(dp, 0.125f * dv[0] + 0.375f * dv[1]);
+      st4(dp + DW * KC, 0.375f * dv[0] + 0.125f * dv[1]);
     }
     __syncthreads();
-    // stage 2: 4x4 FIR, stride 2, taps outer([1,3,3,1])/64 (reference Downsample2d :58-76) -> HBM
+    // stage 2: the horizontal half of the 4x4 FIR, stride 2, taps outer([1,3,3,1])/64 (reference Downsample2d :58-76) -> HBM
     for (int it = tid; it < MT * QC; it += kThreads) {
       const int c4 = it & (QC - 1);
       const int m = it >> LG_QC;
@@ -1898,14 +1902,11 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, 3) dwfir_kernel(const DwFirArgs p) {
       if (b0 + img >= p.B || gy0 + oy >= HO || gx0 + ox >= WO) continue;          // ragged batch / ragged image edge
       const float* dp = d_s + ((img * DH + 2 * oy) * DW + 2 * ox) * KC + c4 * 4;
       f4 a = {0.f, 0.f, 0.f, 0.f};
+      // horizontal half: rows 2 oy (partial sum of the pair that opens the window) and 2 oy + 3 (of the pair that closes it), four columns
 #pragma unroll
-      for (int ky = 0; ky < 4; ++ky) {
-        const float fy = (ky == 0 || ky == 3) ? 1.0f : 3.0f;
-#pragma unroll
-        for (int kx = 0; kx < 4; ++kx) {
-          const float fx = (kx == 0 || kx == 3) ? 1.0f : 3.0f;
-          a += (fy * fx * (1.0f / 64.0f)) * ld4(dp + (ky * DW + kx) * KC);
-        }
+      for (int kx = 0; kx < 4; ++kx) {
+        const float fx = (kx == 0 || kx == 3) ? 0.125f : 0.375f;
+        a += fx * (ld4(dp + kx * KC) + ld4(dp + (3 * DW + kx) * KC));
       }
       const unsigned oel = (unsigned)((((img * HO) + gy0 + oy) * WO + gx0 + ox) * p.C + k0 + c4 * 4);
       if constexpr (OUT16) Io<2>::st(reinterpret_cast<char*>(yb), oel * 2u, a * kF16AScale);

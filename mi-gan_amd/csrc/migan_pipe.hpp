@@ -1182,6 +1182,7 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS((NA + NB) * 64, (NA + NB) / 4) sepconv_pip
         const int xim = xim0 + dx;
         const bool colin = xim >= 0 && xim < p.W;
         float* dp = d_s + ((dy0 * 2 + (dx & 1)) * DWP + (dx >> 1)) * KC + c4 * 4;
+        f4 dv[2];
 #pragma unroll
         for (int o = 0; o < 2; ++o) {
           f4 sacc = bias;
@@ -1190,13 +1191,18 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS((NA + NB) * 64, (NA + NB) / 4) sepconv_pip
 #pragma unroll
             for (int kx = 0; kx < 3; ++kx) sacc += w[ky * 3 + kx] * win[o + ky][kx];
           const int yim = yim0 + dy0 + o;
-          f4 d = {0.f, 0.f, 0.f, 0.f};
-          if (colin && yim >= 0 && yim < p.H) d = act4(sacc);
-          st4(dp + o * (2 * DWP * KC), d);
+          dv[o] = f4{0.f, 0.f, 0.f, 0.f};
+          if (colin && yim >= 0 && yim < p.H) dv[o] = act4(sacc);
         }
+        // The FIR is separable ([1,3,3,1]/8 per axis) and its stride-2 window of output row oy is the row pairs oy and oy + 1: the pair's two
+        // vertical partial sums go to LDS instead of its two rows -- taps (1, 3)/8 for the window that STARTS with this pair (row slot 2k),
+        // (3, 1)/8 for the window that ends with it (row slot 2k + 1) -- and stage 2 reads 8 values per output instead of 16 (round 5;
+        // dwfir_kernel sums in the same order)
+        st4(dp, 0.125f * dv[0] + 0.375f * dv[1]);
+        st4(dp + 2 * DWP * KC, 0.375f * dv[0] + 0.125f * dv[1]);
       }
     };
-    // stage 2: 4x4 FIR, stride 2, taps outer([1,3,3,1])/64 (reference Downsample2d :58-76), x 2^7, fp16 hi/lo -> A planes.  (Splitting an
+    // stage 2: the horizontal half of the 4x4 FIR, stride 2, taps outer([1,3,3,1])/64 (reference Downsample2d :58-76), x 2^7, fp16 hi/lo -> A planes.  (Splitting an
     // item's 16 taps over two lanes -- 512 items, eight waves' worth -- measured 4 % slower: profiles/r04_pipe_layers.txt)
     auto stage2 = [&](int abuf) {
       char* a_b = lds + OFF_A + abuf * L::A_BUF;
@@ -1205,14 +1211,12 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS((NA + NB) * 64, (NA + NB) / 4) sepconv_pip
         const int ox = m & (GW - 1), oy = m >> lgGW;
         const float* dp = d_s + ((2 * oy) * 2 * DWP + ox) * KC + c4 * 4;
         f4 a = {0.f, 0.f, 0.f, 0.f};
+        // rows 2 oy (the partial sum of the pair that opens this output's window) and 2 oy + 3 (of the pair that closes it), four columns
 #pragma unroll
-        for (int ky = 0; ky < 4; ++ky) {
-          const float fy = (ky == 0 || ky == 3) ? 1.0f : 3.0f;
-#pragma unroll
-          for (int kx = 0; kx < 4; ++kx) {
-            const float fx = (kx == 0 || kx == 3) ? 1.0f : 3.0f;
-            a += (fy * fx * (1.0f / 64.0f)) * ld4(dp + ((ky * 2 + (kx & 1)) * DWP + (kx >> 1)) * KC);
-          }
+        for (int kx = 0; kx < 4; ++kx) {
+          const float fx = (kx == 0 || kx == 3) ? 0.125f : 0.375f;
+          const float* q = dp + ((kx & 1) * DWP + (kx >> 1)) * KC;
+          a += fx * (ld4(q) + ld4(q + 3 * 2 * DWP * KC));
         }
         u2v h1, h2;
         split2_f16(a * kF16AScale, h1, h2);
