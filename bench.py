@@ -79,7 +79,13 @@ def parse(argv=None):
     ap.add_argument("--reserve-cus", type=int, default=0, metavar="K",
                     help="N>1: run the forward on a HIP stream whose CU mask leaves K CUs (a multiple of 8: K/8 per XCD) to the RCCL "
                          "kernels of the overlapped all-gather, instead of letting them queue behind 256-CU-wide layers "
-                         "(hipExtStreamCreateWithCUMask; implies --streams 1, the library's own side streams are not masked)")
+                         "(hipExtStreamCreateWithCUMask; implies --streams 1, the library's own side streams are not masked).  An "
+                         "experiment knob, measured counterproductive (profiles/r05_contention.md): use multiples of 32 -- one CU per "
+                         "shader engine of every XCD -- or the workgroup dealing becomes unbalanced")
+    ap.add_argument("--occupy", type=str, default="", metavar="WGS,US[,THREADS[,LDS]]",
+                    help="contention probe for the N>1 question on a one-GPU box: after every step a stand-in for the collective's kernel "
+                         "(scripts/ubench/occupy.hip: WGS workgroups that hold their CUs for US microseconds) is launched on its own stream, "
+                         "ordered behind the step like the output gather, so that it overlaps the next step")
     ap.add_argument("--force-pg", action="store_true",
                     help="N=1: also create a one-rank NCCL (= RCCL) process group and time the same steps through the pipelined output "
                          "gather (rccl_world1 on the line): the collective path on the hardware without a second GPU")
@@ -424,6 +430,22 @@ def run_workload(args, rank, local_rank, world, dist, dev):
     # --reserve-cus K: the forward runs on a CU-masked stream so that the RCCL kernels of the overlapped gather find free CUs
     masked = pkg.distributed.cu_masked_stream(dev, args.reserve_cus) if (args.reserve_cus and not args.dry) else None
 
+    occupy = None
+    if args.occupy and not args.dry:
+        import ctypes
+        f = [int(v) for v in args.occupy.split(",")]
+        o_wgs, o_us, o_thr, o_lds = f[0], f[1], (f[2] if len(f) > 2 else 256), (f[3] if len(f) > 3 else 0)
+        o_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "scripts", "ubench", "_bin", "liboccupy.so")
+        if not os.path.exists(o_path):
+            raise SystemExit(f"--occupy needs {o_path}: hipcc --offload-arch=gfx950 -O3 -shared -fPIC scripts/ubench/occupy.hip -o {o_path}")
+        o_lib, o_stream = ctypes.CDLL(o_path), torch.cuda.Stream(dev)
+
+        def occupy():
+            o_stream.wait_stream(torch.cuda.current_stream(dev))
+            rc = o_lib.occupy_launch(ctypes.c_void_p(o_stream.cuda_stream), o_wgs, o_thr, o_lds, o_us)
+            if rc:
+                raise RuntimeError(f"occupy_launch failed with {rc}")
+
     def step():
         if masked is not None:
             masked.wait_stream(torch.cuda.current_stream(dev))
@@ -434,6 +456,8 @@ def run_workload(args, rank, local_rank, world, dist, dev):
             y = wl["step"]()
         if gather:
             pipe.submit(y if y.dtype == gdt else y.to(gdt))
+        if occupy is not None:
+            occupy()
         return y
 
     def fence():
@@ -598,6 +622,8 @@ def run_workload(args, rank, local_rank, world, dist, dev):
         out["gather_dtype"] = str(gdt).replace("torch.", "")
     if args.reserve_cus:
         out["reserved_cus"] = args.reserve_cus
+    if args.occupy:
+        out["occupy"] = args.occupy
     return out
 
 
