@@ -126,3 +126,50 @@ def test_oracles_vs_reference_arbitrary_size_goldens(pkg, golden_dir):
         np.testing.assert_allclose(torc.generator(x, sd, r).numpy(), g["y"], rtol=0, atol=tol, err_msg=os.path.basename(f))
         if hh * ww <= 48 * 80:
             np.testing.assert_allclose(orc.generator(x, sd, r), g["y"], rtol=0, atol=tol, err_msg=os.path.basename(f))
+
+
+# ------------------------------------------------------------------------------------------------ 16-bit storage modes (BASELINE configs[1])
+STORAGE_CASES = ["bf16_r64", "bf16_r64_x2", "f16_r64", "bf16_r256", "bf16_r256_x2"]
+
+
+def _storage_case(pkg, golden_dir, tag):
+    g = np.load(os.path.join(golden_dir, f"storage_{tag}.npz"))
+    r, n, seed = int(g["resolution"]), int(g["batch"]), int(g["seed"])
+    sd = pkg.synth.make_state_dict(r, seed=seed)
+    x = pkg.synth.make_input(n, r, seed=seed)
+    return g, r, sd, x, str(g["storage"]), bool(int(g["gemm16"])), int(g["stride"])
+
+
+@pytest.mark.parametrize("tag", STORAGE_CASES)
+def test_torch_cpu_oracle_storage_modes_equal_the_hooked_reference(pkg, golden_dir, tag):
+    """tests/golden/make_golden_bf16.py runs the REFERENCE module with forward hooks that round each stored feature map (and, for the
+    "f16" GEMM variant, the operands of the 1x1 convolutions) and nothing else.  The torch-CPU oracle in the same mode performs the same
+    torch ops on the same rounded values: it must reproduce those outputs BIT FOR BIT, every stored tensor included.  This is what pins
+    `storage="bf16"` to the reference; the oracle is no longer held to itself."""
+    g, r, sd, x, storage, gemm16, s = _storage_case(pkg, golden_dir, tag)
+    taps = {}
+    y = torc.generator(x, sd, r, taps=taps, storage=storage, gemm16=gemm16).numpy()
+    np.testing.assert_array_equal(y[:, :, ::s, ::s], g["y"])
+    np.testing.assert_array_equal(y.astype(np.float64).sum(axis=(2, 3)), g["y_sum"])
+    n_checked = 0
+    for k in g.files:
+        if k.startswith("tap/") and k[4:] in taps:
+            np.testing.assert_array_equal(_tap_summary(np.asarray(taps[k[4:]])), g[k], err_msg=k)
+            n_checked += 1
+    assert n_checked >= 3 * (int(np.log2(r)) - 1) - 1
+    # the fp32 output recorded beside it is the plain reference forward: the envelope in the fixture is the REFERENCE's own
+    np.testing.assert_allclose(torc.generator(x, sd, r).numpy()[:, :, ::s, ::s], g["y_f32"], rtol=0, atol=3e-5 * float(g["y_absmax"]))
+    assert abs(float(np.abs(g["y"] - g["y_f32"]).max()) - float(g["envelope"])) <= 1e-6 or s > 1
+
+
+@pytest.mark.parametrize("tag", STORAGE_CASES[:3])
+def test_numpy_oracle_storage_modes_sit_in_the_reference_envelope(pkg, golden_dir, tag):
+    """An independent implementation of the same mode (numpy, another summation order) cannot be bit-equal: a 1-ulp difference before a
+    rounding step flips that step, and the flip is as large as the mode's quantisation noise.  What two correct implementations share is
+    the noise LEVEL: max within 2x the envelope the reference itself shows against its fp32 forward, rms of the difference within 2x
+    (two independent realisations of the same noise differ by sqrt(2) x its rms)."""
+    g, r, sd, x, storage, gemm16, s = _storage_case(pkg, golden_dir, tag)
+    y = orc.generator(x, sd, r, storage=storage, gemm16=gemm16)
+    d = (y[:, :, ::s, ::s].astype(np.float64) - g["y"])
+    assert np.abs(d).max() <= 2.0 * float(g["envelope"])
+    assert np.sqrt((d ** 2).mean()) <= 2.0 * float(g["envelope_rms"])
