@@ -139,7 +139,7 @@ inline Tuning& tuning() {
     if (const char* e = std::getenv("MIGAN_STREAMS")) v.streams = std::min(4, std::max(1, std::atoi(e)));
     if (const char* e = std::getenv("MIGAN_STAGGER")) v.stagger = std::atoi(e);
     if (const char* e = std::getenv("MIGAN_PIPE")) v.pipe = std::atoi(e);
-    if (const char* e = std::getenv("MIGAN_W2")) v.w2 = std::atoi(e);
+    if (const char* e = std::getenv("MIGAN_W2")) v.w2 = std::min(2, std::max(0, std::atoi(e)));
     if (const char* e = std::getenv("MIGAN_PIPE_GRID")) v.pipe_grid = std::max(8, std::atoi(e) / 8 * 8);
     return v;
   }();
@@ -592,7 +592,7 @@ inline unsigned grid_of(const Geo& g, int batch, bool fused_rgb = false) {
 }
 
 // name of the kernel launch_sepconv runs for this geometry and batch
-inline const char* launched_kernel_name(Geo g, int cin, int cout, int batch, bool fused_rgb);
+inline const char* launched_kernel_name(Geo g, int cin, int cout, int batch, bool fused_rgb, bool has_skip);
 
 // n_decide: the batch the kernel FORM is chosen for (0 = a.B).  The per-launch timing run launches the whole batch at once but must time the
 // forms the production forward -- sub-batches on staggered streams -- launches.
@@ -646,10 +646,11 @@ inline void launch_sepconv(Geo g, const SepArgs& a, rt::stream_t stream, int n_d
   last_kernel_ref() = k.name;
 }
 
-inline const char* launched_kernel_name(Geo g, int cin, int cout, int batch, bool fused_rgb) {
-  if (const PipeEntry* pe = pick_pipe(g, cin, cout, batch, fused_rgb, false)) return pe->name;
-  if (use_wide2(g, cin, cout, batch, fused_rgb, false, false)) return wide2_name();
-  if (use_wide2_pw(g, cin, cout, g.tiles_y * g.sy, g.tiles_x * g.sx, batch, false)) return kWide2PwName;      // (maing: whole 8 x 16 tiles)
+// (has_skip: the decisions launch_sepconv takes with a.skip != nullptr -- a plain or pointwise layer with a skip tensor keeps the one-tile kernels)
+inline const char* launched_kernel_name(Geo g, int cin, int cout, int batch, bool fused_rgb, bool has_skip) {
+  if (const PipeEntry* pe = pick_pipe(g, cin, cout, batch, fused_rgb, false, has_skip)) return pe->name;
+  if (use_wide2(g, cin, cout, batch, fused_rgb, has_skip, false)) return wide2_name();
+  if (use_wide2_pw(g, cin, cout, g.tiles_y * g.sy, g.tiles_x * g.sx, batch, has_skip)) return kWide2PwName;      // (maing: whole 8 x 16 tiles)
   g.persist = use_persistent(g, batch, fused_rgb);
   g.torgb = fused_rgb;
   return kernel_name(g);
@@ -1172,7 +1173,7 @@ inline void migan_handle::run_range(const migan::Plan& P, const float* x, float*
       const Geo& G = *Gp;
       fill_geo(a, G);
       launch_sepconv(G, a, stream, nd);
-      L.kernel_last = launched_kernel_name(G, L.cin, L.cout, nd, a.trgb_w != nullptr);
+      L.kernel_last = launched_kernel_name(G, L.cin, L.cout, nd, a.trgb_w != nullptr, a.skip != nullptr);
     }
     if (timed) rt_check(rt::event_record(events[2 * li + 1], stream), "hipEventRecord");
     if (!timed && (int)li == mid_after) rt_check(rt::event_record(ev_mid[part], stream), "hipEventRecord");
@@ -1828,9 +1829,9 @@ int migan_set_tuning(const char* key, int value) {
   else if (k == "pipe_dna") t.pipe_dna = value;
   else if (k == "pipe_min_tiles") t.pipe_min_tiles = std::max(1, value);
   else if (k == "pipe_min_batch") t.pipe_min_batch = std::max(1, value);
-  else if (k == "w2") t.w2 = value;
+  else if (k == "w2") t.w2 = std::min(2, std::max(0, value));
   else if (k == "w2_min_tiles") t.w2_min_tiles = std::max(1, value);
-  else if (k == "w2_pw") t.w2_pw = value;
+  else if (k == "w2_pw") t.w2_pw = value != 0;
   else throw Error(MIGAN_EINVAL, "unknown tuning key: " + k);
   MIGAN_API_END
 }

@@ -93,6 +93,7 @@ class MiganLib:
         source through the fiber emulator (tests/emu); the package itself never does, so no environment variable can make the
         product run on anything but the HIP library."""
         self.path = path or library_path()
+        self.stamp_missing = False
         if not os.path.exists(self.path):
             raise MiganError(
                 f"{self.path} not found: the MI355X HIP extension is not built. "
@@ -103,9 +104,13 @@ class MiganLib:
         if os.path.abspath(self.path) == os.path.abspath(os.path.join(_HERE, "csrc", _LIBNAME)):
             stamp = self.path + ".flags"
             if not os.path.exists(stamp):
-                import warnings
-                warnings.warn(f"{self.path} has no build stamp ({stamp}): it was not produced by mi-gan_amd/build.py (or its ISA lint never "
-                              f"passed); rebuild with `python -c 'import __graft_entry__ as g; g.build()'`", RuntimeWarning)
+                # build.py deletes the stamp exactly when the ISA lint has not passed (the packed-fp32 hazard): a library without
+                # one is refused, not warned about -- hand builds opt out explicitly or go under another name
+                if os.environ.get("MIGAN_ALLOW_UNSTAMPED") != "1":
+                    raise MiganError(f"{self.path} has no build stamp ({stamp}): it was not produced by mi-gan_amd/build.py, or its ISA lint never "
+                                     f"passed; rebuild with `python -c 'import __graft_entry__ as g; g.build()'` (MIGAN_ALLOW_UNSTAMPED=1 loads "
+                                     f"a hand build anyway; measurement builds belong under another name via MIGAN_HIP_LIBRARY)")
+                self.stamp_missing = True
             else:
                 from . import build as _build
                 if open(stamp).read().strip() != _build.flags_digest(()):

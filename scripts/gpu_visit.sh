@@ -16,7 +16,7 @@ for what in "$@"; do
     layers) cd $R; timeout 600 python bench.py --no-secondary --cpu-images 0 --no-latency --dump-layers $OUT/layers_$n.json $arg > $OUT/layers_bench_$n.json 2> $OUT/layers_$n.err; echo "layers rc=$?";;
     trace)  cd /tmp; timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/trace_$n -o t --output-format csv -- python $R/bench.py --steps 5 --warmup 2 --cpu-images 0 --no-secondary --no-latency $arg > $OUT/trace_$n.log 2>&1; echo "trace rc=$?";;
     pmc)    cd /tmp; for c in FETCH_SIZE WRITE_SIZE; do timeout 600 rocprofv3 --kernel-trace --pmc $c -d $OUT/pmc_${c}_$n -o pmc --output-format csv -- python $R/bench.py --pmc-pass 4 --cpu-images 0 --no-secondary --no-latency $arg > $OUT/pmc_${c}_$n.log 2>&1; echo "pmc $c rc=$?"; done
-            cd $R; python scripts/pmc_traffic.py $(find $OUT/pmc_FETCH_SIZE_$n -name '*counter_collection.csv' | head -1) $(find $OUT/pmc_WRITE_SIZE_$n -name '*counter_collection.csv' | head -1) > $OUT/pmc_traffic_$n.json; echo "traffic table: $(wc -c < $OUT/pmc_traffic_$n.json) bytes";;
+            cd $R; python scripts/pmc_traffic.py $(find $OUT/pmc_FETCH_SIZE_$n -name '*counter_collection.csv' | head -1) $(find $OUT/pmc_WRITE_SIZE_$n -name '*counter_collection.csv' | head -1) 6 > $OUT/pmc_traffic_$n.json; echo "traffic table: $(wc -c < $OUT/pmc_traffic_$n.json) bytes";;
     cmd)    cd $R; bash -c "$arg" > $OUT/cmd_$n.log 2>&1; echo "cmd rc=$?"; tail -20 $OUT/cmd_$n.log;;
     *) echo "unknown step $what";;
   esac

@@ -119,3 +119,31 @@ def test_roofline_arithmetic_on_synthetic_launches():
     # the table names the sources it was measured on; the line says whether those are the sources of the library that ran
     assert table["_meta"]["kernel_source_sha"] == r["traffic_measured_on"]
     assert r["traffic_stale"] == (r["traffic_measured_on"] != b.kernel_source_sha())
+
+
+def test_line_roofline_describes_the_whole_forward():
+    """`roofline.frac` on the JSON line is the time-weighted fraction over ALL launches (sum of algorithmic bytes /
+    sum of launch durations), with the fraction of the guide's achievable 6.3 TB/s beside it; the dominant kernel symbol is a sub-object
+    that carries its share of the GPU time."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod2", os.path.join(ROOT, "bench.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    batch = 32
+    launches = [dict(layer="a", kernel="k_stream", flops=1e9, mfma_flops=0.5e9, bytes=30e6),
+                dict(layer="b", kernel="k_stream", flops=1e9, mfma_flops=0.5e9, bytes=30e6),
+                dict(layer="c", kernel="k_small", flops=1e8, mfma_flops=1e8, bytes=1e6)]
+    dom = b.roofline_from_launches(launches, [[0.30, 0.30, 0.40]], batch, "f16x2")
+    r = b.forward_roofline(dom, ms_per_step=0.95)
+    b.finish_traffic(r, dom)
+    whole = 32 * 61e6 / 1.0e-3 / 1e9
+    assert r["bound"] == "hbm" and abs(r["achieved"] - whole) < 0.1 and abs(r["frac"] - whole / 8000.0) < 1e-4
+    assert abs(r["frac_of_achievable"] - whole / 6300.0) < 1e-4 and r["achievable_peak"] == 6300.0
+    assert abs(r["frac_of_timed_step"] - 32 * 61e6 / 0.95e-3 / 8e12) < 1e-4
+    d = r["dominant"]
+    assert d["kernel"] == "k_stream" and abs(d["share_of_gpu_time"] - 0.6) < 1e-3 and d["frac"] > r["frac"]
+    assert "kernel" not in r and r["traffic"] is None and "per_kernel" in r and r["whole_forward"]["ms_per_step"] == 0.95
+    # a matrix-bound forward is priced against the GEMM variant's ceiling
+    gemm = [dict(layer="g", kernel="k_gemm", flops=8e9, mfma_flops=8e9, bytes=1e6)]
+    r2 = b.forward_roofline(b.roofline_from_launches(gemm, [[0.9]], batch, "f16x2"), 0.9)
+    assert r2["bound"] == "mfma" and abs(r2["peak"] - 833.3) < 0.1 and abs(r2["frac"] - 32 * 8e9 / 0.9e-3 / 1e12 / 833.3) < 1e-3

@@ -4,6 +4,7 @@ MIGAN_WAIT_VMCNT, so a missing or mis-counted wait of the DMA ring leaves NaN-po
 lanes run to the next collective one after the other, so a missing barrier between the wave groups gives a wrong result too."""
 import importlib
 
+import numpy as np
 import pytest
 
 from tests.emu_util import emu_lib
@@ -123,6 +124,23 @@ def test_fused_down_off_takes_the_two_kernel_form(lib, pkg):
     lib.set_tuning("pipe", 7)
     run_sepconv_case(lib, pkg, HostMem(), cin=64, cout=128, h=16, w=32, batch=2, down=2, seed=11)
     assert lib.last_kernel().startswith("migan::sepconv_kernel<3,"), lib.last_kernel()
+
+
+@pytest.mark.parametrize("cin,cout,h,w,batch", [(64, 128, 16, 32, 2), (128, 256, 24, 64, 2)])
+def test_fused_down_equals_the_two_kernel_form_bit_for_bit(lib, pkg, cin, cout, h, w, batch):
+    """since round 5 both forms of a down=2 layer evaluate the [1,3,3,1]^2 / 64 FIR separably (vertical (1,3)/8 and (3,1)/8
+    partial sums, then the horizontal half) -- another rounding than the 16-tap sum of rounds 1-4, and the same one in both kernels.  The
+    fused launch (sepconv_pipedown_kernel) and dwfir_kernel + pointwise GEMM must therefore stay in lockstep: same bits."""
+    lib.set_tuning("pipe", 15)
+    a = run_sepconv_case(lib, pkg, HostMem(), cin=cin, cout=cout, h=h, w=w, batch=batch, down=2, seed=13)
+    assert lib.last_kernel().startswith(DOWN), lib.last_kernel()
+    lib.set_tuning("pipe", 7)
+    try:
+        b = run_sepconv_case(lib, pkg, HostMem(), cin=cin, cout=cout, h=h, w=w, batch=batch, down=2, seed=13)
+        assert lib.last_kernel().startswith("migan::sepconv_kernel<3,"), lib.last_kernel()
+    finally:
+        lib.set_tuning("pipe", 15)
+    assert np.array_equal(a, b)
 
 @pytest.mark.parametrize("cin,cout,h,w,batch", [(256, 128, 8, 16, 2), (256, 128, 12, 20, 3), (512, 256, 6, 14, 2), (512, 512, 8, 8, 2)])
 def test_fir_up_streamed_weight_planes(lib, pkg, cin, cout, h, w, batch):
