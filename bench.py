@@ -67,6 +67,10 @@ def parse(argv=None):
                     help="activation storage between layers (f32 = the reference's precision; bf16 = BASELINE configs[1])")
     ap.add_argument("--gemm", type=str, default="f16x2", choices=["f16x2", "bf16x3", "f32"])
     ap.add_argument("--streams", type=int, default=2, choices=[1, 2, 3, 4], help="sub-batches / HIP streams per forward (migan)")
+    ap.add_argument("--nan-policy", type=str, default="propagate", choices=["propagate", "clamp"],
+                    help="migan: what lrelu_agc's clamp does with a NaN activation.  propagate (default library): it stays a NaN, as Tensor.clamp in the "
+                         "reference module; clamp (libmigan_hip_nanclamp.so, -DMIGAN_NAN_CLAMP): -256, as the reference's CUDA plugin -- no NaN test "
+                         "in the kernels, ~2 %% faster; finite inputs give the same bits")
     ap.add_argument("--io", type=str, default="f32", choices=["f32", "u8"],
                     help="migan: u8 = uint8 image + mask in, composed uint8 image out (demo.py's pre/post-processing inside the first / "
                          "last kernels, migan_forward_u8); the all-gather then moves uint8 shards (4x fewer bytes)")
@@ -379,7 +383,7 @@ def build_migan(pkg, args, res, batch, dev, rank):
         k, _, v = kv.partition("=")
         pkg.load_library().set_tuning(k, int(v))
     sd = pkg.synth.make_state_dict(res, seed=0, regime="export")
-    model = pkg.Generator(resolution=res, activation_dtype=args.dtype)
+    model = pkg.Generator(resolution=res, activation_dtype=args.dtype, nan_policy=args.nan_policy)
     model.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd.items()})
     model = model.to(dev).eval()
     if args.dtype == "f32":
@@ -422,7 +426,7 @@ def build_migan(pkg, args, res, batch, dev, rank):
             from oracle import migan_prepost as pp
             return torch.from_numpy(pp.compose(ref_y.numpy() if hasattr(ref_y, "numpy") else ref_y, img_np[:n], mask_np[:n]).astype(np.int16))
 
-    return dict(model=model, x=x, step=step, timed=lambda: model.forward_timed(x), launches=model.launch_info,
+    return dict(model=model, x=x, step=step, inplace=(args.io == "f32"), timed=lambda: model.forward_timed(x), launches=model.launch_info,
                 gemm=gemm, cpu_ref=cpu_ref, out_shape=out_shape, out_dtype=out_dtype, post=post,
                 cpu_desc=f"oracle/migan_torch_cpu.py (torch-CPU/oneDNN op-for-op port of the reference module)",
                 traffic=(("profiles/pmc_traffic_latest.json", res == 512 and batch == 32 and args.dtype == "f32" and gemm == "f16x2")
@@ -431,6 +435,9 @@ def build_migan(pkg, args, res, batch, dev, rank):
                 data="synthetic (seeded export-like weights, demo.py-style mask+image batches)",
                 gemm_text=GEMM_TEXT.get(gemm, gemm),
                 extra_cfg=dict({"activation_storage": args.dtype, "streams": args.streams, **({"tuning": args.tune} if args.tune else {}),
+                                "nan_policy": args.nan_policy + (" (a NaN activation stays a NaN, like Tensor.clamp in the reference module, :21-23)"
+                                                                 if args.nan_policy == "propagate" else
+                                                                 " (opt-in build: v_med3_f32 turns a NaN activation into -256, like the reference's CUDA plugin)"),
                                 "weights": "static (migan_assume_static_weights: 1x1 operand planes prepared once)"},
                                **({"io": "uint8 HWC image + mask in, composed uint8 image out (scripts/demo.py:56-66,135-140 inside the "
                                          "first / last kernels); parity in uint8 steps against compose(oracle output)"}
@@ -482,7 +489,11 @@ def run_workload(args, rank, local_rank, world, dist, dev):
     # N > 1: every step's output shards are all-gathered (RCCL) into one of two buffers; the gather of step i runs on
     # RCCL's stream while step i+1 computes, and every gather completes inside the timed region (fence()).
     gdt = gather_dtype_of(args, wl.get("out_dtype", torch.float32))
-    pipe = pkg.distributed.OutputGather(wl["out_shape"], gdt, dev) if gather else None
+    # the migan forward with fp32 output writes straight into the collective's receive buffers, one collective per sub-batch
+    # (OutputGather.forward_and_submit); other producers (uint8 I/O, Co-Mod-GAN, a converted payload) copy their shard in
+    inplace = bool(gather and wl.get("inplace") and gdt == torch.float32 and not args.reserve_cus)
+    chunks = wl["model"].sub_batches(batch, dev) if inplace else None
+    pipe = pkg.distributed.OutputGather(wl["out_shape"], gdt, dev, chunks=chunks) if gather else None
     # --reserve-cus K: the forward runs on a CU-masked stream so that the RCCL kernels of the overlapped gather find free CUs
     masked = pkg.distributed.cu_masked_stream(dev, args.reserve_cus) if (args.reserve_cus and not args.dry) else None
 
@@ -503,6 +514,11 @@ def run_workload(args, rank, local_rank, world, dist, dev):
                 raise RuntimeError(f"occupy_launch failed with {rc}")
 
     def step():
+        if inplace:
+            slot = pipe.forward_and_submit(wl["model"], wl["x"])
+            if occupy is not None:
+                occupy()
+            return pipe.shards(slot)[0]
         if masked is not None:
             masked.wait_stream(torch.cuda.current_stream(dev))
             with torch.cuda.stream(masked):
@@ -686,6 +702,10 @@ def run_workload(args, rank, local_rank, world, dist, dev):
         out["compute_only_ms_per_step"] = round(compute_only, 4)
         out["gather_mb_per_rank_per_step"] = round(float(np.prod(wl["out_shape"])) * torch.empty(0, dtype=gdt).element_size() / 1e6, 1)
         out["gather_dtype"] = str(gdt).replace("torch.", "")
+        out["gather"] = {"in_place": inplace, "collectives_per_step": len(chunks) if chunks else 1, "sub_batches": chunks or [batch],
+                         "note": ("the forward writes its images into the receive buffers of all_gather_into_tensor (no local copy); one collective per "
+                                  "sub-batch, enqueued behind that sub-batch (migan_forward_parts), overlapped with the rest of the step and the next one")
+                                 if inplace else "the step's output is copied into the receive buffer, then gathered (overlapped with the next step)"}
     if args.reserve_cus:
         out["reserved_cus"] = args.reserve_cus
     if args.occupy:
@@ -696,7 +716,8 @@ def run_workload(args, rank, local_rank, world, dist, dev):
 def primary_default(args):
     """the driver's default line: BASELINE configs[2] with nothing overridden"""
     return (args.model == "migan-512" and not args.resolution and not args.batch and args.dtype == "f32" and args.gemm == "f16x2"
-            and args.io == "f32" and not getattr(args, "is_secondary", False) and not args.tune and not args.no_secondary and args.streams == 2)
+            and args.io == "f32" and not getattr(args, "is_secondary", False) and not args.tune and not args.no_secondary and args.streams == 2
+            and args.nan_policy == "propagate")
 
 
 def latency_batch1(wl_model, pkg, res, dev, n=60):
@@ -733,15 +754,18 @@ def rccl_world1(wl, pkg, batch, dev, steps):
         dist.all_reduce(warm)                               # creates the communicator (and prints RCCL's banner) now
         torch.cuda.synchronize()
         flush_c_stdio()
-        pipe = pkg.distributed.OutputGather(wl["out_shape"], wl.get("out_dtype", torch.float32), dev)
+        inplace = bool(wl.get("inplace")) and wl.get("out_dtype", torch.float32) == torch.float32
+        chunks = wl["model"].sub_batches(batch, dev) if inplace else None
+        pipe = pkg.distributed.OutputGather(wl["out_shape"], wl.get("out_dtype", torch.float32), dev, chunks=chunks)
+        submit = (lambda: pipe.forward_and_submit(wl["model"], wl["x"])) if inplace else (lambda: pipe.submit(wl["step"]()))
         with torch.no_grad():
             y = wl["step"]()
-            slot = pipe.submit(y)
+            slot = submit()
             same = bool(torch.equal(pipe.result(slot), y))
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             for _ in range(steps):
-                pipe.submit(wl["step"]())
+                submit()
             pipe.drain()
             torch.cuda.synchronize()
             el = time.perf_counter() - t0
@@ -756,7 +780,11 @@ def rccl_world1(wl, pkg, batch, dev, steps):
                 "ms_per_step": round(el / steps * 1e3, 4), "steps": steps,
                 "ms_per_step_without_gather": round(el0 / steps * 1e3, 4), "gather_exposed_ms": round((el - el0) / steps * 1e3, 4),
                 "gather_mb_per_step": round(float(np.prod(wl["out_shape"])) * torch.empty((), dtype=wl.get("out_dtype", torch.float32)).element_size() / 1e6, 2),
-                "what": "init_process_group('nccl', world_size=1, device_id=...) + OutputGather.submit per step (all_gather_into_tensor on RCCL's stream)"}
+                "in_place": inplace, "collectives_per_step": len(chunks) if chunks else 1,
+                "what": "init_process_group('nccl', world_size=1, device_id=...) + OutputGather.forward_and_submit per step: the forward writes into the "
+                        "receive buffers of all_gather_into_tensor, one collective per sub-batch (migan_forward_parts), on RCCL's stream.  At world "
+                        "size 1 an in-place all-gather has nothing to move: this leg shows that the path runs and what its launches cost a step, "
+                        "not xGMI time or the contention of a real collective (profiles/r05_contention.md measured that with a stand-in kernel)"}
     finally:
         if created:
             dist.destroy_process_group()
@@ -857,7 +885,7 @@ def worker(rank, local_rank, world, args):
         t_primary = time.perf_counter() - t_wall
         name, res, batch = split_model(args)
         if out is not None and world == 1 and not args.no_secondary and args.model == "migan-512" and not args.resolution \
-                and not args.batch and args.dtype == "f32" and args.gemm == "f16x2" and args.io == "f32":
+                and not args.batch and args.dtype == "f32" and args.gemm == "f16x2" and args.io == "f32" and args.nan_policy == "propagate":
             # the default driver run: also time the exact-fp32-MFMA variant of the same workload and the other two
             # single-GPU BASELINE configs, same protocol
             ex = secondary_line(args, gemm="f32", cpu_images=0, steps=max(5, args.steps // 2), warmup=3)
@@ -870,6 +898,13 @@ def worker(rank, local_rank, world, args):
                     ex["roofline"]["whole_forward"]["alg_mfma_flop"] / (ex["ms_per_step"] * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)
                 out["exact_f32"]["note"] = ("same workload with the 1x1 convs on v_mfma_f32_32x32x2_f32 (exact fp32 products): the number "
                                             "comparable to SURVEY's 5 940 images/s fp32-MFMA ceiling")
+            # the opt-in NaN -> -256 build of the same library (no NaN test in the kernels): what the reference-faithful default costs
+            nc = secondary_line(args, nan_policy="clamp", cpu_images=0, steps=max(10, args.steps), warmup=5, no_latency=True)
+            out["value_nan_clamp"] = nc.get("value")
+            out["config"]["value_nan_clamp"] = nc.get("value")
+            out["nan_clamp"] = {"value": nc.get("value"), "ms_per_step": nc.get("ms_per_step"), **({"error": nc["error"]} if "error" in nc else {}),
+                                "note": "same workload, same protocol, Generator(nan_policy='clamp') = libmigan_hip_nanclamp.so (-DMIGAN_NAN_CLAMP); "
+                                        "`value` is the default library, whose clamp propagates a NaN like the reference module's Tensor.clamp"}
             t_exact = time.perf_counter() - t_wall - t_primary
             out["secondary"] = [
                 secondary_line(args, model="migan-256", dtype="bf16", steps=max(10, args.steps), cpu_images=2),

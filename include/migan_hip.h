@@ -168,6 +168,19 @@ int migan_num_launches(const migan_handle* h, int* n);
 int migan_launch_info(const migan_handle* h, int index, const char** layer, const char** kernel,
                       double* flops_per_image, double* mfma_flops_per_image,
                       double* bytes_per_image, int* workgroups_batch1);
+/* Sub-batch hand-over for multi-GPU callers ("split the shard into 2-4 micro-batches and gather chunk k while computing
+ * k+1").  A forward of `batch` images runs as the sub-batches migan_forward_split reports (batches of >= 16 images: two, see
+ * migan_set_streams).  migan_forward_parts is migan_forward with the hand-over made explicit: sub-batch k writes its images to
+ * y_parts[k] ([part_batch[k]][3][R][R], any device address: e.g. this rank's slice of a collective's receive buffer, so that the
+ * all-gather needs no local copy) and, for k >= 1, runs on the CALLER's stream part_streams[k - 1] instead of a stream of the handle.
+ * The streams are NOT joined: whatever the caller enqueues on `stream` after the call is ordered behind sub-batch 0 only, work on
+ * part_streams[k - 1] behind sub-batch k -- so the collective of sub-batch 0's shard can start while sub-batch 1 still computes.  The
+ * caller must make `stream` wait for every part stream before the next forward on this handle / workspace.  No reference counterpart
+ * (the reference has no multi-GPU inference path); mi-gan_amd/distributed.py::OutputGather.forward_and_submit is the caller. */
+int migan_forward_split(const migan_handle* h, int batch, int part_batch[4], int* n_parts);
+int migan_forward_parts(migan_handle* h, const void* x_nchw, void* const* y_parts, int batch,
+                        void* workspace, size_t workspace_bytes, void* stream,
+                        void* const* part_streams, int n_part_streams, int part_batch[4], int* n_parts);
 /* Same as migan_forward, with a hipEvent pair around every launch on `stream`;
  * layer_ms[i] = duration of launch i.  Synchronises the stream before returning. */
 int migan_forward_timed(migan_handle* h, const void* x_nchw, void* y_nchw, int batch,
@@ -237,9 +250,9 @@ const char* migan_last_error(void);
 /* Symbol (as rocprofv3 prints it) of the fused-SeparableConv2d kernel the calling thread launched last, "" before the first launch:
  * which tile form / schedule the plan picked for a layer and batch (diagnostics and tests). */
 const char* migan_last_kernel(void);
-/* What the clamp of lrelu_agc (reference :21-23) does with a NaN in THIS build of the library: "clamp" (default build: v_med3_f32 maps it to
- * -256, like the reference's CUDA plugin bias_act.cu:139) or "propagate" (libmigan_hip_strictnan.so, built with -DMIGAN_STRICT_NAN: a NaN stays
- * a NaN, like Tensor.clamp in the reference module). */
+/* What the clamp of lrelu_agc (reference :21-23) does with a NaN in THIS build of the library: "propagate" (default build: a NaN stays a NaN,
+ * like Tensor.clamp in the reference module -- SURVEY 8c "follow torch") or "clamp" (libmigan_hip_nanclamp.so, built with -DMIGAN_NAN_CLAMP:
+ * v_med3_f32 maps it to -256, like the reference's CUDA plugin bias_act.cu:139; ~2 % faster).  Finite inputs give the same bits in both. */
 const char* migan_nan_policy(void);
 /* "hip:gfx950" for the product library. */
 const char* migan_backend(void);

@@ -30,9 +30,9 @@ SOURCES = [os.path.join(CSRC, f) for f in ("migan_hip.hip", "migan_k_slice.hip",
 ARCH = "gfx950"
 # (GEMM variant, activation storage format) slices of the sepconv_kernel table; 16-bit storage is built for the fp16 GEMM variants (f16x2 = 2, f16 = 3)
 SLICES: Sequence[Tuple[int, int]] = ((0, 0), (1, 0), (2, 0), (2, 1), (2, 2), (3, 1), (3, 2))
-# -fno-honor-nans is NOT used: what happens to a non-finite value is then what the instructions do (v_max_f32 / v_med3_f32:
-# a NaN activation leaves the clamp as -256, like the reference's CUDA plugin bias_act.cu:139) rather than whatever the
-# optimiser derives from "NaNs cannot occur"; pinned by tests/test_gpu_round2.py::test_finite_inputs_give_finite_outputs_and_nan_policy
+# -fno-honor-nans is NOT used: what happens to a non-finite value is what the source says (clamp4 / clamp1, migan_kernels.hpp: a NaN
+# activation stays a NaN like Tensor.clamp in the reference module; -DMIGAN_NAN_CLAMP: v_med3_f32 turns it into -256 like the reference's
+# CUDA plugin bias_act.cu:139), never whatever the optimiser derives from "NaNs cannot occur"; pinned by tests/test_gpu_robust.py
 FLAGS = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC"] + os.environ.get("MIGAN_HIPCC_FLAGS", "").split()
 
 
@@ -114,7 +114,7 @@ def build(force: bool = False, verbose: bool = False, extra: Sequence[str] = (),
     return OUT
 
 
-STRICT_NAN_OUT = os.path.join(CSRC, "libmigan_hip_strictnan.so")
+NAN_CLAMP_OUT = os.path.join(CSRC, "libmigan_hip_nanclamp.so")
 
 
 def _lint_or_reject(path: str) -> None:
@@ -132,8 +132,8 @@ def _lint_or_reject(path: str) -> None:
 
 
 def build_variant(name: str, extra: Sequence[str], force: bool = False, verbose: bool = False, lint: bool = False) -> str:
-    """another build of the same library under libmigan_hip_<name>.so (objects in csrc/_obj_<name>/): the NaN-propagating variant
-    (-DMIGAN_STRICT_NAN) and the measurement builds (scripts/build_variant.py)"""
+    """another build of the same library under libmigan_hip_<name>.so (objects in csrc/_obj_<name>/): the opt-in NaN -> -256 variant
+    (-DMIGAN_NAN_CLAMP) and the measurement builds (scripts/build_variant.py)"""
     out = os.path.join(CSRC, f"libmigan_hip_{name}.so")
     stamp = out + ".flags"
     if (not force and os.path.exists(out) and os.path.exists(stamp) and open(stamp).read().strip() == flags_digest(extra)
@@ -169,9 +169,10 @@ def build_variant(name: str, extra: Sequence[str], force: bool = False, verbose:
     return out
 
 
-def build_strict_nan(force: bool = False, verbose: bool = False) -> str:
-    """libmigan_hip_strictnan.so: the same library with Tensor.clamp's NaN propagation (Generator(nan_policy="propagate"))"""
-    return build_variant("strictnan", ["-DMIGAN_STRICT_NAN"], force=force, verbose=verbose, lint=True)
+def build_nan_clamp(force: bool = False, verbose: bool = False) -> str:
+    """libmigan_hip_nanclamp.so: the same library without the NaN repair of lrelu_agc's clamp (Generator(nan_policy="clamp"): a NaN
+    activation becomes -256 as in the reference's CUDA plugin; the default library propagates it as Tensor.clamp does)"""
+    return build_variant("nanclamp", ["-DMIGAN_NAN_CLAMP"], force=force, verbose=verbose, lint=True)
 
 
 if __name__ == "__main__":

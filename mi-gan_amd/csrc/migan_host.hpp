@@ -847,8 +847,17 @@ struct migan_handle {
   void ensure_aux();
   void run_range(const migan::Plan& P, const float* x, float* y, int n, char* sub_ws, char* shared, rt::stream_t stream,
                  bool timed, int mid_after, int part, const migan_io_u8* u8, int n_geo = 0);
+  // parts (migan_forward_parts): sub-batch k writes its images to parts->y[k] and, for k >= 1, runs on the CALLER's stream parts->streams[k - 1]
+  // instead of the handle's own; the streams are not joined (the caller orders whatever follows behind each of them)
+  struct Parts {
+    void* const* y = nullptr;
+    void* const* streams = nullptr;
+    int n_streams = 0;
+    int* out_n = nullptr;      // [kMaxStreams] images per sub-batch
+    int* out_parts = nullptr;
+  };
   void forward(migan::Plan& P, const float* x, float* y, int batch, void* ws, size_t ws_bytes, rt::stream_t stream, float* ms,
-               int n_ms, const migan_io_u8* u8 = nullptr);
+               int n_ms, const migan_io_u8* u8 = nullptr, const Parts* parts_io = nullptr);
 };
 
 namespace migan {
@@ -1187,10 +1196,10 @@ inline void migan_handle::run_range(const migan::Plan& P, const float* x, float*
 }
 
 inline void migan_handle::forward(migan::Plan& P, const float* x, float* y, int batch, void* ws, size_t ws_bytes,
-                                  rt::stream_t stream, float* ms, int n_ms, const migan_io_u8* u8) {
+                                  rt::stream_t stream, float* ms, int n_ms, const migan_io_u8* u8, const Parts* parts_io) {
   using namespace migan;
   MIGAN_CHECK(committed, MIGAN_ESTATE, "migan_forward before migan_commit");
-  MIGAN_CHECK((x || u8) && (y || u8) && batch > 0, MIGAN_EINVAL, "null tensor or empty batch");
+  MIGAN_CHECK((x || u8) && (y || u8 || parts_io) && batch > 0, MIGAN_EINVAL, "null tensor or empty batch");
   MIGAN_CHECK(ws != nullptr, MIGAN_EINVAL, "null workspace");
   MIGAN_CHECK(ws_bytes >= workspace_bytes(P, batch), MIGAN_EINVAL, "workspace too small for this batch");
   DeviceGuard guard(device);
@@ -1239,6 +1248,16 @@ inline void migan_handle::forward(migan::Plan& P, const float* x, float* y, int 
   const int n_production = nsub[0];              // what a launch of the throughput path covers
   if (timed) { nsub[0] = batch; parts = 1; }     // per-launch durations: one stream, whole-batch launches (the split workspace always fits them)
   const size_t in_img = (size_t)4 * P.H * P.W, out_img = (size_t)3 * P.H * P.W;
+  if (parts_io) {
+    MIGAN_CHECK(!timed && !u8 && parts_io->y && parts_io->out_n && parts_io->out_parts, MIGAN_EINVAL, "migan_forward_parts: bad argument");
+    MIGAN_CHECK(parts_io->n_streams >= parts - 1 && (parts == 1 || parts_io->streams), MIGAN_EINVAL,
+                "migan_forward_parts: one caller stream per sub-batch after the first is needed (migan_forward_split says how many)");
+    for (int k = 0; k < parts; ++k) {
+      MIGAN_CHECK(parts_io->y[k] != nullptr, MIGAN_EINVAL, "migan_forward_parts: null output of a sub-batch");
+      parts_io->out_n[k] = nsub[k];
+    }
+    *parts_io->out_parts = parts;
+  }
   if (parts > 1) {
     // staggered sub-batches on separate streams: sub-batch k+1 starts when sub-batch k is `stagger` launches in, so the
     // small-resolution layers of one (a few dozen workgroups each) and the tail of every launch run beside full-size layers
@@ -1247,7 +1266,7 @@ inline void migan_handle::forward(migan::Plan& P, const float* x, float* y, int 
     int done = 0;
     char* sub = sub0;
     for (int k = 0; k < parts; ++k) {
-      rt::stream_t sk = k == 0 ? stream : aux_stream[k - 1];
+      rt::stream_t sk = k == 0 ? stream : (parts_io ? (rt::stream_t)parts_io->streams[k - 1] : aux_stream[k - 1]);
       if (k > 0) rt_check(rt::stream_wait_event(sk, ev_mid[k - 1]), "hipStreamWaitEvent");
       migan_io_u8 uk{};
       if (u8) {
@@ -1255,15 +1274,18 @@ inline void migan_handle::forward(migan::Plan& P, const float* x, float* y, int 
         uk.mask = (const unsigned char*)u8->mask + (size_t)done * P.H * P.W;
         uk.out = (unsigned char*)u8->out + (size_t)done * P.H * P.W * 3;
       }
-      run_range(P, x ? x + (size_t)done * in_img : nullptr, y ? y + (size_t)done * out_img : nullptr, nsub[k], sub, shared, sk, false,
+      float* yk = parts_io ? static_cast<float*>(parts_io->y[k]) : (y ? y + (size_t)done * out_img : nullptr);
+      run_range(P, x ? x + (size_t)done * in_img : nullptr, yk, nsub[k], sub, shared, sk, false,
                 k + 1 < parts ? P.stagger : -1, k, u8 ? &uk : nullptr);
-      if (k > 0) rt_check(rt::event_record(ev_join[k - 1], sk), "hipEventRecord");
+      if (k > 0 && !parts_io) rt_check(rt::event_record(ev_join[k - 1], sk), "hipEventRecord");
       sub += sub_bytes(P, nsub[k]);
       done += nsub[k];
     }
-    for (int k = 1; k < parts; ++k) rt_check(rt::stream_wait_event(stream, ev_join[k - 1]), "hipStreamWaitEvent");
+    // (migan_forward_parts: no join -- the caller owns the other streams and orders what follows behind each sub-batch)
+    if (!parts_io)
+      for (int k = 1; k < parts; ++k) rt_check(rt::stream_wait_event(stream, ev_join[k - 1]), "hipStreamWaitEvent");
   } else {
-    run_range(P, x, y, nsub[0], sub0, shared, stream, timed, -1, 0, u8, timed ? n_production : 0);
+    run_range(P, x, parts_io ? static_cast<float*>(parts_io->y[0]) : y, nsub[0], sub0, shared, stream, timed, -1, 0, u8, timed ? n_production : 0);
   }
   if (timed) {
     rt_check(rt::stream_sync(stream), "hipStreamSynchronize");
@@ -1454,6 +1476,28 @@ int migan_forward(migan_handle* h, const void* x, void* y, int batch, void* ws, 
   MIGAN_API_BEGIN
   MIGAN_CHECK(h, MIGAN_EINVAL, "null handle");
   h->forward(h->plan, static_cast<const float*>(x), static_cast<float*>(y), batch, ws, ws_bytes, (rt::stream_t)stream, nullptr, 0);
+  MIGAN_API_END
+}
+
+int migan_forward_split(const migan_handle* h, int batch, int part_batch[4], int* n_parts) {
+  MIGAN_API_BEGIN
+  MIGAN_CHECK(h && part_batch && n_parts && batch > 0, MIGAN_EINVAL, "bad argument");
+  int n[migan_handle::kMaxStreams] = {0, 0, 0, 0};
+  *n_parts = h->split(batch, n);
+  for (int k = 0; k < 4; ++k) part_batch[k] = k < *n_parts ? n[k] : 0;
+  MIGAN_API_END
+}
+
+int migan_forward_parts(migan_handle* h, const void* x, void* const* y_parts, int batch, void* ws, size_t ws_bytes, void* stream,
+                        void* const* part_streams, int n_part_streams, int part_batch[4], int* n_parts) {
+  MIGAN_API_BEGIN
+  MIGAN_CHECK(h && y_parts && part_batch && n_parts, MIGAN_EINVAL, "null argument");
+  migan_handle::Parts io;
+  io.y = y_parts; io.streams = part_streams; io.n_streams = n_part_streams;
+  int n[migan_handle::kMaxStreams] = {0, 0, 0, 0};
+  io.out_n = n; io.out_parts = n_parts;
+  h->forward(h->plan, static_cast<const float*>(x), nullptr, batch, ws, ws_bytes, (rt::stream_t)stream, nullptr, 0, nullptr, &io);
+  for (int k = 0; k < 4; ++k) part_batch[k] = n[k];
   MIGAN_API_END
 }
 
@@ -1839,10 +1883,10 @@ int migan_set_tuning(const char* key, int value) {
 const char* migan_last_error(void) { return migan::last_error_ref().c_str(); }
 const char* migan_last_kernel(void) { return migan::last_kernel_ref(); }
 const char* migan_nan_policy(void) {
-#ifdef MIGAN_STRICT_NAN
-  return "propagate";
-#else
+#ifdef MIGAN_NAN_CLAMP
   return "clamp";
+#else
+  return "propagate";
 #endif
 }
 const char* migan_backend(void) { return rt::backend_name(); }

@@ -107,25 +107,51 @@ struct NoiseArgs {
 // lrelu_agc(alpha=0.2, gain=sqrt(2), clamp=256), reference :20-28: leaky_relu, fp32 multiply by
 // float(np.sqrt(2)), clamp.  max(v, 0.2v) == (v > 0 ? v : 0.2v) for every finite v; the two
 // multiplies stay separate so results round exactly like the reference's three passes.
+// The clamp of lrelu_agc (reference :21-23) on four values / one value.  v_med3_f32 returns the lower bound for a NaN; Tensor.clamp in the
+// reference module keeps it a NaN, and so does this (default) build, at half an instruction per value: one v_cmp_u_f32 tests TWO values
+// (unordered(a, b) holds iff a or b is a NaN), the wave branches on the ballot, and only a wave that holds a NaN runs the per-value
+// compare + select.  Finite data never takes the branch.  Measured on MI355X (profiles/r06_nan_policy.md): -2.1 % on the migan-512 forward
+// against the bare v_med3_f32 (-DMIGAN_NAN_CLAMP, the opt-in build); compare + select on every value (rounds 4-5) cost -4.1 %.
+MIGAN_DEVICE MIGAN_INLINE f4 clamp4(f4 t, float lo, float hi) {
+  f4 c = f4{MIGAN_CLAMP(t.x, lo, hi), MIGAN_CLAMP(t.y, lo, hi), MIGAN_CLAMP(t.z, lo, hi), MIGAN_CLAMP(t.w, lo, hi)};
+#ifndef MIGAN_NAN_CLAMP
+  if (MIGAN_ANY_LANE(__builtin_isunordered(t.x, t.y) | __builtin_isunordered(t.z, t.w))) {
+    MIGAN_COLD_PATH();
+    c.x = t.x != t.x ? t.x : c.x;
+    c.y = t.y != t.y ? t.y : c.y;
+    c.z = t.z != t.z ? t.z : c.z;
+    c.w = t.w != t.w ? t.w : c.w;
+  }
+#endif
+  return c;
+}
+MIGAN_DEVICE MIGAN_INLINE float clamp1(float t, float lo, float hi) {
+  float c = MIGAN_CLAMP(t, lo, hi);
+#ifndef MIGAN_NAN_CLAMP
+  if (MIGAN_ANY_LANE(t != t)) {
+    MIGAN_COLD_PATH();
+    c = t != t ? t : c;
+  }
+#endif
+  return c;
+}
 MIGAN_DEVICE MIGAN_INLINE float act1(float v) {
   float t = fmaxf(v, v * 0.2f);
   t = t * 1.41421356237309515f;
-  return MIGAN_CLAMP(t, -256.0f, 256.0f);
+  return clamp1(t, -256.0f, 256.0f);
 }
 MIGAN_DEVICE MIGAN_INLINE f4 act4(f4 v) {
   // vector form so the two multiplies become v_pk_mul_f32 (2 instead of 4 VALU issues each)
   f4 t = __builtin_elementwise_max(v, v * 0.2f);
   t = t * 1.41421356237309515f;
-  return f4{MIGAN_CLAMP(t.x, -256.0f, 256.0f), MIGAN_CLAMP(t.y, -256.0f, 256.0f), MIGAN_CLAMP(t.z, -256.0f, 256.0f),
-            MIGAN_CLAMP(t.w, -256.0f, 256.0f)};
+  return clamp4(t, -256.0f, 256.0f);
 }
 
 // act4 with the gain pre-multiplied by a power of two s: act4g(v, fl(sqrt2 * s)) == act4(v * s) exactly
 MIGAN_DEVICE MIGAN_INLINE f4 act4g(f4 v, float gain) {
   f4 t = __builtin_elementwise_max(v, v * 0.2f);
   t = t * gain;
-  return f4{MIGAN_CLAMP(t.x, -256.0f, 256.0f), MIGAN_CLAMP(t.y, -256.0f, 256.0f), MIGAN_CLAMP(t.z, -256.0f, 256.0f),
-            MIGAN_CLAMP(t.w, -256.0f, 256.0f)};
+  return clamp4(t, -256.0f, 256.0f);
 }
 
 // ---- error-compensated bf16 GEMM operands -----------------------------------------------------
@@ -169,8 +195,7 @@ MIGAN_DEVICE MIGAN_INLINE f4 act4_scaled(f4 v) {
   constexpr float sc = (float)(1 << S);
   f4 t = __builtin_elementwise_max(v, v * 0.2f);
   t = t * (1.41421356237309515f * sc);
-  return f4{MIGAN_CLAMP(t.x, -256.0f * sc, 256.0f * sc), MIGAN_CLAMP(t.y, -256.0f * sc, 256.0f * sc),
-            MIGAN_CLAMP(t.z, -256.0f * sc, 256.0f * sc), MIGAN_CLAMP(t.w, -256.0f * sc, 256.0f * sc)};
+  return clamp4(t, -256.0f * sc, 256.0f * sc);
 }
 
 MIGAN_DEVICE MIGAN_INLINE f4 ld4(const float* p) { return *reinterpret_cast<const f4*>(p); }

@@ -194,9 +194,10 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(pipe_threads(NA), (NA + kPipeBWaves) / 4) 
       c = MIGAN_MFMA_BF16_32X32X16(a, b[0], c);
       float* o = in_s + (u * 32 + 4 * bhalf) * KC + bl31;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float v = c[r];                                                   // = gain * fromrgb(x)
-        o[((r & 3) + 8 * (r >> 2)) * KC] = MIGAN_CLAMP(fmaxf(v, v * 0.2f), -256.0f, 256.0f);
+      for (int q = 0; q < 4; ++q) {
+        const f4 v = f4{c[4 * q], c[4 * q + 1], c[4 * q + 2], c[4 * q + 3]};      // = gain * fromrgb(x)
+        const f4 a4 = clamp4(__builtin_elementwise_max(v, v * 0.2f), -256.0f, 256.0f);
+        o[(8 * q) * KC] = a4.x; o[(8 * q + 1) * KC] = a4.y; o[(8 * q + 2) * KC] = a4.z; o[(8 * q + 3) * KC] = a4.w;
       }
     }
   };

@@ -46,11 +46,6 @@ struct W2Lds {
 
 template <int N> struct W2Int { static constexpr int value = N; };
 
-MIGAN_DEVICE MIGAN_INLINE float act1g(float v, float gain) {      // act1 with the gain pre-multiplied by a power of two (see act4g)
-  float t = fmaxf(v, v * 0.2f);
-  t = t * gain;
-  return MIGAN_CLAMP(t, -256.0f, 256.0f);
-}
 
 // V bit 1: the pointwise GEMM of a down=2 layer (reference :155-163 after Downsample2d: the 1x1 on dwfir_kernel's half-resolution output) -- the
 // same ring and MFMA / epilogue code, a 16 x 16 input tile without halo, and x 2^7 + fp16 split in place of the depthwise stage.
@@ -431,12 +426,15 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(kW2Threads, 3) sepconv_wide2_kernel(const 
           nsn = MIGAN_FMUL_RN(half ? nhi : nlo, ns);               // product rounded first, reference :166
         }
         char* yr = const_cast<char*>(yt) + (size_t)((2 * i + (rr >> 4)) * W_ + (rr & 15)) * px_bytes;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          float v = acc[i][j][r];
-          if constexpr (HN) v = act1(v * acc_scale + nsn);
-          else v = act1g(v, gain_s);
-          if (!MIGAN_ABL(1)) MIGAN_STORE_NT(at_bytes(reinterpret_cast<float*>(yr + j * 128), lo), v);
+        // (the four column blocks of a row as one vector: the clamp's NaN test covers two values per compare, clamp4)
+        f4 v = f4{acc[i][0][r], acc[i][1][r], acc[i][2][r], acc[i][3][r]};
+        if constexpr (HN) v = act4(v * acc_scale + nsn);
+        else v = act4g(v, gain_s);
+        if (!MIGAN_ABL(1)) {
+          MIGAN_STORE_NT(at_bytes(reinterpret_cast<float*>(yr), lo), v.x);
+          MIGAN_STORE_NT(at_bytes(reinterpret_cast<float*>(yr + 128), lo), v.y);
+          MIGAN_STORE_NT(at_bytes(reinterpret_cast<float*>(yr + 256), lo), v.z);
+          MIGAN_STORE_NT(at_bytes(reinterpret_cast<float*>(yr + 384), lo), v.w);
         }
       }
   };

@@ -67,47 +67,128 @@ def sharded_forward(forward: Callable[..., torch.Tensor], x_global, group=None, 
 
 
 class OutputGather:
-    """Double-buffered asynchronous all-gather of equal-size output shards.
+    """Double-buffered asynchronous all-gather of equal-size output shards, IN PLACE and per sub-batch.
 
-    ``submit(y_local)`` starts the gather of one batch on the backend's communication stream (RCCL: its own HIP
-    stream, ordered after the kernels that produced ``y_local``) and returns a slot; the caller goes on to compute
-    the next batch, so at N > 1 the collective (100 MB per GPU and batch at 32 x 3 x 512 x 512 fp32) overlaps the
-    next forward instead of adding to it.  ``result(slot)`` waits for that gather and returns the gathered tensor
-    (valid until the slot is reused, ``depth`` submits later); ``drain()`` waits for everything in flight.
+    Every slot owns the receive buffers of the collective; ``shards(slot)`` hands out this rank's slices of them and the forward writes
+    its images straight there (``Generator.forward(x, out=...)`` / ``forward_parts``), so ``all_gather_into_tensor`` runs in place: no
+    local copy of the shard (100.7 MB per step at 32 x 3 x 512 x 512 fp32), and at world size 1 no data movement at all.
+
+    ``chunks`` = the sub-batch sizes of the forward (``Generator.sub_batches(n)``, e.g. [16, 16]): one receive buffer and one collective
+    per sub-batch ("split the shard into 2-4 micro-batches and gather chunk k while computing k+1").  ``forward_and_submit``
+    runs ``Generator.forward_parts`` and enqueues the collective of sub-batch k right behind that sub-batch -- sub-batch 0's shard goes out
+    over xGMI while sub-batch 1 still computes, and the gathers of step i overlap step i+1.  ``submit(y_local)`` is the copying form for
+    producers that cannot write in place (uint8 I/O, Co-Mod-GAN): one copy into the slot's shard views, then the same collectives.
+
+    ``result(slot)`` waits for that slot's collectives and returns the gathered tensor in rank order ([world * n, ...]; zero-copy with
+    one chunk, assembled from the chunk buffers otherwise -- ``result_chunks`` returns the [world, n_k, ...] views without a copy), valid
+    until the slot is reused ``depth`` submits later; ``drain()`` waits for everything in flight.
     """
 
-    def __init__(self, shard_shape, dtype, device, group=None, depth: int = 2):
+    def __init__(self, shard_shape, dtype, device, group=None, depth: int = 2, chunks=None):
         if not dist.is_initialized():
             raise RuntimeError("OutputGather needs an initialised process group")
         self.group = group
         self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
         shard_shape = tuple(shard_shape)
-        self.bufs = [torch.empty((self.world * shard_shape[0],) + shard_shape[1:], dtype=dtype, device=device)
-                     for _ in range(max(1, depth))]
-        self.works = [None] * len(self.bufs)
-        self.keep = [None] * len(self.bufs)          # the local shard must stay alive until its gather completed
+        self.n = int(shard_shape[0])
+        self.chunks = [int(c) for c in (chunks or [self.n])]
+        if sum(self.chunks) != self.n or any(c <= 0 for c in self.chunks):
+            raise ValueError(f"chunks {self.chunks} do not partition the shard of {self.n} images")
+        self.device = torch.device(device)
+        rest = shard_shape[1:]
+        # one receive buffer per (slot, chunk): [world * n_k, ...]; this rank's slice of it is where the forward writes
+        self.bufs = [[torch.empty((self.world * c,) + rest, dtype=dtype, device=device) for c in self.chunks] for _ in range(max(1, depth))]
+        self.works = [[None] * len(self.chunks) for _ in self.bufs]
+        self.keep = [None] * len(self.bufs)          # a copied-from local shard must stay alive until its copy was enqueued
         self.next = 0
+        self.part_streams = []
+        if self.device.type == "cuda" and len(self.chunks) > 1:
+            self.part_streams = [torch.cuda.Stream(self.device) for _ in self.chunks[1:]]
 
-    def submit(self, y_local: torch.Tensor) -> int:
+    # ---- slots --------------------------------------------------------------------------------------------------------------------
+    def _take_slot(self) -> int:
         slot = self.next
         self.next = (slot + 1) % len(self.bufs)
-        if self.works[slot] is not None:             # the buffer is about to be overwritten
-            self.works[slot].wait()
-        y_local = y_local.contiguous()
-        self.keep[slot] = y_local
-        self.works[slot] = dist.all_gather_into_tensor(self.bufs[slot], y_local, group=self.group, async_op=True)
+        self._wait(slot)                              # the buffers are about to be overwritten
         return slot
 
+    def _wait(self, slot: int) -> None:
+        for k, w in enumerate(self.works[slot]):
+            if w is not None:
+                w.wait()
+                self.works[slot][k] = None
+        self.keep[slot] = None
+
+    def shards(self, slot: int):
+        """this rank's slice of every chunk buffer of `slot`: [n_k, ...] views the producer writes into"""
+        return [b[self.rank * c:(self.rank + 1) * c] for b, c in zip(self.bufs[slot], self.chunks)]
+
+    def _gather_chunk(self, slot: int, k: int):
+        c = self.chunks[k]
+        buf = self.bufs[slot][k]
+        return dist.all_gather_into_tensor(buf, buf[self.rank * c:(self.rank + 1) * c], group=self.group, async_op=True)
+
+    # ---- producers ----------------------------------------------------------------------------------------------------------------
+    def submit(self, y_local: torch.Tensor) -> int:
+        """copying form: y_local [n, ...] -> the slot's shard views (skipped where it already lives there), then one collective per chunk"""
+        slot = self._take_slot()
+        views = self.shards(slot)
+        lo = 0
+        for k, (v, c) in enumerate(zip(views, self.chunks)):
+            src = y_local[lo:lo + c]
+            if src.data_ptr() != v.data_ptr():
+                v.copy_(src)
+            lo += c
+        self.keep[slot] = y_local
+        for k in range(len(self.chunks)):
+            self.works[slot][k] = self._gather_chunk(slot, k)
+        return slot
+
+    def forward_and_submit(self, model, x: torch.Tensor) -> int:
+        """the in-place form for mi-gan_amd's Generator: the forward writes its images into the receive buffers, sub-batch by sub-batch, and
+        each sub-batch's collective is enqueued right behind it"""
+        slot = self._take_slot()
+        outs = self.shards(slot)
+        if len(outs) == 1:
+            model(x, out=outs[0])
+            self.works[slot][0] = self._gather_chunk(slot, 0)
+            return slot
+        on_gpu = self.device.type == "cuda"            # (a CPU device: the gloo tests drive this path with a stand-in model and no streams)
+        cur = torch.cuda.current_stream(self.device) if on_gpu else None
+        for s in self.part_streams:
+            s.wait_stream(cur)                        # (whatever produced x and freed the workspace is behind us on the current stream)
+        sizes = model.forward_parts(x, outs, self.part_streams)
+        if list(sizes) != self.chunks:
+            raise RuntimeError(f"the forward ran sub-batches {list(sizes)}, this gather was built for {self.chunks}")
+        # the process group's communication stream picks up the CURRENT stream's position: sub-batch 0 here, sub-batch k on its own stream
+        self.works[slot][0] = self._gather_chunk(slot, 0)
+        for k in range(1, len(self.chunks)):
+            if on_gpu:
+                with torch.cuda.stream(self.part_streams[k - 1]):
+                    self.works[slot][k] = self._gather_chunk(slot, k)
+            else:
+                self.works[slot][k] = self._gather_chunk(slot, k)
+        for s in self.part_streams:
+            cur.wait_stream(s)                        # the join migan_forward_parts leaves to its caller
+        return slot
+
+    # ---- consumers ----------------------------------------------------------------------------------------------------------------
+    def result_chunks(self, slot: int):
+        """[world, n_k, ...] view of every chunk buffer of `slot` (no copy), after its collectives completed"""
+        self._wait(slot)
+        return [b.view((self.world, c) + tuple(b.shape[1:])) for b, c in zip(self.bufs[slot], self.chunks)]
+
     def result(self, slot: int) -> torch.Tensor:
-        if self.works[slot] is not None:
-            self.works[slot].wait()
-            self.works[slot] = None
-            self.keep[slot] = None
-        return self.bufs[slot]
+        """the gathered batch in rank order, [world * n, ...]"""
+        parts = self.result_chunks(slot)
+        if len(parts) == 1:
+            return self.bufs[slot][0]
+        return torch.cat(parts, dim=1).reshape((self.world * self.n,) + tuple(parts[0].shape[2:]))
 
     def drain(self) -> None:
         for slot in range(len(self.bufs)):
-            self.result(slot)
+            self._wait(slot)
 
 
 def _hip_runtime():

@@ -68,7 +68,7 @@ EXPORTS = (
     "migan_forward_timed", "migan_set_debug", "migan_debug_tensor", "migan_sepconv_forward",
     "migan_pack_input", "migan_compose_output",
     "migan_pipeline_mask_resize", "migan_pipeline_scratch_bytes", "migan_pipeline_bbox", "migan_pipeline_pre", "migan_pipeline_post",
-    "migan_set_tuning", "migan_last_error", "migan_last_kernel", "migan_nan_policy", "migan_backend", "migan_gemm_variant", "migan_version",
+    "migan_forward_split", "migan_forward_parts", "migan_set_tuning", "migan_last_error", "migan_last_kernel", "migan_nan_policy", "migan_backend", "migan_gemm_variant", "migan_version",
     # include/comodgan_hip.h
     "comodgan_create", "comodgan_destroy", "comodgan_num_weights", "comodgan_weight_info", "comodgan_set_weight",
     "comodgan_commit", "comodgan_workspace_bytes", "comodgan_assume_static_weights", "comodgan_noise_floats", "comodgan_forward",
@@ -134,6 +134,8 @@ class MiganLib:
         L.migan_workspace_bytes_hw.argtypes = [vp, ci, ci, ci, C.POINTER(C.c_size_t)]
         L.migan_forward_hw.argtypes = [vp, vp, vp, ci, ci, ci, vp, C.c_size_t, vp]
         L.migan_forward_u8.argtypes = [vp, vp, vp, vp, ci, vp, C.c_size_t, vp]
+        L.migan_forward_split.argtypes = [vp, ci, C.POINTER(ci), C.POINTER(ci)]
+        L.migan_forward_parts.argtypes = [vp, vp, C.POINTER(vp), ci, vp, C.c_size_t, vp, C.POINTER(vp), ci, C.POINTER(ci), C.POINTER(ci)]
         L.migan_pipeline_mask_resize.argtypes = [vp, ci, ci, vp, ci, ci, vp]
         L.migan_pipeline_scratch_bytes.argtypes = [ci, ci, C.POINTER(C.c_size_t)]
         L.migan_pipeline_bbox.argtypes = [vp, ci, ci, ci, ci, vp, C.POINTER(ci), vp]
@@ -206,7 +208,7 @@ class MiganLib:
         return self.lib.migan_gemm_variant().decode()
 
     def nan_policy(self) -> str:
-        """"clamp" (default build) or "propagate" (libmigan_hip_strictnan.so): what lrelu_agc's clamp does with a NaN"""
+        """"propagate" (default build: Tensor.clamp's behaviour, reference :21-23) or "clamp" (libmigan_hip_nanclamp.so): what lrelu_agc's clamp does with a NaN"""
         return self.lib.migan_nan_policy().decode()
 
     def last_kernel(self) -> str:
@@ -333,6 +335,21 @@ class MiganHandle:
     def forward(self, x_ptr: int, y_ptr: int, batch: int, ws_ptr: int, ws_bytes: int, stream: int = 0) -> None:
         self.lib.check(self.lib.lib.migan_forward(self._h, C.c_void_p(x_ptr), C.c_void_p(y_ptr), int(batch),
                                                   C.c_void_p(ws_ptr), C.c_size_t(ws_bytes), C.c_void_p(stream)))
+
+    def forward_split(self, batch: int) -> List[int]:
+        """images per sub-batch of a forward of `batch` images (migan_forward_split)"""
+        n, parts = (C.c_int * 4)(), C.c_int()
+        self.lib.check(self.lib.lib.migan_forward_split(self._h, int(batch), n, C.byref(parts)))
+        return [int(n[k]) for k in range(parts.value)]
+
+    def forward_parts(self, x_ptr: int, y_ptrs: List[int], batch: int, ws_ptr: int, ws_bytes: int, stream: int, part_streams: List[int]) -> List[int]:
+        """migan_forward_parts: sub-batch k -> y_ptrs[k]; sub-batch k >= 1 on the caller's stream part_streams[k - 1]; streams are not joined"""
+        ys = (C.c_void_p * 4)(*([C.c_void_p(p) for p in y_ptrs] + [C.c_void_p(0)] * (4 - len(y_ptrs))))
+        st = (C.c_void_p * 4)(*([C.c_void_p(p) for p in part_streams] + [C.c_void_p(0)] * (4 - len(part_streams))))
+        n, parts = (C.c_int * 4)(), C.c_int()
+        self.lib.check(self.lib.lib.migan_forward_parts(self._h, C.c_void_p(x_ptr), ys, int(batch), C.c_void_p(ws_ptr), C.c_size_t(ws_bytes),
+                                                        C.c_void_p(stream), st, len(part_streams), n, C.byref(parts)))
+        return [int(n[k]) for k in range(parts.value)]
 
     def workspace_bytes_hw(self, batch: int, height: int, width: int) -> int:
         n = C.c_size_t()
@@ -477,23 +494,24 @@ class CoModGANHandle:
 _LIB: Optional[MiganLib] = None
 
 
-_STRICT_LIB: Optional["MiganLib"] = None
+_CLAMP_LIB: Optional["MiganLib"] = None
 
 
-def load_library(path: Optional[str] = None, nan_policy: str = "clamp") -> MiganLib:
-    """Process-wide libmigan_hip.so (raises MiganError when it is not built).  nan_policy="propagate": the build of the same library
-    whose clamp keeps a NaN a NaN, like Tensor.clamp in the reference module (libmigan_hip_strictnan.so, -DMIGAN_STRICT_NAN)."""
-    global _LIB, _STRICT_LIB
+def load_library(path: Optional[str] = None, nan_policy: str = "propagate") -> MiganLib:
+    """Process-wide libmigan_hip.so (raises MiganError when it is not built).  nan_policy="propagate" (default): a NaN activation stays a NaN
+    through lrelu_agc's clamp, like Tensor.clamp in the reference module; "clamp": the build of the same library without that repair
+    (libmigan_hip_nanclamp.so, -DMIGAN_NAN_CLAMP: v_med3_f32 turns a NaN into -256, ~2 % faster)."""
+    global _LIB, _CLAMP_LIB
     if nan_policy not in ("clamp", "propagate"):
         raise ValueError(f"nan_policy must be 'clamp' or 'propagate', got {nan_policy!r}")
     if path is not None:
         return MiganLib(path)
-    if nan_policy == "propagate":
-        if _STRICT_LIB is None:
-            _STRICT_LIB = MiganLib(os.path.join(_HERE, "csrc", "libmigan_hip_strictnan.so"))
-            if _STRICT_LIB.nan_policy() != "propagate":
-                raise MiganError("libmigan_hip_strictnan.so was not built with -DMIGAN_STRICT_NAN")
-        return _STRICT_LIB
+    if nan_policy == "clamp":
+        if _CLAMP_LIB is None:
+            _CLAMP_LIB = MiganLib(os.path.join(_HERE, "csrc", "libmigan_hip_nanclamp.so"))
+            if _CLAMP_LIB.nan_policy() != "clamp":
+                raise MiganError("libmigan_hip_nanclamp.so was not built with -DMIGAN_NAN_CLAMP")
+        return _CLAMP_LIB
     if _LIB is None:
         _LIB = MiganLib()
     return _LIB

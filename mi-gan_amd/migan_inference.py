@@ -217,13 +217,13 @@ def _init_tensor(e: schema.Entry) -> torch.Tensor:
 class Generator(nn.Module):
     """MI-GAN inference generator (reference migan_inference.py:355-369) on MI355X."""
 
-    def __init__(self, resolution: int = 256, activation_dtype="f32", nan_policy: str = "clamp"):
+    def __init__(self, resolution: int = 256, activation_dtype="f32", nan_policy: str = "propagate"):
         """resolution: as the reference (:356).  activation_dtype (extension): storage format of the feature maps between
         layers on the GPU -- "f32" (the reference's precision, <= 1e-3 parity), "bf16" (BASELINE configs[1]) or "f16";
         parameters, input, output and all arithmetic stay float32 (include/migan_hip.h, MIGAN_DTYPE_*).
-        nan_policy (extension): "clamp" (default) -- a NaN activation leaves lrelu_agc's clamp as -256, as in the reference's CUDA
-        plugin; "propagate" -- it stays a NaN, as Tensor.clamp does in the reference module (:21-23); runs the -DMIGAN_STRICT_NAN
-        build of the library (a few per cent slower: two more VALU instructions per activation)."""
+        nan_policy (extension): "propagate" (default) -- a NaN activation stays a NaN through lrelu_agc's clamp, as Tensor.clamp does in
+        the reference module (:21-23); "clamp" -- it leaves the clamp as -256, as in the reference's CUDA plugin (bias_act.cu:139): the
+        -DMIGAN_NAN_CLAMP build of the library, ~2 % faster (no NaN test at all; finite inputs give the same bits either way)."""
         super().__init__()
         if nan_policy not in ("clamp", "propagate"):
             raise ValueError(f"nan_policy must be 'clamp' or 'propagate', got {nan_policy!r}")
@@ -391,15 +391,52 @@ class Generator(nn.Module):
         return x.contiguous()
 
     # ------------------------------------------------------------------ API
-    def forward(self, x: torch.Tensor) -> torch.Tensor:
-        """Args: x: 4 channel rgb+mask [N,4,R,R]; returns img [N,3,R,R] (reference :362-369)."""
+    def forward(self, x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Args: x: 4 channel rgb+mask [N,4,R,R]; returns img [N,3,R,R] (reference :362-369).
+        out (extension): a contiguous float32 [N,3,R,R] tensor on x's device to write the image into instead of a fresh one -- e.g. this
+        rank's slice of an all-gather's receive buffer (distributed.OutputGather), so that the collective runs in place."""
         x = self._check_input(x)
         h = self._engine(x)
         n = x.shape[0]
         ws = self._workspace(h, n, x.device)
-        y = torch.empty((n, 3, self.resolution, self.resolution), dtype=torch.float32, device=x.device)
+        y = self._check_out(out, (n, 3, self.resolution, self.resolution), x.device)
         h.forward(x.data_ptr(), y.data_ptr(), n, ws.data_ptr(), ws.numel(), self._stream(x))
         return y
+
+    def _check_out(self, out: Optional[torch.Tensor], shape, device) -> torch.Tensor:
+        if out is None:
+            return torch.empty(shape, dtype=torch.float32, device=device)
+        if tuple(out.shape) != tuple(shape) or out.dtype != torch.float32 or out.device != device or not out.is_contiguous():
+            raise RuntimeError(f"out must be a contiguous float32 tensor of shape {list(shape)} on {device}, got {list(out.shape)} {out.dtype} on {out.device}")
+        return out
+
+    def sub_batches(self, batch: int, device=None) -> List[int]:
+        """images per sub-batch of a forward of `batch` images on this model's handle (migan_forward_split): [batch] below 16 images or with
+        set_streams(1), else two (up to four) staggered sub-batches"""
+        if self._handle is None:
+            if device is None:
+                raise RuntimeError("sub_batches before the first forward needs the device")
+            self._engine(torch.empty((1, 4, self.resolution, self.resolution), dtype=torch.float32, device=device))
+        return self._handle.forward_split(batch)
+
+    def forward_parts(self, x: torch.Tensor, outs: List[torch.Tensor], part_streams: List["torch.cuda.Stream"]) -> List[int]:
+        """migan_forward_parts (extension, multi-GPU callers): the forward of x with the sub-batch hand-over made explicit.  Sub-batch k
+        (sizes: sub_batches(N)) writes outs[k] ([n_k,3,R,R], contiguous float32) and, for k >= 1, runs on part_streams[k - 1]; the streams
+        are NOT joined -- work enqueued on the current stream afterwards is ordered behind sub-batch 0 only, work on part_streams[k - 1]
+        behind sub-batch k.  The caller joins them (current_stream.wait_stream(s)) before the next forward of this model."""
+        x = self._check_input(x)
+        h = self._engine(x)
+        n = x.shape[0]
+        sizes = h.forward_split(n)
+        if len(outs) != len(sizes) or len(part_streams) < len(sizes) - 1:
+            raise RuntimeError(f"a forward of {n} images runs as {len(sizes)} sub-batch(es) {sizes}: need that many outputs and one stream per sub-batch after the first")
+        r = self.resolution
+        ys = [self._check_out(o, (nk, 3, r, r), x.device) for o, nk in zip(outs, sizes)]
+        ws = self._workspace(h, n, x.device)
+        got = h.forward_parts(x.data_ptr(), [y.data_ptr() for y in ys], n, ws.data_ptr(), ws.numel(), self._stream(x),
+                              [int(s.cuda_stream) for s in part_streams[:len(sizes) - 1]])
+        assert got == sizes
+        return sizes
 
     def forward_any_size(self, x: torch.Tensor) -> torch.Tensor:
         """Fully convolutional forward (reference README.md:87 asks for ``filter_const`` / ``noise_const`` to be made dynamic):

@@ -135,12 +135,10 @@ void run_grid(void (*invoke)(const void*), const void* arg, unsigned grid, unsig
 #define MIGAN_FADD_RN(a, b) ((float)((a) + (b)))
 #define MIGAN_FSUB_RN(a, b) ((float)((a) - (b)))
 inline float __shfl_xor(float v, int mask);
-#ifdef MIGAN_STRICT_NAN
-inline float hipemu_clamp_nan(float v, float lo, float hi) { return v != v ? v : fminf(fmaxf(v, lo), hi); }
-#define MIGAN_CLAMP(v, lo, hi) hipemu_clamp_nan((v), (lo), (hi))
-#else
-#define MIGAN_CLAMP(v, lo, hi) fminf(fmaxf((v), (lo)), (hi))
-#endif
+// (lane-wise: the guarded code is a no-op in lanes where the predicate is false, so the wave-uniform branch of the product is only a speed-up)
+#define MIGAN_ANY_LANE(p) (p)
+#define MIGAN_COLD_PATH() do {} while (0)
+#define MIGAN_CLAMP(v, lo, hi) fminf(fmaxf((v), (lo)), (hi))       // (like v_med3_f32: a NaN leaves it as lo; clamp4 / clamp1 repair it)
 #define MIGAN_SWIZZLE_XOR(v, m) __shfl_xor((v), (m))
 inline float hipemu_sum8(float v) {
   v += __shfl_xor(v, 1);

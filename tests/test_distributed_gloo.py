@@ -115,6 +115,85 @@ def test_output_gather_pipeline_world2_gloo(tmp_path):
             np.testing.assert_array_equal(blk[:, 0, 0, 0], np.arange(3) + 10 * r)
 
 
+class _StandInModel:
+    """what OutputGather.forward_and_submit needs of mi-gan_amd's Generator, on CPU: forward(x, out=) and forward_parts(x, outs, streams) write
+    a function of x into the buffers they are given and report the sub-batch sizes (the HIP module does the same through migan_forward_parts)"""
+
+    def __init__(self, sizes):
+        self.sizes = list(sizes)
+        self.calls = []
+
+    @staticmethod
+    def f(x):
+        return x * 2.0 + 1.0
+
+    def __call__(self, x, out=None):
+        assert out is not None and out.is_contiguous() and out.shape == x.shape
+        out.copy_(self.f(x))
+        self.calls.append(("forward", out.data_ptr()))
+        return out
+
+    def forward_parts(self, x, outs, streams):
+        lo = 0
+        for o, n in zip(outs, self.sizes):
+            assert o.is_contiguous() and o.shape[0] == n
+            o.copy_(self.f(x[lo:lo + n]))
+            lo += n
+        self.calls.append(("parts", tuple(o.data_ptr() for o in outs)))
+        return list(self.sizes)
+
+
+def _inplace_worker(rank, world, port, steps, chunks, out_dir):
+    sys.path.insert(0, ROOT)
+    import importlib
+    pkg = importlib.import_module("mi-gan_amd")
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    n = sum(chunks)
+    shard = (n, 3, 4, 4)
+    pipe = pkg.distributed.OutputGather(shard, torch.float32, torch.device("cpu"), chunks=chunks)
+    model = _StandInModel(chunks)
+    got, slots = [], []
+    for i in range(steps):
+        x = torch.arange(n * 3 * 4 * 4, dtype=torch.float32).reshape(shard) + 1000.0 * i + 100000.0 * rank
+        slots.append(pipe.forward_and_submit(model, x))
+        # in place: the forward wrote into this rank's slices of the receive buffers of that slot, nowhere else
+        want_ptrs = tuple(v.data_ptr() for v in pipe.shards(slots[-1]))
+        assert model.calls[-1][1] == (want_ptrs if len(chunks) > 1 else want_ptrs[0])
+        if i >= 1:
+            got.append(pipe.result(slots[i - 1]).clone())
+    pipe.drain()
+    got.append(pipe.result(slots[-1]).clone())
+    parts = pipe.result_chunks(slots[-1])
+    assert [tuple(p.shape[:2]) for p in parts] == [(world, c) for c in chunks]
+    np.save(os.path.join(out_dir, f"inplace_{rank}.npy"), torch.stack(got).numpy())
+    # the copying form on the same object (producers that cannot write in place), chunked the same way
+    y = torch.full(shard, float(rank))
+    np.save(os.path.join(out_dir, f"copy_{rank}.npy"), pipe.result(pipe.submit(y)).clone().numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("chunks", [[3], [2, 1], [2, 2]])
+def test_output_gather_in_place_and_per_sub_batch_world2_gloo(tmp_path, chunks):
+    """the forward writes its images into the collective's receive buffers (no local copy) and every sub-batch's
+    shard is gathered by its own collective, enqueued right behind that sub-batch; the gathered batch is in rank order whatever the
+    chunking, step after step, with the double buffering of bench.py's loop."""
+    world, steps = 2, 4
+    mp.spawn(_inplace_worker, args=(world, _free_port(), steps, chunks, str(tmp_path)), nprocs=world, join=True)
+    a, b = np.load(tmp_path / "inplace_0.npy"), np.load(tmp_path / "inplace_1.npy")
+    np.testing.assert_array_equal(a, b)
+    n = sum(chunks)
+    assert a.shape == (steps, world * n, 3, 4, 4)
+    base = np.arange(n * 3 * 4 * 4, dtype=np.float32).reshape(n, 3, 4, 4)
+    for i in range(steps):
+        for r in range(world):
+            np.testing.assert_array_equal(a[i, r * n:(r + 1) * n], (base + 1000.0 * i + 100000.0 * r) * 2.0 + 1.0)
+    c = np.load(tmp_path / "copy_0.npy")
+    assert c.shape == (world * n, 3, 4, 4) and all(np.all(c[r * n:(r + 1) * n] == r) for r in range(world))
+
+
 def _worker_comodgan(rank, world, port, total, out_dir):
     sys.path.insert(0, ROOT)
     import importlib

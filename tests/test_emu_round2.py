@@ -276,6 +276,33 @@ def test_two_sub_batches_equal_one_batch(pkg, lib):
     np.testing.assert_array_equal(ya, y1)
 
 
+def test_forward_parts_hands_each_sub_batch_its_own_output(pkg, lib):
+    """migan_forward_parts (multi-GPU callers, include/migan_hip.h): the same forward with the sub-batch hand-over made explicit -- sub-batch
+    k writes to y_parts[k] (here: separate buffers, as the slices of a collective's receive buffers are) and the split is the one
+    migan_forward_split reports; images are the bits migan_forward gives."""
+    res, seed = 8, 6
+    h, sd, keep = _bind(pkg, lib, res, seed)
+    for batch, streams, want_split in ((21, 2, [16, 5]), (37, 3, [16, 16, 5]), (7, 2, [7]), (32, 1, [32])):
+        h.set_streams(streams)
+        assert h.forward_split(batch) == want_split
+        x = pkg.synth.make_input(batch, res, seed=seed + batch)
+        y, _ = _forward(h, x)
+        xa = aligned(x)
+        outs = [aligned(np.full((n, 3, res, res), np.nan, np.float32)) for n in want_split]
+        need = h.workspace_bytes(batch)
+        ws = np.zeros(need // 4 + 64, np.float32)
+        got = h.forward_parts(xa.ctypes.data, [o.ctypes.data for o in outs], batch, ws.ctypes.data, need, 0, [1] * (len(want_split) - 1))
+        assert got == want_split
+        np.testing.assert_array_equal(np.concatenate(outs, axis=0), y)
+    h.set_streams(2)
+    xa = aligned(pkg.synth.make_input(21, res, seed=1))
+    outs = [aligned(np.zeros((n, 3, res, res), np.float32)) for n in (16, 5)]
+    need = h.workspace_bytes(21)
+    ws = np.zeros(need // 4 + 64, np.float32)
+    with pytest.raises(ValueError):          # a caller stream per sub-batch after the first is required
+        h.forward_parts(xa.ctypes.data, [o.ctypes.data for o in outs], 21, ws.ctypes.data, need, 0, [])
+
+
 # ------------------------------------------------------------------------------------------------ static weights
 def test_static_weights_contract(pkg, lib):
     res, seed = 8, 3

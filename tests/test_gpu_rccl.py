@@ -92,6 +92,45 @@ def test_world1_nccl_gather_of_two_stream_forwards_is_bit_identical(pkg, dev, nc
         assert torch.equal(pipe8.result(s), y8)
 
 
+def test_world1_nccl_in_place_gather_per_sub_batch_is_bit_identical(pkg, dev, nccl_world1):
+    """the forward writes its images into the collective's receive buffers (Generator.forward(x, out=...),
+    migan_forward_parts) and every sub-batch's shard is gathered by its own in-place all_gather_into_tensor, enqueued behind that
+    sub-batch on its own stream.  Under test on the hardware: the ordering between the caller's stream, the part streams the library
+    runs sub-batch 1 on, RCCL's stream and the reuse of the double-buffered slots and of the workspace by the next forward."""
+    res, batch = 64, 32
+    m = _model(pkg, res, dev)
+    m.set_streams(2)
+    xs = [torch.from_numpy(pkg.synth.make_input(batch, res, seed=60 + i, kind="demo")).to(dev) for i in range(5)]
+    with torch.no_grad():
+        want = [m(x).clone() for x in xs]
+        # out=: the same bits, written where the caller says
+        buf = torch.full((batch + 2, 3, res, res), float("nan"), device=dev)
+        y = m(xs[0], out=buf[1:batch + 1])
+        assert y.data_ptr() == buf[1].data_ptr() and torch.equal(y, want[0]) and bool(torch.isnan(buf[0]).all()) and bool(torch.isnan(buf[-1]).all())
+        with pytest.raises(RuntimeError):
+            m(xs[0], out=torch.empty((batch, 3, res, res), device=dev)[:, :, ::1, :].transpose(2, 3))
+        chunks = m.sub_batches(batch)
+        assert chunks == [16, 16]
+        pipe = pkg.distributed.OutputGather((batch, 3, res, res), torch.float32, dev, depth=2, chunks=chunks)
+        slots = []
+        for i, x in enumerate(xs):
+            slots.append(pipe.forward_and_submit(m, x))
+            if i >= 1:
+                assert torch.equal(pipe.result(slots[i - 1]), want[i - 1])
+        pipe.drain()
+        assert torch.equal(pipe.result(slots[-1]), want[-1])
+        # one chunk (set_streams(1)): result() is the receive buffer itself, no copy anywhere
+        m.set_streams(1)
+        assert m.sub_batches(batch) == [batch]
+        pipe1 = pkg.distributed.OutputGather((batch, 3, res, res), torch.float32, dev)
+        s = pipe1.forward_and_submit(m, xs[2])
+        got = pipe1.result(s)
+        assert got.data_ptr() == pipe1.shards(s)[0].data_ptr() and torch.equal(got, want[2])
+        # a plain forward afterwards still joins its own streams
+        m.set_streams(2)
+        assert torch.equal(m(xs[3]), want[3])
+
+
 def test_bench_force_pg_reports_the_one_rank_gather(pkg, dev):
     """bench.py --force-pg: the N = 1 line also times the step with a 1-rank NCCL group and the pipelined gather"""
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
@@ -104,6 +143,7 @@ def test_bench_force_pg_reports_the_one_rank_gather(pkg, dev):
     line = json.loads(last)
     pg = line["rccl_world1"]
     assert pg["backend"] == "nccl" and pg["ranks"] == 1 and pg["gathered_equals_forward"] is True and pg["ms_per_step"] > 0
+    assert pg["in_place"] is True and pg["collectives_per_step"] == 2
 
 
 _TWO_RANKS = textwrap.dedent("""
