@@ -756,31 +756,60 @@ def rccl_world1(wl, pkg, batch, dev, steps):
         flush_c_stdio()
         inplace = bool(wl.get("inplace")) and wl.get("out_dtype", torch.float32) == torch.float32
         chunks = wl["model"].sub_batches(batch, dev) if inplace else None
-        pipe = pkg.distributed.OutputGather(wl["out_shape"], wl.get("out_dtype", torch.float32), dev, chunks=chunks)
-        submit = (lambda: pipe.forward_and_submit(wl["model"], wl["x"])) if inplace else (lambda: pipe.submit(wl["step"]()))
-        with torch.no_grad():
+        odt = wl.get("out_dtype", torch.float32)
+
+        def run(mode):
+            # parts: one in-place collective per sub-batch (forward_parts); inplace: the forward writes the receive buffer, one collective per
+            # step; copy: rounds 2-5 -- the step's output tensor is copied into the receive buffer, then gathered
+            if mode == "parts":
+                pipe = pkg.distributed.OutputGather(wl["out_shape"], odt, dev, chunks=chunks)
+                submit = lambda: pipe.forward_and_submit(wl["model"], wl["x"])
+            elif mode == "inplace":
+                pipe = pkg.distributed.OutputGather(wl["out_shape"], odt, dev)
+                submit = lambda: pipe.forward_and_submit(wl["model"], wl["x"])
+            else:
+                pipe = pkg.distributed.OutputGather(wl["out_shape"], odt, dev)
+                submit = lambda: pipe.submit(wl["step"]())
             y = wl["step"]()
             slot = submit()
             same = bool(torch.equal(pipe.result(slot), y))
+            for _ in range(2):
+                submit()
+            pipe.drain()
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             for _ in range(steps):
                 submit()
             pipe.drain()
             torch.cuda.synchronize()
-            el = time.perf_counter() - t0
-            # the same steps without the collective, back to back on the same clocks: what the gather of step i, queued behind the persistent
-            # one-workgroup-per-CU kernels of step i + 1, adds to a step
+            return same, time.perf_counter() - t0
+
+        def plain():
+            torch.cuda.synchronize()
             t0 = time.perf_counter()
             for _ in range(steps):
                 wl["step"]()
             torch.cuda.synchronize()
-            el0 = time.perf_counter() - t0
+            return time.perf_counter() - t0
+
+        with torch.no_grad():
+            modes = (["parts", "inplace"] if inplace else []) + ["copy"]
+            res = {}
+            for mode in modes:
+                # each mode beside its own run of the same steps without the collective, back to back on the same clocks: what the gather of
+                # step i, queued behind the persistent one-workgroup-per-CU kernels of step i + 1, adds to a step
+                same_m, el_m = run(mode)
+                el0_m = plain()
+                res[mode] = {"gathered_equals_forward": same_m, "ms_per_step": round(el_m / steps * 1e3, 4),
+                             "ms_per_step_without_gather": round(el0_m / steps * 1e3, 4), "gather_exposed_ms": round((el_m - el0_m) / steps * 1e3, 4)}
+            default_mode = "parts" if inplace else "copy"
+            same = all(r["gathered_equals_forward"] for r in res.values())
+            el, el0 = res[default_mode]["ms_per_step"] * steps / 1e3, res[default_mode]["ms_per_step_without_gather"] * steps / 1e3
         return {"backend": dist.get_backend(), "ranks": dist.get_world_size(), "gathered_equals_forward": same,
                 "ms_per_step": round(el / steps * 1e3, 4), "steps": steps,
                 "ms_per_step_without_gather": round(el0 / steps * 1e3, 4), "gather_exposed_ms": round((el - el0) / steps * 1e3, 4),
                 "gather_mb_per_step": round(float(np.prod(wl["out_shape"])) * torch.empty((), dtype=wl.get("out_dtype", torch.float32)).element_size() / 1e6, 2),
-                "in_place": inplace, "collectives_per_step": len(chunks) if chunks else 1,
+                "in_place": inplace, "collectives_per_step": len(chunks) if chunks else 1, "modes": res,
                 "what": "init_process_group('nccl', world_size=1, device_id=...) + OutputGather.forward_and_submit per step: the forward writes into the "
                         "receive buffers of all_gather_into_tensor, one collective per sub-batch (migan_forward_parts), on RCCL's stream.  At world "
                         "size 1 an in-place all-gather has nothing to move: this leg shows that the path runs and what its launches cost a step, "
