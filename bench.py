@@ -80,6 +80,12 @@ def parse(argv=None):
                     help="N>1: what the ranks exchange.  auto = the forward's own output (fp32 [n,3,R,R], 100.7 MB per rank and step at "
                          "migan-512 x 32; uint8 [n,R,R,3], 25.2 MB, with --io u8); f16 = the fp32 output rounded to fp16 before the gather "
                          "(half the bytes; |y| ~ 30, so ~1e-2 absolute: not for parity runs); u8 requires --io u8")
+    ap.add_argument("--gather-mode", type=str, default="inplace", choices=["inplace", "parts", "copy"],
+                    help="N>1 (migan, fp32 output): inplace (default) = the forward writes its images into this rank's slice of the collective's receive "
+                         "buffer, ONE in-place all_gather_into_tensor per step; parts = the same per sub-batch (migan_forward_parts: the collective of "
+                         "sub-batch 0's shard is enqueued behind sub-batch 0 while sub-batch 1 computes); copy = the step's output tensor is copied "
+                         "into the receive buffer first (producers that cannot write in place always do this).  Measured at world size 1 "
+                         "(profiles/r06_experiments.md): exposed per step 0.0 / 0.29 / 0.05 ms")
     ap.add_argument("--reserve-cus", type=int, default=0, metavar="K",
                     help="N>1: run the forward on a HIP stream whose CU mask leaves K CUs (a multiple of 8: K/8 per XCD) to the RCCL "
                          "kernels of the overlapped all-gather, instead of letting them queue behind 256-CU-wide layers "
@@ -491,8 +497,8 @@ def run_workload(args, rank, local_rank, world, dist, dev):
     gdt = gather_dtype_of(args, wl.get("out_dtype", torch.float32))
     # the migan forward with fp32 output writes straight into the collective's receive buffers, one collective per sub-batch
     # (OutputGather.forward_and_submit); other producers (uint8 I/O, Co-Mod-GAN, a converted payload) copy their shard in
-    inplace = bool(gather and wl.get("inplace") and gdt == torch.float32 and not args.reserve_cus)
-    chunks = wl["model"].sub_batches(batch, dev) if inplace else None
+    inplace = bool(gather and wl.get("inplace") and gdt == torch.float32 and not args.reserve_cus and args.gather_mode != "copy" and not args.dry)
+    chunks = wl["model"].sub_batches(batch, dev) if (inplace and args.gather_mode == "parts") else None
     pipe = pkg.distributed.OutputGather(wl["out_shape"], gdt, dev, chunks=chunks) if gather else None
     # --reserve-cus K: the forward runs on a CU-masked stream so that the RCCL kernels of the overlapped gather find free CUs
     masked = pkg.distributed.cu_masked_stream(dev, args.reserve_cus) if (args.reserve_cus and not args.dry) else None
@@ -702,10 +708,11 @@ def run_workload(args, rank, local_rank, world, dist, dev):
         out["compute_only_ms_per_step"] = round(compute_only, 4)
         out["gather_mb_per_rank_per_step"] = round(float(np.prod(wl["out_shape"])) * torch.empty(0, dtype=gdt).element_size() / 1e6, 1)
         out["gather_dtype"] = str(gdt).replace("torch.", "")
-        out["gather"] = {"in_place": inplace, "collectives_per_step": len(chunks) if chunks else 1, "sub_batches": chunks or [batch],
-                         "note": ("the forward writes its images into the receive buffers of all_gather_into_tensor (no local copy); one collective per "
-                                  "sub-batch, enqueued behind that sub-batch (migan_forward_parts), overlapped with the rest of the step and the next one")
-                                 if inplace else "the step's output is copied into the receive buffer, then gathered (overlapped with the next step)"}
+        out["gather"] = {"mode": args.gather_mode if inplace else "copy", "in_place": inplace, "collectives_per_step": len(chunks) if chunks else 1,
+                         "note": ("the forward writes its images into this rank's slice of all_gather_into_tensor's receive buffer (no local copy), "
+                                  + ("one collective per sub-batch, enqueued behind that sub-batch (migan_forward_parts)" if chunks else
+                                     "one in-place collective per step") + ", overlapped with the next step")
+                                 if inplace else "the step's output is copied into the receive buffer, then gathered in place (overlapped with the next step)"}
     if args.reserve_cus:
         out["reserved_cus"] = args.reserve_cus
     if args.occupy:
@@ -802,18 +809,19 @@ def rccl_world1(wl, pkg, batch, dev, steps):
                 el0_m = plain()
                 res[mode] = {"gathered_equals_forward": same_m, "ms_per_step": round(el_m / steps * 1e3, 4),
                              "ms_per_step_without_gather": round(el0_m / steps * 1e3, 4), "gather_exposed_ms": round((el_m - el0_m) / steps * 1e3, 4)}
-            default_mode = "parts" if inplace else "copy"
+            default_mode = "inplace" if inplace else "copy"
             same = all(r["gathered_equals_forward"] for r in res.values())
             el, el0 = res[default_mode]["ms_per_step"] * steps / 1e3, res[default_mode]["ms_per_step_without_gather"] * steps / 1e3
         return {"backend": dist.get_backend(), "ranks": dist.get_world_size(), "gathered_equals_forward": same,
                 "ms_per_step": round(el / steps * 1e3, 4), "steps": steps,
                 "ms_per_step_without_gather": round(el0 / steps * 1e3, 4), "gather_exposed_ms": round((el - el0) / steps * 1e3, 4),
                 "gather_mb_per_step": round(float(np.prod(wl["out_shape"])) * torch.empty((), dtype=wl.get("out_dtype", torch.float32)).element_size() / 1e6, 2),
-                "in_place": inplace, "collectives_per_step": len(chunks) if chunks else 1, "modes": res,
-                "what": "init_process_group('nccl', world_size=1, device_id=...) + OutputGather.forward_and_submit per step: the forward writes into the "
-                        "receive buffers of all_gather_into_tensor, one collective per sub-batch (migan_forward_parts), on RCCL's stream.  At world "
-                        "size 1 an in-place all-gather has nothing to move: this leg shows that the path runs and what its launches cost a step, "
-                        "not xGMI time or the contention of a real collective (profiles/r05_contention.md measured that with a stand-in kernel)"}
+                "in_place": inplace, "collectives_per_step": 1, "mode": default_mode, "modes": res,
+                "what": "init_process_group('nccl', world_size=1, device_id=...) + OutputGather.forward_and_submit per step: the forward writes into this "
+                        "rank's slice of the receive buffer of all_gather_into_tensor, one in-place collective per step on RCCL's stream (`modes`: the "
+                        "same per sub-batch, and the copying form).  At world size 1 an in-place all-gather has nothing to move: this leg shows that "
+                        "the path runs, that the result is the forward's bits and what the submission costs a step -- not xGMI time or the contention "
+                        "of a real collective (profiles/r05_contention.md measured that with a stand-in kernel)"}
     finally:
         if created:
             dist.destroy_process_group()

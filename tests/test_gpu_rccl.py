@@ -143,7 +143,8 @@ def test_bench_force_pg_reports_the_one_rank_gather(pkg, dev):
     line = json.loads(last)
     pg = line["rccl_world1"]
     assert pg["backend"] == "nccl" and pg["ranks"] == 1 and pg["gathered_equals_forward"] is True and pg["ms_per_step"] > 0
-    assert pg["in_place"] is True and pg["collectives_per_step"] == 2
+    assert pg["in_place"] is True and pg["mode"] == "inplace" and set(pg["modes"]) == {"parts", "inplace", "copy"}
+    assert all(m["gathered_equals_forward"] for m in pg["modes"].values())
 
 
 _TWO_RANKS = textwrap.dedent("""
