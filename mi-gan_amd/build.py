@@ -59,7 +59,7 @@ STAMP = OUT + ".flags"
 
 
 def flags_digest(extra: Sequence[str] = ()) -> str:
-    """what the library was compiled with (a measurement build with -DMIGAN_ABLATE / -DMIGAN_PHASE_PROF must never pass for the product)"""
+    """what the library was compiled with (a measurement build with -DMIGAN_PHASE_PROF must never pass for the product)"""
     return hashlib.sha256(" ".join([*FLAGS, *extra, *(f"{g}.{s}" for g, s in SLICES)]).encode()).hexdigest()[:16]
 
 

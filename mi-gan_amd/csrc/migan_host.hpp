@@ -83,7 +83,6 @@ struct Tuning {
                                // profiles/r03_wide_kernel.md
   int wide_up = 1;             // FIR-up layers with Cout % 256 == 0 on the 256-column tile as well (sepconv_wide_kernel<..., UP>; needs wide == 3)
   int nt256 = 1;               // MIGAN_NT256=0|1: 64-pixel x 256-channel tiles for the 256-channel layer that feeds ToRGB (fuses it)
-  int ablate = 0;              // MIGAN_ABLATE (measurement builds compiled with -DMIGAN_ABLATE only)
   int persist_min = 8192;      // MIGAN_PERSIST_MIN: launches with at least this many tiles run persistent workgroups
   int persist_grid = 512;      // MIGAN_PERSIST_GRID: ... that many (2 per CU on MI355X), each walking its share of tiles
   int kc16 = 0;                // MIGAN_KC16 bit mask: 16-channel K chunks for the 64-output-channel main-geometry layers (f16x2 GEMM):
@@ -130,7 +129,6 @@ inline Tuning& tuning() {
     if (const char* e = std::getenv("MIGAN_GEMM")) v.gemm = std::string(e) == "f32" ? 0 : (std::string(e) == "bf16x3" ? 1 : 2);
     if (const char* e = std::getenv("MIGAN_WIDE")) v.wide = std::atoi(e);
     if (const char* e = std::getenv("MIGAN_NT256")) v.nt256 = std::atoi(e) != 0;
-    if (const char* e = std::getenv("MIGAN_ABLATE")) v.ablate = std::atoi(e);
     if (const char* e = std::getenv("MIGAN_PERSIST_MIN")) v.persist_min = std::max(1, std::atoi(e));
     if (const char* e = std::getenv("MIGAN_PERSIST_GRID")) v.persist_grid = std::max(8, std::atoi(e) / 8 * 8);   // multiple of 8: one share per XCD
     if (const char* e = std::getenv("MIGAN_KC16")) v.kc16 = std::atoi(e);
@@ -570,7 +568,6 @@ inline void fill_geo(SepArgs& a, const Geo& g) {
   a.off_a = g.off_a; a.off_b = g.off_b; a.off_v = g.off_v; a.off_rgb = g.off_rgb; a.off_w = g.off_w;
   a.b_stride = g.b_stride;
   a.a_stride = g.a_stride;
-  a.ablate = tuning().ablate;
   a.prof = prof_buffer();
 }
 

@@ -79,8 +79,6 @@ struct SepArgs {
   int off_a, off_b, off_v, off_rgb, off_w;   // LDS carve, in floats
   int b_stride;                    // floats between the two 1x1-weight buffers (0 = single buffered)
   int a_stride;                    // MODE_PW: floats between the two A-operand buffers
-  int ablate;                      // measurement builds only (MIGAN_ABLATE): bit0 no epilogue stores, bit1 no epilogue,
-                                   // bit2 no depthwise stage, bit3 no MFMA, bit4 no global input loads, bit5 no 1x1-weight loads; 0 in production
 };
 
 struct RgbArgs {
@@ -363,12 +361,6 @@ MIGAN_DEVICE MIGAN_INLINE void compose_pixel(const unsigned char* img, const uns
   o[2] = keep ? q[2] : unit_to_u8(y2);
 }
 
-#ifdef MIGAN_ABLATE
-#define MIGAN_ABL(bit) ((p.ablate & (bit)) != 0)
-#else
-#define MIGAN_ABL(bit) false
-#endif
-
 #ifdef MIGAN_PHASE_PROF
 #define PROF_BEGIN() long long prof_t = (long long)MIGAN_CLOCK(); long long prof_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
 #define PROF_MARK(i) do { const long long n_ = (long long)MIGAN_CLOCK(); prof_acc[i] += n_ - prof_t; prof_t = n_; } while (0)
@@ -621,23 +613,13 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, MINW) sepconv_kernel(const SepArgs p)
   auto issue_loads = [&](int b0_, const unsigned (&goff_)[NI], const unsigned (&boff_)[NB], int k0) {
     if constexpr (!FROMRGB) {
       const char* __restrict__ xk = gx_ + ((size_t)b0_ * p.H * p.W * p.CI + k0) * IoIn::ESZ;
-      if (MIGAN_ABL(16)) {
 #pragma unroll
-        for (int j = 0; j < NI; ++j) rin[j] = IoIn::zero();
-      } else {
-#pragma unroll
-        for (int j = 0; j < NI; ++j) rin[j] = IoIn::ld(xk, goff_[j]);
-      }
+      for (int j = 0; j < NI; ++j) rin[j] = IoIn::ld(xk, goff_[j]);
     }
     if constexpr (BF) {
       const unsigned short* __restrict__ wk = p.wsplit + (size_t)(k0 >> 5) * 32 * p.CO + (k0 & 31);   // 32-channel block k0/32, column k0%32
-      if (MIGAN_ABL(32)) {
 #pragma unroll
-        for (int j = 0; j < NB; ++j) rb[j] = f4{0.f, 0.f, 0.f, 0.f};
-      } else {
-#pragma unroll
-        for (int j = 0; j < NB; ++j) rb[j] = ld4(at_bytes(reinterpret_cast<const float*>(wk), boff_[j]));
-      }
+      for (int j = 0; j < NB; ++j) rb[j] = ld4(at_bytes(reinterpret_cast<const float*>(wk), boff_[j]));
     } else {
       const float* __restrict__ wk = gwpw + k0;
 #pragma unroll
@@ -793,7 +775,6 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, MINW) sepconv_kernel(const SepArgs p)
     // from LDS) is scattered into three running sums (the outputs it is the bottom / middle / top
     // tap row of), so each LDS value is read once per column and no register window is kept.
     if constexpr (MODE != MODE_PW) {
-      if (!MIGAN_ABL(4)) {
       const int RS = 1 << lgRS;
       const int ncols = (IMGS * GW * QC) << lgRS;
       for (int it = tid; it < ncols; it += kThreads) {
@@ -830,7 +811,6 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, MINW) sepconv_kernel(const SepArgs p)
           else emit_a(a_s, mbase + (o << lgGW), c4, act4(sacc));
         }
       }
-      }
       __syncthreads();
     }
     PROF_MARK(2);
@@ -839,8 +819,7 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, MINW) sepconv_kernel(const SepArgs p)
     // v_mfma_f32_32x32x2_f32: lane l supplies A[i=l&31][k=l>>5] and B[k=l>>5][j=l&31].  Each lane
     // reads 4 consecutive k with one ds_read_b128; the two lane halves take k = 8kk+4*half+t, the
     // same for A and B, so any assignment of k to (half,t) sums the full K.
-    if (MIGAN_ABL(8)) {
-    } else if constexpr (BF) {
+    if constexpr (BF) {
       // v_mfma_f32_32x32x16_{bf16,f16}: lane l supplies A[i=l&31][k=8*(l>>5)..+7] and B[k=8*(l>>5)..+7][j=l&31]
       // as one 16-byte LDS read each; NPL planes per operand; six (bf16x3) or three (f16x2) MFMAs per
       // 32x32 tile and k-step, smallest products first.
@@ -908,7 +887,6 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, MINW) sepconv_kernel(const SepArgs p)
     PROF_MARK(3);
   }
 
-  if (!MIGAN_ABL(2)) {
   // ======================================= epilogue ========================================
   // `tide` is the thread id laundered through an empty asm: everything the epilogue derives from it
   // is then recomputed per tile instead of being hoisted above the K loop by LICM (which would keep
@@ -1040,7 +1018,7 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, MINW) sepconv_kernel(const SepArgs p)
         }
         f4 outv = v;
         if constexpr (HS) outv = v + IoOut::cvt(sk[u]);
-        if (ok[u] && !MIGAN_ABL(1)) IoOut::st(yb + (size_t)upix[u] * p.CO * OE, loff[u], outv);
+        if (ok[u]) IoOut::st(yb + (size_t)upix[u] * p.CO * OE, loff[u], outv);
         if constexpr (do_rgb) {
           // ToRGB (reference :312): this lane's share of the 3 dot products over the CO channels of the pixel
           // goes into the g_s slot the item just consumed; the per-pixel sums are formed in the tail pass below.
@@ -1153,13 +1131,12 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, MINW) sepconv_kernel(const SepArgs p)
             v = F16 ? act4g(v, gain_s) : act4(v);
           }
           if constexpr (HS) v += IoOut::cvt(sk[a][bb]);
-          if (!MIGAN_ABL(1)) IoOut::st(yb, (unsigned)(loff + (upix + a * p.WO + bb) * p.CO) * OE, v);
+          IoOut::st(yb, (unsigned)(loff + (upix + a * p.WO + bb) * p.CO) * OE, v);
         }
     }
     };
     if (has_noise) { if (sb) epi_items(TrueT{}, TrueT{}); else epi_items(TrueT{}, FalseT{}); }
     else { if (sb) epi_items(FalseT{}, TrueT{}); else epi_items(FalseT{}, FalseT{}); }
-  }
   }
   PROF_MARK(5);
   if (!has_next) break;
@@ -1342,25 +1319,15 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(kWideThreads, 2) sepconv_wide_kernel(const
     for (int j = 0; j < DNB; ++j) MIGAN_LDS_DMA16(wbuf, dboff[j], (unsigned)k0 * (unsigned)p.CO * 2u, bb + (j * LT + lwave * 64) * 4);
   };
   auto load_in = [&](int k0) {                     // input tile + depthwise taps of one chunk
-    if (MIGAN_ABL(16)) {
 #pragma unroll
-      for (int j = 0; j < NI; ++j) rin[j] = IoT::zero();
-    } else {
-#pragma unroll
-      for (int j = 0; j < NI; ++j) rin[j] = IoT::ld(xb + (size_t)k0 * OE, goff[j]);
-    }
+    for (int j = 0; j < NI; ++j) rin[j] = IoT::ld(xb + (size_t)k0 * OE, goff[j]);
     if (tid < KC * 9 / 4) rw = ld4(p.wdw + (size_t)k0 * 9 + (unsigned)(tid * 4));
     else if (tid < NW4) rw = ld4(p.bdw + k0 + (unsigned)((tid - KC * 9 / 4) * 4));
   };
   auto load_b = [&](int k0) {                      // fp16 planes of the 1x1 weights of one chunk
     const unsigned short* __restrict__ wk = p.wsplit + (size_t)k0 * p.CO;
-    if (MIGAN_ABL(32)) {
 #pragma unroll
-      for (int j = 0; j < NB; ++j) rb[j] = f4{1.f, 2.f, 3.f, (float)k0};
-    } else {
-#pragma unroll
-      for (int j = 0; j < NB; ++j) rb[j] = ld4(at_bytes(reinterpret_cast<const float*>(wk), boff[j]));
-    }
+    for (int j = 0; j < NB; ++j) rb[j] = ld4(at_bytes(reinterpret_cast<const float*>(wk), boff[j]));
   };
   auto store_in = [&](int buf) {
     float* in_s = smem + OFF_IN + buf * IN_SZ;
@@ -1558,10 +1525,10 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(kWideThreads, 2) sepconv_wide_kernel(const
       PROF_MARK(pslot + 0);
       return;
     }
-    if (c + 1 < nkc && !MIGAN_ABL(64)) store_b((c + 1) & 1);        // last read by the MFMAs of chunk c-1
+    if (c + 1 < nkc) store_b((c + 1) & 1);        // last read by the MFMAs of chunk c-1
     if constexpr (BALL) PROF_MARK(pslot + 0);        // (phase profile of the BALL form: [weight tile -> LDS, input tile -> LDS + loads, depthwise | MFMA, barrier])
     if (c + 2 < nkc) {
-      if (!MIGAN_ABL(128)) store_in(c & 1);       // last read by the depthwise stage of chunk c
+      store_in(c & 1);       // last read by the depthwise stage of chunk c
       load_b((c + 2) * KC);
     }
     if (c + 3 < nkc) load_in((c + 3) * KC);
@@ -1571,7 +1538,7 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(kWideThreads, 2) sepconv_wide_kernel(const
       for (int c = 0; c < nkc; ++c) {
         stage(c);
         PROF_MARK(pslot + 1);
-        if (c + 1 < nkc && !MIGAN_ABL(4)) depthwise((c + 1) & 1, (c + 1) & 1);
+        if (c + 1 < nkc) depthwise((c + 1) & 1, (c + 1) & 1);
         PROF_MARK(pslot + 2);
         if constexpr (DMA) { if (c + 2 < nkc) store_taps(c & 1); MIGAN_WAIT_VMCNT(0); }
         __syncthreads();
@@ -1582,7 +1549,7 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(kWideThreads, 2) sepconv_wide_kernel(const
       for (int c = 0; c < nkc; ++c) {
         stage(c);
         PROF_MARK(pslot + 1);
-        if (!MIGAN_ABL(8)) mfma_chunk(c & 1);
+        mfma_chunk(c & 1);
         PROF_MARK(pslot + 2);
         if constexpr (DMA) { if (c + 2 < nkc) store_taps(c & 1); MIGAN_WAIT_VMCNT(0); }
         __syncthreads();
@@ -1595,9 +1562,9 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(kWideThreads, 2) sepconv_wide_kernel(const
     for (int c = 0; c < nkc; ++c) {
       stage(c);
       PROF_MARK(pslot + 0);
-      if (groupA && c + 1 < nkc && !MIGAN_ABL(4)) depthwise((c + 1) & 1, (c + 1) & 1);   // a_s[(c+1)&1] last read by the MFMAs of chunk c-1
+      if (groupA && c + 1 < nkc) depthwise((c + 1) & 1, (c + 1) & 1);   // a_s[(c+1)&1] last read by the MFMAs of chunk c-1
       PROF_MARK(pslot + 1);
-      if (!MIGAN_ABL(8)) mfma_chunk(c & 1);
+      mfma_chunk(c & 1);
       PROF_MARK(pslot + 2);
       __syncthreads();
       PROF_MARK(pslot + 3);
@@ -1730,7 +1697,7 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(kWideThreads, 2) sepconv_wide_kernel(const
         }
         f4 outv = v;
         if constexpr (HS) outv = v + IoT::cvt(sk[u]);
-        if (!MIGAN_ABL(1)) IoT::st(yb + (size_t)upix[u] * p.CO * OE, off_t, outv);
+        IoT::st(yb + (size_t)upix[u] * p.CO * OE, off_t, outv);
         if constexpr (TORGB) {
           v = IoT::rounded(outv);
           float r0, r1, r2;

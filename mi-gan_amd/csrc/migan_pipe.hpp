@@ -177,7 +177,7 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(pipe_threads(NA), (NA + kPipeBWaves) / 4) 
   // (with 8 + 8 waves the six units of a step are split: group B's waves 0..2 take units 0..2, group A's waves 3..5 units 3..5 -- the
   // depthwise group has the slack for them; with 4 + 8 waves group A is the busy one and group B's waves 0..5 take them all)
   auto build_units = [&](const BuildCursor& bc, int wave, int nwaves) {
-    if (bc.is >= G || MIGAN_ABL(16)) return;
+    if (bc.is >= G) return;
     const int bl31 = tid & 31, bhalf = (tid >> 5) & 1;
     const char* r_s = lds + L::OFF_RGB + (bc.ik & 1) * L::RGB_BUF + bhalf * 16;
     const char* f_s = lds + L::OFF_F + bc.ic * (3 * 32 * 32) + bl31 * 32 + bhalf * 16;
@@ -325,7 +325,6 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(pipe_threads(NA), (NA + kPipeBWaves) / 4) 
     };
     const unsigned img_bytes = (unsigned)(p.H * p.W * CIN) * 4u;
     auto dma_in = [&](int b0_, int chunk, int slot) {
-      if (MIGAN_ABL(16)) return;
       float* in_s = reinterpret_cast<float*>(lds + L::OFF_IN + slot * L::IN_SLOT);
       const MIGAN_BUF xbuf = MIGAN_MAKE_BUF(reinterpret_cast<const char*>(p.x) + (size_t)b0_ * img_bytes, img_bytes);
 #pragma unroll
@@ -368,7 +367,6 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(pipe_threads(NA), (NA + kPipeBWaves) / 4) 
 
     // ---- depthwise 3x3 + bias + act (x 2^7) + fp16 hi/lo split of one chunk: one SEGH-row strip x 4 channels per thread --------------
     auto depthwise = [&](int slot, int chunk, int abuf) {
-      if (MIGAN_ABL(4)) return;
       const float* in_s = reinterpret_cast<const float*>(lds + L::OFF_IN + slot * L::IN_SLOT);
       const float* wc = w_s + (TAPS_RES ? chunk : (chunk & 1)) * 320;
       char* a_b = lds + L::OFF_A + abuf * L::A_BUF;
@@ -585,7 +583,6 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(pipe_threads(NA), (NA + kPipeBWaves) / 4) 
 
   // first: the first product of a tile reads the constant 0 as C (no accumulator clearing at the hand-over)
   auto mfma_chunk = [&](int abuf, int bbuf, bool first) {
-    if (MIGAN_ABL(8)) return;
     const char* ab = lds + L::OFF_A + abuf * L::A_BUF;
     const char* bb = lds + L::OFF_B + bbuf * L::B_CHUNK;
 #pragma unroll
@@ -707,7 +704,6 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(pipe_threads(NA), (NA + kPipeBWaves) / 4) 
     // trip is waited for: stage (16 ds_write_b32, at the hand-over or right after the previous block's rows were consumed), fetch
     // (4 ds_read_b128, issued before the step's MFMAs) and finish (noise, activation, store, ToRGB share -- after the MFMAs).
     auto stage_block = [&](const f16v& a) {
-      if (MIGAN_ABL(2)) return;
       MIGAN_WAVE_SYNC();                                        // (rows of the previous block were read by other lanes of this wave)
 #pragma unroll
       for (int r = 0; r < 16; ++r) t_s[twr[((r >> 1) & 1) + 2 * ((r >> 2) & 1)] + ((r & 3) + 8 * (r >> 2)) * 32] = a[r];
@@ -715,19 +711,17 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(pipe_threads(NA), (NA + kPipeBWaves) / 4) 
     };
     f4 tv[4];
     auto fetch_block = [&]() {
-      if (MIGAN_ABL(2)) return;
 #pragma unroll
       for (int q = 0; q < 4; ++q) tv[q] = ld4(t_s + ((q & 1) ? trd1 : trd0) + q * 8 * 32);
     };
     auto finish_block = [&](int j) {
-      if (MIGAN_ABL(2)) return;
       char* yb = reinterpret_cast<char*>(p.y) + (size_t)pb0 * img_out_bytes;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         f4 v = tv[q] * acc_scale + MIGAN_FMUL_RN(nz[q], ns);        // product rounded first, reference :166
         v = act4(v);
         const unsigned pix = pix0 + (unsigned)((q >> 1) * p.WO + (q & 1) * 8);
-        if (!MIGAN_ABL(1)) Io<0>::st(yb, (pix * (unsigned)p.CO + (unsigned)(pn0 + cbk * (NT / 2) + j * 32 + q4 * 4)) * 4u, v);
+        Io<0>::st(yb, (pix * (unsigned)p.CO + (unsigned)(pn0 + cbk * (NT / 2) + j * 32 + q4 * 4)) * 4u, v);
         if constexpr (TORGB) {
           float r0, r1, r2;
           torgb_partial(v, tw[j][0], tw[j][1], tw[j][2], r0, r1, r2);
@@ -739,7 +733,6 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(pipe_threads(NA), (NA + kPipeBWaves) / 4) 
     // owns the same rows
     float mine[3] = {0.f, 0.f, 0.f};
     auto rgb_partials = [&]() {
-      if (MIGAN_ABL(2)) return;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const float s0 = MIGAN_SUM8(rs[q][0]), s1 = MIGAN_SUM8(rs[q][1]), s2 = MIGAN_SUM8(rs[q][2]);
@@ -748,7 +741,6 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(pipe_threads(NA), (NA + kPipeBWaves) / 4) 
       if (cbk == 1 && q4 < 4) st4(part_s + (8 * q4 + prow) * 4, f4{mine[0], mine[1], mine[2], 0.0f});
     };
     auto rgb_finish = [&]() {                                   // (one barrier after rgb_partials)
-      if (MIGAN_ABL(2)) return;
       if (cbk == 0 && q4 < 4) {
         const f4 other = ld4(part_s + (8 * q4 + prow) * 4);
         const size_t plane = (size_t)p.HO * p.WO;
@@ -901,7 +893,6 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(pipe_threads(NA), (NA + kPipeBWaves) / 4) 
         }
     };
     auto item_finish = [&](int k, int h, const ItemIo& io) {
-      if (MIGAN_ABL(2)) return;
       int m;
       unsigned lpix, loff;
       if (!item_geo(k, h, m, lpix, loff)) return;
@@ -926,7 +917,7 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(pipe_threads(NA), (NA + kPipeBWaves) / 4) 
           f4 v = out[a][bb] * acc_scale + MIGAN_FMUL_RN(io.nzv[a][bb], ns);    // product rounded first, reference :166
           v = act4(v);
           v += io.sk[a][bb];
-          if (!MIGAN_ABL(1)) Io<0>::st(yb, loff + (unsigned)(a * p.WO + bb) * (unsigned)p.CO * 4u, v);
+          Io<0>::st(yb, loff + (unsigned)(a * p.WO + bb) * (unsigned)p.CO * 4u, v);
         }
     };
     // step c of a tile: phase h = c / SP; its first step writes the half, step 1 + i of the phase runs the items k with slice_of(k) == i

@@ -114,7 +114,6 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(kW2Threads, 3) sepconv_wide2_kernel(const 
     constexpr bool B32 = (V & 1) != 0;
     constexpr bool PW = (V & 2) != 0;                      // pointwise GEMM: no halo, no depthwise stage (second half of a down=2 layer)
     static_assert(!PW || B32, "the pointwise form is built on the 32-channel-chunk weight ring");
-    if (MIGAN_ABL(64)) MIGAN_SETPRIO(2);                   // (measurement builds: the depthwise group ahead of the MFMA waves at issue)
     // ---- input tile of one sub-chunk -> ring slot: 1296 units of 16 bytes = 5 per thread + 4 lanes of every wave (so that each wave
     // issues the same six instructions and one vmcnt count holds for all of them).  The image is a buffer descriptor: a halo pixel
     // outside it (the conv's zero padding, reference :126) is a lane offset beyond its range and arrives as zeros.  Interior tiles use
@@ -161,7 +160,6 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(kW2Threads, 3) sepconv_wide2_kernel(const 
     };
     const unsigned img_bytes = (unsigned)(p.H * p.W * CI) * 4u;
     auto dma_in = [&](int b0_, int ks, int slot) {
-      if (MIGAN_ABL(16)) return;
       float* in_s = reinterpret_cast<float*>(lds + L::OFF_IN + slot * L::IN_SLOT);
       const MIGAN_BUF xbuf = MIGAN_MAKE_BUF(reinterpret_cast<const char*>(p.x) + (size_t)b0_ * img_bytes, img_bytes);
       const unsigned soff = tile_soff + (unsigned)(ks * KS) * 4u;
@@ -201,7 +199,6 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(kW2Threads, 3) sepconv_wide2_kernel(const 
       }
     }
     auto dma_b = [&](int n0_, int ks, int slot) {
-      if (MIGAN_ABL(32)) return;
       if constexpr (B32) {                                 // the whole 32-channel chunk ks >> 1
         float* bb = reinterpret_cast<float*>(lds + L::OFF_B + slot * (2 * L::B_SLOT));
         const unsigned soff = (unsigned)(((ks >> 1) * p.CO + n0_) * 32) * 2u;
@@ -217,7 +214,6 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(kW2Threads, 3) sepconv_wide2_kernel(const 
 
     // ---- depthwise 3x3 + bias + act (x 2^7) + fp16 hi/lo split of one sub-chunk: one 4-row strip x 4 channels per thread ------------
     auto depthwise = [&](int slot, int tslot, int abuf) {
-      if (MIGAN_ABL(4)) return;
       if constexpr (PW) {
         // the input pixels ARE the A operand rows (dwfir_kernel's output: activated, FIR-filtered, fp32): x 2^7, fp16 hi / lo split
         const float* in_s = reinterpret_cast<const float*>(lds + L::OFF_IN + slot * L::IN_SLOT);
@@ -363,7 +359,6 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(kW2Threads, 3) sepconv_wide2_kernel(const 
   // B32: weight-plane rows of 64 bytes, 16-byte slot (2 ks + half) ^ ((row >> 2) & 3) (ks = sub-step parity inside the chunk)
   const int foffb = l31 * 64 + ((half ^ ((l31 >> 2) & 3)) << 4);
   auto mfma_step = [&](int abuf, int bidx) {               // bidx = sub-step & 3: the weight-plane slot (B32: chunk slot bidx >> 1, half bidx & 1)
-    if (MIGAN_ABL(8)) return;
     const char* ab = lds + L::OFF_A + abuf * L::A_BUF + (wm * 64) * 32 + foff;
     const char* bb = B32 ? lds + L::OFF_B + (bidx >> 1) * (2 * L::B_SLOT) + (wn * 128) * 64 + (foffb ^ ((bidx & 1) << 5))
                          : lds + L::OFF_B + bidx * L::B_SLOT + (wn * 128) * 32 + foff;
@@ -430,12 +425,10 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(kW2Threads, 3) sepconv_wide2_kernel(const 
         f4 v = f4{acc[i][0][r], acc[i][1][r], acc[i][2][r], acc[i][3][r]};
         if constexpr (HN) v = act4(v * acc_scale + nsn);
         else v = act4g(v, gain_s);
-        if (!MIGAN_ABL(1)) {
-          MIGAN_STORE_NT(at_bytes(reinterpret_cast<float*>(yr), lo), v.x);
-          MIGAN_STORE_NT(at_bytes(reinterpret_cast<float*>(yr + 128), lo), v.y);
-          MIGAN_STORE_NT(at_bytes(reinterpret_cast<float*>(yr + 256), lo), v.z);
-          MIGAN_STORE_NT(at_bytes(reinterpret_cast<float*>(yr + 384), lo), v.w);
-        }
+        MIGAN_STORE_NT(at_bytes(reinterpret_cast<float*>(yr), lo), v.x);
+        MIGAN_STORE_NT(at_bytes(reinterpret_cast<float*>(yr + 128), lo), v.y);
+        MIGAN_STORE_NT(at_bytes(reinterpret_cast<float*>(yr + 256), lo), v.z);
+        MIGAN_STORE_NT(at_bytes(reinterpret_cast<float*>(yr + 384), lo), v.w);
       }
   };
 
@@ -460,7 +453,7 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(kW2Threads, 3) sepconv_wide2_kernel(const 
       mfma_step(1, 3);
       PPROF_MARK(4);
       if (c + 4 == nks) {
-        if (!MIGAN_ABL(2)) { if (has_noise) epilogue(TrueT{}); else epilogue(FalseT{}); }
+        if (has_noise) epilogue(TrueT{}); else epilogue(FalseT{});
         zero_acc();
         if (t + 1 < T) tile_next(ctc);
         PPROF_MARK(5);

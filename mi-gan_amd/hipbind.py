@@ -100,7 +100,7 @@ class MiganLib:
                 f"Run `python -c 'import __graft_entry__ as g; g.build()'` (hipcc --offload-arch=gfx950). "
                 f"There is no CPU/PyTorch fallback for this path.")
         # the in-tree product library must be the product build: build.py stamps it with a digest of its compile flags, and a measurement
-        # build (-DMIGAN_ABLATE / -DMIGAN_PHASE_PROF) left under this name would otherwise be picked up silently
+        # build (-DMIGAN_PHASE_PROF) left under this name would otherwise be picked up silently
         if os.path.abspath(self.path) == os.path.abspath(os.path.join(_HERE, "csrc", _LIBNAME)):
             stamp = self.path + ".flags"
             if not os.path.exists(stamp):

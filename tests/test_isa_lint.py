@@ -42,9 +42,9 @@ def test_no_packed_fp32_fma_or_add_with_low_lane_operand_swizzle(tmp_path):
 
 
 def test_build_refuses_measurement_builds_as_fresh(tmp_path, monkeypatch):
-    """a library compiled with extra flags (-DMIGAN_ABLATE, -DMIGAN_PHASE_PROF) must not pass for the product on the next plain build()"""
+    """a library compiled with extra flags (-DMIGAN_PHASE_PROF) must not pass for the product on the next plain build()"""
     b = importlib.import_module("mi-gan_amd.build")
-    assert b.flags_digest(()) != b.flags_digest(("-DMIGAN_ABLATE",))
+    assert b.flags_digest(()) != b.flags_digest(("-DMIGAN_PHASE_PROF",))
     if os.path.exists(b.OUT) and os.path.exists(b.STAMP):
         assert b.is_fresh(()) in (True, False)
         assert not b.is_fresh(("-DMIGAN_PHASE_PROF",))
