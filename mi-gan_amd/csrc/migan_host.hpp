@@ -105,8 +105,7 @@ struct Tuning {
   int stagger_pct = 15;        // MIGAN_STAGGER_PCT: the next sub-batch starts after this share of a forward's launches (round 5 sweep, two runs each:
                                // 5 .. 18 % 3680 - 3693 images/s, 22 % (rounds 2 - 4) 3655 - 3663, 30 % 3655, 40 % 3638)
   int pipe = 15;               // MIGAN_PIPE bit mask: software-pipelined persistent kernels (sepconv_pipe_kernel; fp32 storage, f16x2 GEMM) for
-                               // 1 plain (+ fused ToRGB) layers, 2 the fused-FromRGB layer, 4 FIR-up layers, 8 down=2 layers as one fused launch, 16 (off) FIR-up
-                               // layers with more than 64 output channels as 64-column chunks, 32 (off) the 256 / 512-channel plain layers as 128-column chunks
+                               // 1 plain (+ fused ToRGB) layers, 2 the fused-FromRGB layer, 4 FIR-up layers, 8 down=2 layers as one fused launch
                                // (sepconv_pipedown_kernel) -- wherever an instantiation exists
                                // (the 512 x 512 layers of migan-512: -5 / -10 / -9 % per layer, profiles/r04_pipe_layers.txt)
   int pipe_grid = 256;         // MIGAN_PIPE_GRID: persistent workgroups of those launches (one 12- or 16-wave workgroup per CU on MI355X)
@@ -352,25 +351,20 @@ inline const PipeEntry* pick_pipe(const Geo& g, int cin, int cout, int batch, bo
   // the plain epilogue of the pipelined kernels has no skip add (no layer of the generator needs one there: its only plain + skip layer is the
   // 512-channel synthesis.b4.conv1); a plain SeparableConv2d with a skip tensor through migan_sepconv_forward keeps the one-tile kernels
   if (g.mode == MODE_NORMAL && has_skip) return nullptr;
-  // (pipe bit 32, experiment, off: the 256 / 512-channel plain layers -- sepconv_wide_kernel's -- as 128-column chunks of the pipelined kernel:
-  // encoder.b128.conv1 0.379 -> 0.373 ms, the 512-channel layers 0.30 -> 0.37 (depthwise recomputed per chunk): profiles/LOG.md)
-  const bool wide_as_chunks = g.wide && (tuning().pipe & 32) && !fused_rgb && g.mode == MODE_NORMAL;
-  const bool up_chunks = g.wide && g.mode == MODE_UP && (tuning().pipe & 16);     // (the chunked FIR-up experiment takes the wide-tile FIR-up layers too)
-  if (!(tuning().pipe & bit) || g.stv != 0 || g.gemmv != 2 || !g.maing || (g.wide && !wide_as_chunks && !up_chunks) || g.MT != 128 || g.KC != 32 || g.lgIMGS != 0) return nullptr;
+  if (!(tuning().pipe & bit) || g.stv != 0 || g.gemmv != 2 || !g.maing || g.wide || g.MT != 128 || g.KC != 32 || g.lgIMGS != 0) return nullptr;
   if (g.mode != MODE_NORMAL && g.mode != MODE_UP) return nullptr;
   if (batch < tuning().pipe_min_batch || g.tiles_x * g.tiles_y * g.nchunks * batch < tuning().pipe_min_tiles) return nullptr;
   (void)u8;
   const PipeSlice sl = pipe_slice();
   for (int i = 0; i < sl.n; ++i) {
     const PipeEntry& e = sl.entries[i];
-    // FIR-up layers always run 64-column tiles here (the shared result tile of 128 columns does not fit beside the ring): a layer
-    // with more output channels is walked as cout / 64 column chunks per pixel tile, whatever column tile the one-tile plan uses
-    const int nt = g.mode == MODE_UP ? 64 : (wide_as_chunks ? 128 : g.NT);
+    // FIR-up layers run 64-column tiles here (the shared result tile of 128 columns does not fit beside the ring), and only where that is the
+    // whole layer (synthesis.b512.conv1): walking a wider layer as 64-column chunks recomputes the depthwise stage per chunk and measured
+    // 10-30 % slower than the 128-column one-tile kernels (rounds 4-5; removed)
+    const int nt = g.mode == MODE_UP ? 64 : g.NT;
     int na = (tuning().pipe_na8 & bit) ? 8 : tuning().pipe_na;
     if ((g.mode == MODE_NORMAL && nt == 128) || g.mode == MODE_UP) na = 4;    // (these forms exist with 4 depthwise waves only: migan_pipe_table.inc)
-    // ... and only where that is the whole layer (synthesis.b512.conv1), unless pipe bit 16 asks for the chunked form: it recomputes the
-    // depthwise stage per 64-column chunk and measured 10-30 % SLOWER than the 128-column one-tile kernels on synthesis.b256 / b128 / b64 .conv1
-    if (g.mode == MODE_UP && cout != nt && !(tuning().pipe & 16)) continue;
+    if (g.mode == MODE_UP && cout != nt) continue;
     if (e.mode == g.mode && e.NT == nt && e.cin == cin && e.fromrgb == g.fromrgb && e.torgb == fused_rgb && e.na == na && cout % nt == 0 &&
         cout == g.NT * g.nchunks && (PipeResident(e) ? cout == nt : true))
       return &e;

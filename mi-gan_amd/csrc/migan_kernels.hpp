@@ -111,27 +111,26 @@ struct NoiseArgs {
 // compare + select.  Finite data never takes the branch.  Measured on MI355X (profiles/r06_nan_policy.md): -2.1 % on the migan-512 forward
 // against the bare v_med3_f32 (-DMIGAN_NAN_CLAMP, the opt-in build); compare + select on every value (rounds 4-5) cost -4.1 %.
 MIGAN_DEVICE MIGAN_INLINE f4 clamp4(f4 t, float lo, float hi) {
-  f4 c = f4{MIGAN_CLAMP(t.x, lo, hi), MIGAN_CLAMP(t.y, lo, hi), MIGAN_CLAMP(t.z, lo, hi), MIGAN_CLAMP(t.w, lo, hi)};
 #ifndef MIGAN_NAN_CLAMP
+  // (the test comes first and the clamped values replace t in both paths: t and its clamp are never live together -- the kernels that sit at
+  // their register cap spilled otherwise)
   if (MIGAN_ANY_LANE(__builtin_isunordered(t.x, t.y) | __builtin_isunordered(t.z, t.w))) {
     MIGAN_COLD_PATH();
-    c.x = t.x != t.x ? t.x : c.x;
-    c.y = t.y != t.y ? t.y : c.y;
-    c.z = t.z != t.z ? t.z : c.z;
-    c.w = t.w != t.w ? t.w : c.w;
+    const f4 c = f4{MIGAN_CLAMP(t.x, lo, hi), MIGAN_CLAMP(t.y, lo, hi), MIGAN_CLAMP(t.z, lo, hi), MIGAN_CLAMP(t.w, lo, hi)};
+    return f4{t.x != t.x ? t.x : c.x, t.y != t.y ? t.y : c.y, t.z != t.z ? t.z : c.z, t.w != t.w ? t.w : c.w};
   }
 #endif
-  return c;
+  return f4{MIGAN_CLAMP(t.x, lo, hi), MIGAN_CLAMP(t.y, lo, hi), MIGAN_CLAMP(t.z, lo, hi), MIGAN_CLAMP(t.w, lo, hi)};
 }
 MIGAN_DEVICE MIGAN_INLINE float clamp1(float t, float lo, float hi) {
-  float c = MIGAN_CLAMP(t, lo, hi);
 #ifndef MIGAN_NAN_CLAMP
   if (MIGAN_ANY_LANE(t != t)) {
     MIGAN_COLD_PATH();
-    c = t != t ? t : c;
+    const float c = MIGAN_CLAMP(t, lo, hi);
+    return t != t ? t : c;
   }
 #endif
-  return c;
+  return MIGAN_CLAMP(t, lo, hi);
 }
 MIGAN_DEVICE MIGAN_INLINE float act1(float v) {
   float t = fmaxf(v, v * 0.2f);

@@ -93,14 +93,6 @@ def test_single_image_forwards_take_them_too_unless_told_otherwise(lib, pkg):
         lib.set_tuning("pipe_min_batch", 1)
 
 
-@pytest.mark.parametrize("cin,cout", [(256, 256), (512, 512)])
-def test_wide_layers_as_128_column_chunks(lib, pkg, cin, cout):
-    """tuning bit 32 (off by default: measured no faster than sepconv_wide_kernel): the streamed weight planes and, at 512 input channels,
-    the streamed depthwise taps of the plain form"""
-    lib.set_tuning("pipe", 63)
-    run_sepconv_case(lib, pkg, HostMem(), cin=cin, cout=cout, h=16, w=16, batch=2, noise=True, seed=5)
-    assert lib.last_kernel().startswith(PIPE + f"0, 128, {cin}, false, false"), lib.last_kernel()
-
 DOWN = "migan::sepconv_pipedown_kernel<"
 
 
@@ -141,15 +133,6 @@ def test_fused_down_equals_the_two_kernel_form_bit_for_bit(lib, pkg, cin, cout, 
     finally:
         lib.set_tuning("pipe", 15)
     assert np.array_equal(a, b)
-
-@pytest.mark.parametrize("cin,cout,h,w,batch", [(256, 128, 8, 16, 2), (256, 128, 12, 20, 3), (512, 256, 6, 14, 2), (512, 512, 8, 8, 2)])
-def test_fir_up_streamed_weight_planes(lib, pkg, cin, cout, h, w, batch):
-    """FIR-up layers with more input / output channels: 64-column chunks per pixel tile, weight planes through the two-slot ring
-    (tuning bit 16: off in the default plan, where it measured slower than the one-tile kernels)"""
-    lib.set_tuning("pipe", 31)
-    lib.set_tuning("pipe_na", 4)
-    run_sepconv_case(lib, pkg, HostMem(), cin=cin, cout=cout, h=h, w=w, batch=batch, up=2, noise=True, skip=True, seed=17)
-    assert lib.last_kernel().startswith(PIPE + f"2, 64, {cin}, false, false"), lib.last_kernel()
 
 @pytest.mark.parametrize("h,w,batch", [(16, 32, 2), (8, 16, 3), (24, 16, 2)])
 @pytest.mark.parametrize("torgb", [False, True])

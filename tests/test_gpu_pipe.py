@@ -132,16 +132,6 @@ def test_fused_down(lib, pkg, dev, h, w, batch, grid, cin, cout, dna, nb):
     finally:
         lib.set_tuning("pipe_dna", 12)
 
-@pytest.mark.parametrize("cin,cout,h,w,batch,grid", [(256, 128, 64, 64, 4, 0), (256, 128, 12, 20, 3, 8), (512, 256, 32, 32, 4, 0), (512, 512, 16, 16, 8, 0)])
-def test_fir_up_streamed_weight_planes(lib, pkg, dev, cin, cout, h, w, batch, grid):
-    """FIR-up layers with more input / output channels: 64-column chunks per pixel tile, weight planes through the two-slot ring
-    (tuning bit 16: off in the default plan, where it measured slower than the one-tile kernels)"""
-    lib.set_tuning("pipe", 31)
-    lib.set_tuning("pipe_na", 4)
-    _grid(lib, grid)
-    run_sepconv_case(lib, pkg, CudaMem(dev), cin=cin, cout=cout, h=h, w=w, batch=batch, up=2, noise=True, skip=True, seed=17)
-    assert lib.last_kernel().startswith(PIPE + f"2, 64, {cin}, false, false"), lib.last_kernel()
-
 @pytest.mark.parametrize("h,w,batch,grid", [(64, 64, 8, 0), (16, 32, 5, 8), (128, 128, 2, 0)])
 @pytest.mark.parametrize("torgb", [False, True])
 def test_plain_128_to_128(lib, pkg, dev, h, w, batch, grid, torgb):
