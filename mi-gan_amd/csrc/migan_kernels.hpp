@@ -108,29 +108,39 @@ struct NoiseArgs {
 // The clamp of lrelu_agc (reference :21-23) on four values / one value.  v_med3_f32 returns the lower bound for a NaN; Tensor.clamp in the
 // reference module keeps it a NaN, and so does this (default) build, at half an instruction per value: one v_cmp_u_f32 tests TWO values
 // (unordered(a, b) holds iff a or b is a NaN), the wave branches on the ballot, and only a wave that holds a NaN runs the per-value
-// compare + select.  Finite data never takes the branch.  Measured on MI355X (profiles/r06_nan_policy.md): -2.1 % on the migan-512 forward
-// against the bare v_med3_f32 (-DMIGAN_NAN_CLAMP, the opt-in build); compare + select on every value (rounds 4-5) cost -4.1 %.
+// compare + select, in a block laid out of line (__builtin_expect): finite data falls through.  Measured on MI355X, migan-512 forward, each row
+// against the bare v_med3_f32 of -DMIGAN_NAN_CLAMP on the same box (profiles/r06_nan_policy.md): compare + select on every value (rounds 4-5)
+// -4.1 %; this form with the repair block inline -1.7 ... -2.1 %; out of line -1.2 % (shipped); testing first and clamping in each arm -4.6 %;
+// three values folded by v_maximum3_f32 (NaN-propagating, gfx950) + one compare per four -1.65 %.
+#ifdef MIGAN_NAN_NOEXPECT          // (measurement builds: the repair block inline behind a taken branch, the first form of round 6)
+#define MIGAN_UNLIKELY(x) (x)
+#else                              // the repair block out of line: the fast path falls through
+#define MIGAN_UNLIKELY(x) __builtin_expect((x), 0)
+#endif
 MIGAN_DEVICE MIGAN_INLINE f4 clamp4(f4 t, float lo, float hi) {
+  // (the clamps are issued BEFORE the branch on purpose: they run in the shadow of the compare -> ballot -> s_cbranch latency.  Testing first
+  // and clamping in each arm measured -4.6 % against -2.1 % on the forward: profiles/r06_nan_policy.md)
+  f4 c = f4{MIGAN_CLAMP(t.x, lo, hi), MIGAN_CLAMP(t.y, lo, hi), MIGAN_CLAMP(t.z, lo, hi), MIGAN_CLAMP(t.w, lo, hi)};
 #ifndef MIGAN_NAN_CLAMP
-  // (the test comes first and the clamped values replace t in both paths: t and its clamp are never live together -- the kernels that sit at
-  // their register cap spilled otherwise)
-  if (MIGAN_ANY_LANE(__builtin_isunordered(t.x, t.y) | __builtin_isunordered(t.z, t.w))) {
+  if (MIGAN_UNLIKELY(MIGAN_ANY_LANE(__builtin_isunordered(t.x, t.y) | __builtin_isunordered(t.z, t.w)))) {
     MIGAN_COLD_PATH();
-    const f4 c = f4{MIGAN_CLAMP(t.x, lo, hi), MIGAN_CLAMP(t.y, lo, hi), MIGAN_CLAMP(t.z, lo, hi), MIGAN_CLAMP(t.w, lo, hi)};
-    return f4{t.x != t.x ? t.x : c.x, t.y != t.y ? t.y : c.y, t.z != t.z ? t.z : c.z, t.w != t.w ? t.w : c.w};
+    c.x = t.x != t.x ? t.x : c.x;
+    c.y = t.y != t.y ? t.y : c.y;
+    c.z = t.z != t.z ? t.z : c.z;
+    c.w = t.w != t.w ? t.w : c.w;
   }
 #endif
-  return f4{MIGAN_CLAMP(t.x, lo, hi), MIGAN_CLAMP(t.y, lo, hi), MIGAN_CLAMP(t.z, lo, hi), MIGAN_CLAMP(t.w, lo, hi)};
+  return c;
 }
 MIGAN_DEVICE MIGAN_INLINE float clamp1(float t, float lo, float hi) {
+  float c = MIGAN_CLAMP(t, lo, hi);
 #ifndef MIGAN_NAN_CLAMP
-  if (MIGAN_ANY_LANE(t != t)) {
+  if (MIGAN_UNLIKELY(MIGAN_ANY_LANE(t != t))) {
     MIGAN_COLD_PATH();
-    const float c = MIGAN_CLAMP(t, lo, hi);
-    return t != t ? t : c;
+    c = t != t ? t : c;
   }
 #endif
-  return MIGAN_CLAMP(t, lo, hi);
+  return c;
 }
 MIGAN_DEVICE MIGAN_INLINE float act1(float v) {
   float t = fmaxf(v, v * 0.2f);

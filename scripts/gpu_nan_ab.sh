@@ -1,13 +1,13 @@
 #!/bin/bash
-# A/B of the NaN policies on one box: default build (v_med3_f32: NaN -> -256), -DMIGAN_NAN_PAIRFIX (pairwise v_cmp_u_f32 + wave-uniform
-# branch), -DMIGAN_STRICT_NAN (compare + select per value); then the NaN-mask tests of the pair-fix library against the oracle.
+# A/B of the NaN policies on one box: default build (clamp4 / clamp1: pairwise v_cmp_u_f32, repair block out of line), the same with the
+# repair block inline (-DMIGAN_NAN_NOEXPECT), the opt-in -DMIGAN_NAN_CLAMP build (bare v_med3_f32).
 set -u
 R=${GRAFT_REPO_ROOT:-$(pwd)}; OUT=$R/gpurun_out/${1:-nanab}; mkdir -p $OUT
 export TMPDIR=/tmp HSA_ENABLE_IPC_MODE_LEGACY=0
 cd $R
 B="python bench.py --no-secondary --cpu-images 0 --no-latency --steps 30 --warmup 8"
-for rep in 1 2; do
-  for v in default nanpair strictnan; do
+for rep in 1 2 3; do
+  for v in default nanclamp; do
     if [ $v = default ]; then unset MIGAN_HIP_LIBRARY; else export MIGAN_HIP_LIBRARY=$R/mi-gan_amd/csrc/libmigan_hip_$v.so; fi
     timeout 300 $B > $OUT/bench_${v}_$rep.json 2> $OUT/bench_${v}_$rep.err
     python - <<PY
@@ -18,5 +18,3 @@ print("$v", $rep, d.get("value"), d.get("ms_per_step"), d.get("roofline",{}).get
 PY
   done
 done
-unset MIGAN_HIP_LIBRARY
-timeout 600 python scripts/gpu_nan_masks.py $R/mi-gan_amd/csrc/libmigan_hip_nanpair.so > $OUT/nan_masks.log 2>&1; echo "masks rc=$?"; tail -8 $OUT/nan_masks.log
