@@ -485,6 +485,18 @@ inline const char* torgb_name(int stv) {
   return n[stv];
 }
 
+// layers with fewer than 64 channels (resolutions above 512): one plain kernel per (down / up, fromrgb)
+// (the tiled kernels take Cin % 32 == 0 and Cout % 64 == 0: choose_geo)
+inline bool is_narrow(int cin, int cout) { return cin % 32 != 0 || cout % 64 != 0; }
+inline SepKernelFn narrow_fn(int mode, bool fromrgb) {
+  if (fromrgb) return narrow_sepconv_kernel<MODE_NORMAL, true>;
+  return mode == MODE_DOWN ? narrow_sepconv_kernel<MODE_DOWN, false> : (mode == MODE_UP ? narrow_sepconv_kernel<MODE_UP, false> : narrow_sepconv_kernel<MODE_NORMAL, false>);
+}
+inline const char* narrow_name(int mode, bool fromrgb) {
+  if (fromrgb) return "migan::narrow_sepconv_kernel<0, true>";
+  return mode == MODE_DOWN ? "migan::narrow_sepconv_kernel<1, false>" : (mode == MODE_UP ? "migan::narrow_sepconv_kernel<2, false>" : "migan::narrow_sepconv_kernel<0, false>");
+}
+
 // Raise the dynamic-LDS limit of every instantiation (tiles use up to 145 KiB).  The attribute is per device, so
 // this runs once per device ordinal (the caller has made that device current).
 inline void prepare_kernels() {
@@ -719,6 +731,9 @@ struct Launch {
   mutable std::string kernel_last;   // kernel symbol actually launched by the last forward (persistent variant or not)
   bool is_rgb = false;
   bool is_dwfir = false;
+  bool narrow = false;               // fewer than 64 channels on either side (resolutions above 512): narrow_sepconv_kernel<mode, fromrgb>
+  int mode = MODE_NORMAL;            // (narrow launches: the SeparableConv2d's down / up)
+  bool fromrgb = false;
   Geo g;
   std::vector<Geo> g_small;          // small-tile variants of g, smallest tile first: the first one whose tile count for the launch is at
                                      // most tuning().small_max_wgs runs instead of g
@@ -930,10 +945,19 @@ inline void migan_handle::build_plan(migan::Plan& P, int H, int W) const {
     Launch L;
     L.layer = layer;
     L.hin = hs(res_in); L.win = ws(res_in); L.hout = hs(res_out); L.wout = ws(res_out);
-    L.g = choose_geo(mode, cin, cout, L.hin, L.win, fromrgb, with_torgb, gemm, stv);
-    L.g.torgb = with_torgb && L.g.nchunks == 1;        // one workgroup owns all channels of its pixels: ToRGB fuses
-    L.kernel = kernel_name(L.g);
-    if (tuning().small && has_small_tiles(gemm, stv) && !fromrgb && !L.g.torgb && cout % 128 == 0 &&
+    L.narrow = is_narrow(cin, cout);
+    L.mode = mode; L.fromrgb = fromrgb;
+    if (L.narrow) {
+      MIGAN_CHECK(stv == 0, MIGAN_EUNSUPPORTED, "resolutions above 512 (layers with fewer than 64 channels) run with fp32 activation storage only");
+      MIGAN_CHECK(cin % 4 == 0 && cout % 4 == 0 && cin <= 64 && cout <= 64, MIGAN_EINVAL, "internal: narrow layer with unexpected channel counts");
+      L.g.mode = mode; L.g.nchunks = 1;                // (no tile geometry: one thread per output pixel)
+      L.kernel = narrow_name(mode, fromrgb);
+    } else {
+      L.g = choose_geo(mode, cin, cout, L.hin, L.win, fromrgb, with_torgb, gemm, stv);
+      L.g.torgb = with_torgb && L.g.nchunks == 1;        // one workgroup owns all channels of its pixels: ToRGB fuses
+      L.kernel = kernel_name(L.g);
+    }
+    if (!L.narrow && tuning().small && has_small_tiles(gemm, stv) && !fromrgb && !L.g.torgb && cout % 128 == 0 &&
         (mode == MODE_UP || (L.hin % 4 == 0 && L.win % (L.hin == 4 && L.win == 4 ? 4 : 8) == 0))) {
       if (tuning().small_ksplit && tuning().small_kc == 64 && cin % 64 == 0)
         L.g_small.push_back(choose_geo(mode, cin, cout, L.hin, L.win, false, false, gemm, stv, 3));
@@ -962,10 +986,11 @@ inline void migan_handle::build_plan(migan::Plan& P, int H, int W) const {
     L.flops = L.mfma_flops + 2.0 * 9 * cin * pin;
     if (mode == MODE_PW) L.flops = L.mfma_flops;     // depthwise + FIR are accounted to the dwfir launch
     if (mode == MODE_UP) L.flops += 2.0 * 4 * cout * pout;
+    if (mode == MODE_DOWN) L.flops += 2.0 * 16 * cin * pout;      // (narrow layers only: the tiled plan splits a down=2 layer into dwfir + pointwise)
     L.bytes = (fromrgb ? 4.0 * 4.0 : e * cin) * pin + e * cout * pout + (skip_buf != BUF_NONE ? e * cout * pout : 0.0);
     if (mode == MODE_PW) L.bytes = e * cout * pout;   // algorithmic input read is accounted to the dwfir launch
     if (fromrgb) L.flops += 2.0 * 4 * cin * pin;
-    L.wgs_batch1 = (int)grid_of(L.g, 1);
+    L.wgs_batch1 = L.narrow ? cdiv(L.hout * L.wout, kThreads) : (int)grid_of(L.g, 1);
     P.launches.push_back(L);
     if (debug) P.debug_tensors.push_back({layer, out_buf});
     return P.launches.back();
@@ -983,7 +1008,13 @@ inline void migan_handle::build_plan(migan::Plan& P, int H, int W) const {
       l1.b_frgb = slot_index(b + ".fromrgb.bias");
     }
     if (debug) P.debug_tensors.back().second = feat[ilog2(res)];
-    if (res > 4) {
+    if (res > 4 && is_narrow(c, channels_at(res / 2))) {
+      // (resolutions above 512: one plain launch for the whole down=2 layer)
+      const int cn = channels_at(res / 2);
+      const int ob = out_for(b + ".conv2", res / 2, cn, P0);
+      add_sep(b + ".conv2", MODE_DOWN, c, cn, res, res / 2, false, false, feat[ilog2(res)], ob, BUF_NONE);
+      cur = ob;
+    } else if (res > 4) {
       const int cn = channels_at(res / 2);
       // down=2 layer = depthwise+FIR kernel (writes the half-resolution cin-channel tensor) + pointwise GEMM
       {
@@ -1031,7 +1062,12 @@ inline void migan_handle::build_plan(migan::Plan& P, int H, int W) const {
     const double pout = (double)hs(res) * ws(res);
     const double rgb_flops = 2.0 * 3 * c * pout + (img_cur != BUF_NONE ? 2.0 * 4 * 3 * pout : 0.0);
     const double rgb_bytes = 4.0 * (3.0 * pout + (img_cur != BUF_NONE ? 3.0 * pout / 4 : 0.0));
-    if (l2.g.nchunks == 1) {
+    if (l2.narrow) {
+      // (resolutions above 512: the plain kernel finishes the pixel's ToRGB itself)
+      l2.w_trgb = wt; l2.b_trgb = bt;
+      l2.imgprev_buf = img_cur; l2.imgout_buf = img_out;
+      l2.flops += rgb_flops; l2.bytes += rgb_bytes;
+    } else if (l2.g.nchunks == 1) {
       // one workgroup owns all output channels of its pixels: ToRGB fused into the conv2 epilogue
       l2.w_trgb = wt; l2.b_trgb = bt;
       l2.g.torgb = true;
@@ -1140,6 +1176,22 @@ inline void migan_handle::run_range(const migan::Plan& P, const float* x, float*
       a.x = bptr(L.in_buf); a.y = (float*)bptr(L.out_buf); a.wdw = wptr(L.w_dw); a.bdw = wptr(L.b_dw);
       a.B = n; a.H = L.hin; a.W = L.win; a.C = L.cin;
       launch_dwfir(L.dg, a, stream, dwfir_variant(stv, gemm));
+    } else if (L.narrow) {
+      MIGAN_CHECK(u8 == nullptr || (L.in_buf != BUF_X && L.imgout_buf != BUF_Y), MIGAN_EUNSUPPORTED,
+                  "the uint8-in / uint8-out forward is not available at resolutions above 512");
+      SepArgs a{};
+      a.x = bptr(L.in_buf); a.y = bptr(L.out_buf); a.skip = bptr(L.skip_buf);
+      a.wdw = wptr(L.w_dw); a.bdw = wptr(L.b_dw); a.wpw = wptr(L.w_pw);
+      a.noise = L.noise_plane_off >= 0 ? reinterpret_cast<const float*>(shared + L.noise_plane_off) : wptr(L.w_noise);
+      a.noise_strength = wptr(L.w_ns);
+      a.frgb_w = wptr(L.w_frgb); a.frgb_b = wptr(L.b_frgb);
+      a.trgb_w = wptr(L.w_trgb); a.trgb_b = wptr(L.b_trgb);
+      a.img_prev = (const float*)bptr(L.imgprev_buf); a.img_out = (float*)bptr(L.imgout_buf);
+      a.B = n; a.H = L.hin; a.W = L.win; a.CI = L.cin; a.CO = L.cout; a.HO = L.hout; a.WO = L.wout;
+      const size_t npix = (size_t)n * L.hout * L.wout;
+      rt_check(rt::launch(narrow_fn(L.mode, L.fromrgb), a, (unsigned)((npix + kThreads - 1) / kThreads), kThreads, 0, stream), narrow_name(L.mode, L.fromrgb));
+      L.kernel_last = narrow_name(L.mode, L.fromrgb);
+      last_kernel_ref() = L.kernel_last.c_str();
     } else if (L.is_rgb) {
       RgbArgs a{};
       a.x = bptr(L.in_buf); a.w = wptr(L.w_trgb); a.b = wptr(L.b_trgb);
@@ -1214,7 +1266,7 @@ inline void migan_handle::forward(migan::Plan& P, const float* x, float* y, int 
     sa.dst = reinterpret_cast<unsigned short*>(shared);
     sa.f16 = gemm == 3 ? 2 : (gemm == 2 ? 1 : 0);
     for (const Launch& L : P.launches) {
-      if (L.is_rgb || L.is_dwfir) continue;
+      if (L.is_rgb || L.is_dwfir || L.narrow) continue;      // (narrow layers read conv2.weight in fp32)
       MIGAN_CHECK(sa.n < 40, MIGAN_EINVAL, "internal: too many layers for the weight-split table");
       sa.src[sa.n] = slots[L.w_pw].ptr;
       sa.dst_off[sa.n] = L.wsplit_off;
@@ -1310,7 +1362,7 @@ int migan_create(int resolution, int dtype, int device, migan_handle** out) {
   *out = nullptr;
   MIGAN_CHECK(resolution > 0 && (resolution & (resolution - 1)) == 0, MIGAN_EINVAL,
               "resolution must be a power of two (reference migan_inference.py:215-216)");
-  MIGAN_CHECK(resolution >= 8 && resolution <= 512, MIGAN_EINVAL, "resolution must be in [8, 512]");
+  MIGAN_CHECK(resolution >= 8 && resolution <= 4096, MIGAN_EINVAL, "resolution must be in [8, 4096]");
   MIGAN_CHECK(dtype == MIGAN_DTYPE_F32 || dtype == MIGAN_DTYPE_BF16 || dtype == MIGAN_DTYPE_F16, MIGAN_EINVAL,
               "dtype must be MIGAN_DTYPE_F32, MIGAN_DTYPE_BF16 or MIGAN_DTYPE_F16 (activation storage format)");
   DeviceGuard guard(device);
@@ -1608,6 +1660,27 @@ int migan_sepconv_forward(const migan_sepconv_desc* d, void* stream) {
   const int h_out = d->down == 2 ? h_in / 2 : (d->up == 2 ? h_in * 2 : h_in);
   const int w_out = d->down == 2 ? w_in / 2 : (d->up == 2 ? w_in * 2 : w_in);
   MIGAN_CHECK(d->noise_const == nullptr || d->noise_strength != nullptr, MIGAN_EINVAL, "noise_const without noise_strength");
+  if (is_narrow(d->cin, d->cout) && d->cin <= 64 && d->cout <= 64 && d->cin % 4 == 0 && d->cout % 4 == 0) {
+    // fewer than 64 channels on either side (the layers of resolutions above 512): the plain kernel, the whole layer in one launch
+    MIGAN_CHECK(stv == 0, MIGAN_EUNSUPPORTED, "layers with fewer than 64 channels run with fp32 activation storage only");
+    MIGAN_CHECK(d->torgb_weight == nullptr || (d->up == 1 && d->down == 1 && d->img_out && d->torgb_bias), MIGAN_EINVAL,
+                "ToRGB needs up == down == 1, torgb_bias and img_out");
+    MIGAN_CHECK(d->fromrgb_weight == nullptr || (d->up == 1 && d->down == 1), MIGAN_EINVAL, "fromrgb is only fused into plain layers");
+    const int nmode = d->down == 2 ? MODE_DOWN : (d->up == 2 ? MODE_UP : MODE_NORMAL);
+    SepArgs a{};
+    a.x = d->x; a.y = d->y; a.skip = d->skip;
+    a.wdw = (const float*)d->conv1_weight; a.bdw = (const float*)d->conv1_bias; a.wpw = (const float*)d->conv2_weight;
+    a.noise = (const float*)d->noise_const; a.noise_strength = (const float*)d->noise_strength;
+    a.frgb_w = (const float*)d->fromrgb_weight; a.frgb_b = (const float*)d->fromrgb_bias;
+    a.trgb_w = (const float*)d->torgb_weight; a.trgb_b = (const float*)d->torgb_bias;
+    a.img_prev = (const float*)d->img_prev; a.img_out = (float*)d->img_out;
+    a.B = d->batch; a.H = h_in; a.W = w_in; a.CI = d->cin; a.CO = d->cout; a.HO = h_out; a.WO = w_out;
+    const size_t npix = (size_t)d->batch * h_out * w_out;
+    const bool frgb = d->fromrgb_weight != nullptr;
+    rt_check(rt::launch(narrow_fn(nmode, frgb), a, (unsigned)((npix + kThreads - 1) / kThreads), kThreads, 0, (rt::stream_t)stream), narrow_name(nmode, frgb));
+    last_kernel_ref() = narrow_name(nmode, frgb);
+    return MIGAN_OK;
+  }
   const void* gemm_in = d->x;
   int mode = d->up == 2 ? MODE_UP : MODE_NORMAL, gemm_h = h_in, gemm_w = w_in;
   // split GEMM variants need room for the 16-bit weight planes; without it the exact fp32 MFMA path runs

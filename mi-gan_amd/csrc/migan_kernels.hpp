@@ -2049,6 +2049,113 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, 2) torgb_kernel(const RgbArgs p) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// SeparableConv2d with fewer than 64 channels on either side (reference :154-170 at resolutions above 512: channels(1024) = 32,
+// channels(2048) = 16, ...: `min(32768 // res, 512)`, :222-223).  The tiled kernels need 64-wide MFMA column tiles and 32-channel K chunks; these
+// layers exist only in generators above the largest checkpoint the reference publishes (512), so they get a plain restatement of the layer
+// instead of a tuned kernel: one thread per OUTPUT pixel, fp32 storage, straight fp32 sums -- depthwise 3x3 + bias -> lrelu_agc -> [FIR-down] ->
+// 1x1 -> [FIR-up] -> noise -> lrelu_agc -> skip, with EncoderBlock.fromrgb in front (FROMRGB) and ToRGB + the upsampled previous image behind
+// (trgb_w != null).  It makes `Generator(1024)` ... `Generator(4096)` run and agree with the reference; it is not a fast path.
+template <int MODE, bool FROMRGB>
+MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, 2) narrow_sepconv_kernel(const SepArgs p) {
+  constexpr int CMAX = 64;
+  const size_t pix = (size_t)blockIdx.x * kThreads + threadIdx.x;
+  const size_t plane_o = (size_t)p.HO * p.WO;
+  if (pix >= (size_t)p.B * plane_o) return;
+  const int b = (int)(pix / plane_o);
+  const int rem = (int)(pix % plane_o);
+  const int oy = rem / p.WO, ox = rem % p.WO;
+  const int CI = p.CI, CO = p.CO, H = p.H, W = p.W;
+  const float* xin = reinterpret_cast<const float*>(p.x);
+  // input of the depthwise conv at (yy, xx), channel ci: the stored activation, or act(fromrgb(raw pixel)) (reference :194-195); zero outside
+  // the image (the conv's padding, :126)
+  auto in_at = [&](int yy, int xx, int ci) -> float {
+    if (yy < 0 || yy >= H || xx < 0 || xx >= W) return 0.0f;
+    if constexpr (FROMRGB) {
+      const float* rp = xin + ((size_t)b * 4) * H * W + (size_t)yy * W + xx;
+      float s = p.frgb_b[ci];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) s += p.frgb_w[ci * 4 + k] * rp[(size_t)k * H * W];
+      return act1(s);
+    } else {
+      return xin[(((size_t)b * H + yy) * W + xx) * CI + ci];
+    }
+  };
+  // conv1 + lrelu_agc at GEMM-resolution pixel (yy, xx), all CI channels (:155-156)
+  auto dw_act = [&](int yy, int xx, float (&a)[CMAX]) {
+    for (int ci = 0; ci < CI; ++ci) {
+      float s = p.bdw[ci];
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) s += p.wdw[ci * 9 + ky * 3 + kx] * in_at(yy + ky - 1, xx + kx - 1, ci);
+      a[ci] = act1(s);
+    }
+  };
+  auto gemm = [&](const float (&a)[CMAX], float (&g)[CMAX]) {        // conv2, 1x1 without bias (:161)
+    for (int co = 0; co < CO; ++co) {
+      float s = 0.0f;
+      for (int ci = 0; ci < CI; ++ci) s += p.wpw[co * CI + ci] * a[ci];
+      g[co] = s;
+    }
+  };
+  float a[CMAX], g[CMAX];
+  if constexpr (MODE == MODE_DOWN) {
+    // Downsample2d (:58-76): 4x4 FIR [1,3,3,1]^2 / 64, stride 2, zero padding 1, on the activated depthwise output
+    float d[CMAX];
+    for (int ci = 0; ci < CI; ++ci) d[ci] = 0.0f;
+    for (int ky = 0; ky < 4; ++ky)
+      for (int kx = 0; kx < 4; ++kx) {
+        const int yy = 2 * oy + ky - 1, xx = 2 * ox + kx - 1;
+        if (yy < 0 || yy >= H || xx < 0 || xx >= W) continue;
+        const float f = ((ky == 0 || ky == 3) ? 0.125f : 0.375f) * ((kx == 0 || kx == 3) ? 0.125f : 0.375f);
+        dw_act(yy, xx, a);
+        for (int ci = 0; ci < CI; ++ci) d[ci] += f * a[ci];
+      }
+    gemm(d, g);
+  } else if constexpr (MODE == MODE_UP) {
+    // Upsample2d (:79-103) in closed form: out[2i] = g[i-1]/4 + 3 g[i]/4, out[2i+1] = 3 g[i]/4 + g[i+1]/4 per axis, zeros outside
+    const int iy = oy >> 1, ix = ox >> 1;
+    const int y0 = (oy & 1) ? iy : iy - 1, x0 = (ox & 1) ? ix : ix - 1;
+    const float wy0 = (oy & 1) ? 0.75f : 0.25f, wx0 = (ox & 1) ? 0.75f : 0.25f;
+    float u[CMAX], t[CMAX];
+    for (int co = 0; co < CO; ++co) u[co] = 0.0f;
+    for (int dy = 0; dy < 2; ++dy)
+      for (int dx = 0; dx < 2; ++dx) {
+        const int yy = y0 + dy, xx = x0 + dx;
+        if (yy < 0 || yy >= H || xx < 0 || xx >= W) continue;
+        const float f = (dy ? 1.0f - wy0 : wy0) * (dx ? 1.0f - wx0 : wx0);
+        dw_act(yy, xx, a);
+        gemm(a, t);
+        for (int co = 0; co < CO; ++co) u[co] += f * t[co];
+      }
+    for (int co = 0; co < CO; ++co) g[co] = u[co];
+  } else {
+    dw_act(oy, ox, a);
+    gemm(a, g);
+  }
+  // noise (:165-167, the product rounded first), lrelu_agc (:168-169), skip (:272 / :305), store
+  const float nz = p.noise ? MIGAN_FMUL_RN(p.noise[(size_t)oy * p.WO + ox], p.noise_strength[0]) : 0.0f;
+  float* yo = reinterpret_cast<float*>(p.y) + pix * CO;
+  const float* sk = p.skip ? reinterpret_cast<const float*>(p.skip) + pix * CO : nullptr;
+  float r0 = 0.0f, r1 = 0.0f, r2 = 0.0f;
+  for (int co = 0; co < CO; ++co) {
+    float v = act1(p.noise ? g[co] + nz : g[co]);
+    if (p.trgb_w) { r0 += p.trgb_w[co] * v; r1 += p.trgb_w[CO + co] * v; r2 += p.trgb_w[2 * CO + co] * v; }
+    if (sk) v += sk[co];
+    yo[co] = v;
+  }
+  if (p.trgb_w) {      // torgb (:277 / :312) + Upsample2d of the running image (:308-313)
+    const float rgb[3] = {r0 + p.trgb_b[0], r1 + p.trgb_b[1], r2 + p.trgb_b[2]};
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) {
+      float up = 0.0f;
+      if (p.img_prev) up = up_prev3(p.img_prev + ((size_t)b * 3 + ch) * (plane_o >> 2), p.HO >> 1, p.WO >> 1, oy, ox);
+      p.img_out[((size_t)b * 3 + ch) * plane_o + rem] = up + rgb[ch];
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // The steps either side of Generator.forward in the reference's scripts/demo.py, at network resolution
 // (SURVEY section 8f row N2): uint8 image + mask -> network input, network output -> composited uint8.
 // Pure HBM streaming kernels: one thread per 4 horizontally adjacent pixels (12 + 4 bytes in as four

@@ -231,10 +231,13 @@ class Generator(nn.Module):
         schema.check_resolution(resolution)                    # ValueError like reference :215-216
         if resolution > schema.MAX_RESOLUTION:
             raise NotImplementedError(
-                f"resolution {resolution}: feature width {schema.channels(resolution)} is below the 64-channel "
-                "MFMA column tile; supported resolutions are 8..512")
+                f"resolution {resolution}: feature width {schema.channels(resolution)} (reference :222-223); supported "
+                f"resolutions are {schema.MIN_RESOLUTION}..{schema.MAX_RESOLUTION}")
         self.resolution = resolution
         self._act_dtype = dtype_code(activation_dtype)
+        if resolution > 512 and self._act_dtype != 0:
+            raise NotImplementedError("resolutions above 512 (layers with fewer than 64 channels: a plain kernel, csrc/migan_kernels.hpp "
+                                      "narrow_sepconv_kernel) run with activation_dtype='f32' only")
         self._gemm: Optional[str] = None                       # None: the library default (f16x2-split MFMA)
         self._streams: Optional[int] = None
         self._frozen = False

@@ -19,7 +19,8 @@ from typing import List, Tuple
 CH_BASE = 32768
 CH_MAX = 512
 MIN_RESOLUTION = 8
-MAX_RESOLUTION = 512      # ch(1024)=32 < the 64-wide MFMA column tile; not built
+MAX_RESOLUTION = 4096     # channels(4096) = 8.  Above 512 the layers have fewer than 64 channels and run a plain (untuned) kernel, fp32 storage
+                          # only (round 6); the reference publishes no checkpoint above 512
 
 
 def channels(res: int) -> int:

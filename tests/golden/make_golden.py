@@ -46,7 +46,7 @@ def tap_summary(t: torch.Tensor) -> np.ndarray:
 
 def schema_json():
     out = {}
-    for r in (8, 16, 32, 64, 128, 256, 512):
+    for r in (8, 16, 32, 64, 128, 256, 512, 1024, 2048):          # (above 512: narrower than 64 channels, round 6)
         g = ref.Generator(resolution=r)
         params = {k for k, _ in g.named_parameters()}
         out[str(r)] = [[k, list(v.shape), "param" if k in params else "buffer"]
@@ -148,3 +148,4 @@ if __name__ == "__main__":
     generator_case("r256_export", 256, 1, 16, "export", stride=4)
     generator_case("r512_export", 512, 1, 17, "export", stride=8)
     generator_case("r512_randn", 512, 1, 18, "export", kind="randn", stride=8)
+    generator_case("r1024_export", 1024, 1, 19, "export", stride=16)      # round 6: 32-channel layers at full size (reference :222-223)

@@ -182,7 +182,7 @@ def test_bad_arguments_are_rejected(lib):
     a = np.zeros(64, dtype=np.float32)
     with pytest.raises(ValueError):
         lib.sepconv_forward(x=ptr(a), y=ptr(a), conv1_weight=ptr(a), conv1_bias=ptr(a), conv2_weight=ptr(a),
-                            batch=1, cin=48, cout=64, res_in=16)          # cin not a multiple of 32
+                            batch=1, cin=50, cout=64, res_in=16)          # cin not a multiple of 4 (of 32 for the tiled kernels)
     with pytest.raises(ValueError):
         lib.sepconv_forward(x=ptr(a), y=ptr(a), conv1_weight=ptr(a), conv1_bias=ptr(a), conv2_weight=ptr(a),
                             batch=1, cin=64, cout=64, res_in=0)           # empty image

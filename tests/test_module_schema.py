@@ -17,21 +17,21 @@ def golden_schema(golden_dir):
         return json.load(f)
 
 
-@pytest.mark.parametrize("res", [8, 16, 32, 64, 128, 256, 512])
+@pytest.mark.parametrize("res", [8, 16, 32, 64, 128, 256, 512, 1024, 2048])
 def test_schema_table_equals_reference(pkg, golden_schema, res):
     want = [(k, tuple(s), kind) for k, s, kind in golden_schema[str(res)]]
     got = [(e.name, tuple(e.shape), e.kind) for e in pkg.schema.entries(res)]
     assert got == want
 
 
-@pytest.mark.parametrize("res", [8, 64, 256, 512])
+@pytest.mark.parametrize("res", [8, 64, 256, 512, 1024])
 def test_module_state_dict_equals_reference(pkg, golden_schema, res):
     m = pkg.Generator(resolution=res)
     params = {k for k, _ in m.named_parameters()}
     got = [(k, tuple(v.shape), "param" if k in params else "buffer") for k, v in m.state_dict().items()]
     want = [(k, tuple(s), kind) for k, s, kind in golden_schema[str(res)]]
     assert got == want                      # same keys, same order, same shapes, same param/buffer split
-    assert len(got) == {8: 39, 64: 108, 256: 154, 512: 177}[res]
+    assert len(got) == {8: 39, 64: 108, 256: 154, 512: 177, 1024: 200}[res]
 
 
 def test_load_state_dict_is_strict_like_the_reference(pkg):
@@ -55,7 +55,10 @@ def test_constructor_errors(pkg):
         with pytest.raises(ValueError):     # reference :215-216, :330-331
             pkg.Generator(resolution=r)
     with pytest.raises(NotImplementedError):
-        pkg.Generator(resolution=1024)
+        pkg.Generator(resolution=8192)          # (4 channels at full size: below the layouts' 4-channel quads at the next step)
+    with pytest.raises(NotImplementedError):
+        pkg.Generator(resolution=1024, activation_dtype="bf16")      # above 512: fp32 storage only
+    assert pkg.Generator(resolution=1024).resolution == 1024         # round 6: the reference accepts any power of two (:215-223)
     assert pkg.Generator().resolution == 256   # reference default :356
 
 

@@ -93,8 +93,8 @@ def test_numpy_oracle_generator_goldens(pkg, golden_dir):
 
 
 def test_torch_cpu_oracle_generator_goldens(pkg, golden_dir):
-    cases = _cases(golden_dir, 512)
-    assert len(cases) >= 8
+    cases = _cases(golden_dir, 1024)            # (1024: 32-channel layers at full size, reference :222-223)
+    assert len(cases) >= 9
     for path in cases:
         _check_case(pkg, path, lambda x, sd, r, taps: torc.generator(x, sd, r, taps=taps).numpy(), 3e-5)
 
