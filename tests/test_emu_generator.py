@@ -140,9 +140,13 @@ def test_state_errors(pkg, lib):
     keep["synthesis.b8.upsample.filter.weight"][...] *= 0.5                         # not setup_filter([1,3,3,1])
     with pytest.raises(NotImplementedError, match="setup_filter"):
         h.commit()
-    for r in (12, 4, 1024):
+    for r in (12, 4, 8192):                                                         # (not a power of two, below 8, above 4096)
         with pytest.raises(ValueError):
             pkg.hipbind.MiganHandle(lib, r)
+    with pytest.raises(NotImplementedError):                                        # above 512: fp32 activation storage only
+        pkg.hipbind.MiganHandle(lib, 1024, dtype="bf16")
+    h1024 = pkg.hipbind.MiganHandle(lib, 1024)                                      # round 6: 1024 ... 4096 plan (reference :215-223)
+    assert sum(l["kernel"].startswith("migan::narrow_sepconv_kernel<") for l in h1024.launches()) == 3
 
 
 def test_forward_argument_errors(pkg, lib):
