@@ -495,8 +495,9 @@ def run_workload(args, rank, local_rank, world, dist, dev):
     # N > 1: every step's output shards are all-gathered (RCCL) into one of two buffers; the gather of step i runs on
     # RCCL's stream while step i+1 computes, and every gather completes inside the timed region (fence()).
     gdt = gather_dtype_of(args, wl.get("out_dtype", torch.float32))
-    # the migan forward with fp32 output writes straight into the collective's receive buffers, one collective per sub-batch
-    # (OutputGather.forward_and_submit); other producers (uint8 I/O, Co-Mod-GAN, a converted payload) copy their shard in
+    # the migan forward with fp32 output writes straight into the collective's receive buffer (OutputGather.forward_and_submit: one in-place
+    # collective per step, or one per sub-batch with --gather-mode parts); other producers (uint8 I/O, Co-Mod-GAN, a converted payload) copy
+    # their shard into it first
     inplace = bool(gather and wl.get("inplace") and gdt == torch.float32 and not args.reserve_cus and args.gather_mode != "copy" and not args.dry)
     chunks = wl["model"].sub_batches(batch, dev) if (inplace and args.gather_mode == "parts") else None
     pipe = pkg.distributed.OutputGather(wl["out_shape"], gdt, dev, chunks=chunks) if gather else None
