@@ -497,6 +497,21 @@ inline const char* narrow_name(int mode, bool fromrgb) {
   return mode == MODE_DOWN ? "migan::narrow_sepconv_kernel<1, false>" : (mode == MODE_UP ? "migan::narrow_sepconv_kernel<2, false>" : "migan::narrow_sepconv_kernel<0, false>");
 }
 
+// (a.B / H / W / HO / WO / CI / CO set by the caller)
+inline void launch_narrow(int mode, bool fromrgb, SepArgs a, rt::stream_t stream) {
+  unsigned grid;
+  size_t lds = 0;
+  if (mode == MODE_UP) {           // one workgroup per 16 x 16 low-resolution pixels, their 18 x 18 1x1 outputs in LDS
+    a.tiles_x = cdiv(a.W, kNarrowUpTile); a.tiles_y = cdiv(a.H, kNarrowUpTile);
+    grid = (unsigned)(a.tiles_x * a.tiles_y * a.B);
+    lds = (size_t)(kNarrowUpTile + 2) * (kNarrowUpTile + 2) * a.CO * sizeof(float);
+  } else {                         // one thread per output pixel
+    grid = (unsigned)(((size_t)a.B * a.HO * a.WO + kThreads - 1) / kThreads);
+  }
+  rt_check(rt::launch(narrow_fn(mode, fromrgb), a, grid, kThreads, lds, stream), narrow_name(mode, fromrgb));
+  last_kernel_ref() = narrow_name(mode, fromrgb);
+}
+
 // Raise the dynamic-LDS limit of every instantiation (tiles use up to 145 KiB).  The attribute is per device, so
 // this runs once per device ordinal (the caller has made that device current).
 inline void prepare_kernels() {
@@ -1188,10 +1203,8 @@ inline void migan_handle::run_range(const migan::Plan& P, const float* x, float*
       a.trgb_w = wptr(L.w_trgb); a.trgb_b = wptr(L.b_trgb);
       a.img_prev = (const float*)bptr(L.imgprev_buf); a.img_out = (float*)bptr(L.imgout_buf);
       a.B = n; a.H = L.hin; a.W = L.win; a.CI = L.cin; a.CO = L.cout; a.HO = L.hout; a.WO = L.wout;
-      const size_t npix = (size_t)n * L.hout * L.wout;
-      rt_check(rt::launch(narrow_fn(L.mode, L.fromrgb), a, (unsigned)((npix + kThreads - 1) / kThreads), kThreads, 0, stream), narrow_name(L.mode, L.fromrgb));
+      launch_narrow(L.mode, L.fromrgb, a, stream);
       L.kernel_last = narrow_name(L.mode, L.fromrgb);
-      last_kernel_ref() = L.kernel_last.c_str();
     } else if (L.is_rgb) {
       RgbArgs a{};
       a.x = bptr(L.in_buf); a.w = wptr(L.w_trgb); a.b = wptr(L.b_trgb);
@@ -1675,10 +1688,7 @@ int migan_sepconv_forward(const migan_sepconv_desc* d, void* stream) {
     a.trgb_w = (const float*)d->torgb_weight; a.trgb_b = (const float*)d->torgb_bias;
     a.img_prev = (const float*)d->img_prev; a.img_out = (float*)d->img_out;
     a.B = d->batch; a.H = h_in; a.W = w_in; a.CI = d->cin; a.CO = d->cout; a.HO = h_out; a.WO = w_out;
-    const size_t npix = (size_t)d->batch * h_out * w_out;
-    const bool frgb = d->fromrgb_weight != nullptr;
-    rt_check(rt::launch(narrow_fn(nmode, frgb), a, (unsigned)((npix + kThreads - 1) / kThreads), kThreads, 0, (rt::stream_t)stream), narrow_name(nmode, frgb));
-    last_kernel_ref() = narrow_name(nmode, frgb);
+    launch_narrow(nmode, d->fromrgb_weight != nullptr, a, (rt::stream_t)stream);
     return MIGAN_OK;
   }
   const void* gemm_in = d->x;

@@ -2055,16 +2055,30 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, 2) torgb_kernel(const RgbArgs p) {
 // instead of a tuned kernel: one thread per OUTPUT pixel, fp32 storage, straight fp32 sums -- depthwise 3x3 + bias -> lrelu_agc -> [FIR-down] ->
 // 1x1 -> [FIR-up] -> noise -> lrelu_agc -> skip, with EncoderBlock.fromrgb in front (FROMRGB) and ToRGB + the upsampled previous image behind
 // (trgb_w != null).  It makes `Generator(1024)` ... `Generator(4096)` run and agree with the reference; it is not a fast path.
+// MODE_UP: one workgroup per 16 x 16 low-resolution pixels -- the 1x1 output of the 18 x 18 pixels under the tile goes to LDS once
+// ([324][CO] floats, p.tiles_x x p.tiles_y tiles per image), then every thread finishes the 2 x 2 output pixels of its low-resolution pixel
+// (thread per output pixel evaluated the 1x1 four times per output: 11.7 ms for synthesis.b1024.conv1; this form: see DESIGN section 9).
+constexpr int kNarrowUpTile = 16;
 template <int MODE, bool FROMRGB>
 MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, 2) narrow_sepconv_kernel(const SepArgs p) {
   constexpr int CMAX = 64;
-  const size_t pix = (size_t)blockIdx.x * kThreads + threadIdx.x;
-  const size_t plane_o = (size_t)p.HO * p.WO;
-  if (pix >= (size_t)p.B * plane_o) return;
-  const int b = (int)(pix / plane_o);
-  const int rem = (int)(pix % plane_o);
-  const int oy = rem / p.WO, ox = rem % p.WO;
+  constexpr int T = kNarrowUpTile, TH = T + 2;
   const int CI = p.CI, CO = p.CO, H = p.H, W = p.W;
+  const size_t plane_o = (size_t)p.HO * p.WO;
+  size_t pix = 0;
+  int b = 0, rem = 0, oy = 0, ox = 0, ty0 = 0, tx0 = 0;
+  if constexpr (MODE == MODE_UP) {
+    int t = (int)blockIdx.x;
+    tx0 = (t % p.tiles_x) * T; t /= p.tiles_x;
+    ty0 = (t % p.tiles_y) * T;
+    b = t / p.tiles_y;
+  } else {
+    pix = (size_t)blockIdx.x * kThreads + threadIdx.x;
+    if (pix >= (size_t)p.B * plane_o) return;
+    b = (int)(pix / plane_o);
+    rem = (int)(pix % plane_o);
+    oy = rem / p.WO; ox = rem % p.WO;
+  }
   const float* xin = reinterpret_cast<const float*>(p.x);
   // input of the depthwise conv at (yy, xx), channel ci: the stored activation, or act(fromrgb(raw pixel)) (reference :194-195); zero outside
   // the image (the conv's padding, :126)
@@ -2113,22 +2127,44 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, 2) narrow_sepconv_kernel(const SepArg
       }
     gemm(d, g);
   } else if constexpr (MODE == MODE_UP) {
-    // Upsample2d (:79-103) in closed form: out[2i] = g[i-1]/4 + 3 g[i]/4, out[2i+1] = 3 g[i]/4 + g[i+1]/4 per axis, zeros outside
-    const int iy = oy >> 1, ix = ox >> 1;
-    const int y0 = (oy & 1) ? iy : iy - 1, x0 = (ox & 1) ? ix : ix - 1;
-    const float wy0 = (oy & 1) ? 0.75f : 0.25f, wx0 = (ox & 1) ? 0.75f : 0.25f;
-    float u[CMAX], t[CMAX];
-    for (int co = 0; co < CO; ++co) u[co] = 0.0f;
-    for (int dy = 0; dy < 2; ++dy)
-      for (int dx = 0; dx < 2; ++dx) {
-        const int yy = y0 + dy, xx = x0 + dx;
-        if (yy < 0 || yy >= H || xx < 0 || xx >= W) continue;
-        const float f = (dy ? 1.0f - wy0 : wy0) * (dx ? 1.0f - wx0 : wx0);
+    // phase 1: g = conv2(act(conv1(x))) at the 18 x 18 low-resolution pixels under the tile (zero outside the image: Upsample2d's padding)
+    MIGAN_DYN_SMEM(g_s);
+    for (int i = (int)threadIdx.x; i < TH * TH; i += kThreads) {
+      const int yy = ty0 - 1 + i / TH, xx = tx0 - 1 + i % TH;
+      if (yy >= 0 && yy < H && xx >= 0 && xx < W) {
         dw_act(yy, xx, a);
-        gemm(a, t);
-        for (int co = 0; co < CO; ++co) u[co] += f * t[co];
+        gemm(a, g);
+        for (int co = 0; co < CO; ++co) g_s[i * CO + co] = g[co];
+      } else {
+        for (int co = 0; co < CO; ++co) g_s[i * CO + co] = 0.0f;
       }
-    for (int co = 0; co < CO; ++co) g[co] = u[co];
+    }
+    __syncthreads();
+    // phase 2: Upsample2d (:79-103) in closed form: out[2i] = g[i-1]/4 + 3 g[i]/4, out[2i+1] = 3 g[i]/4 + g[i+1]/4 per axis; thread (ly, lx) of
+    // the tile finishes the 2 x 2 output pixels of its low-resolution pixel: noise (:165-167), lrelu_agc (:168-169), skip (:305), store
+    const int ly = (int)threadIdx.x / T, lx = (int)threadIdx.x % T;
+    const int iy = ty0 + ly, ix = tx0 + lx;
+    if (iy >= H || ix >= W) return;
+    for (int dyo = 0; dyo < 2; ++dyo)
+      for (int dxo = 0; dxo < 2; ++dxo) {
+        const int oyy = 2 * iy + dyo, oxx = 2 * ix + dxo;
+        const int y0 = dyo ? ly + 1 : ly, x0 = dxo ? lx + 1 : lx;                  // first tap in tile coordinates (+1: the halo ring)
+        const float wy0 = dyo ? 0.75f : 0.25f, wx0 = dxo ? 0.75f : 0.25f;
+        const size_t opix = ((size_t)b * p.HO + oyy) * p.WO + oxx;
+        const float nz = p.noise ? MIGAN_FMUL_RN(p.noise[(size_t)oyy * p.WO + oxx], p.noise_strength[0]) : 0.0f;
+        float* yo = reinterpret_cast<float*>(p.y) + opix * CO;
+        const float* sk = p.skip ? reinterpret_cast<const float*>(p.skip) + opix * CO : nullptr;
+        for (int co = 0; co < CO; ++co) {
+          float u = 0.0f;
+          for (int dy = 0; dy < 2; ++dy)
+            for (int dx = 0; dx < 2; ++dx)
+              u += ((dy ? 1.0f - wy0 : wy0) * (dx ? 1.0f - wx0 : wx0)) * g_s[((y0 + dy) * TH + (x0 + dx)) * CO + co];
+          float v = act1(p.noise ? u + nz : u);
+          if (sk) v += sk[co];
+          yo[co] = v;
+        }
+      }
+    return;
   } else {
     dw_act(oy, ox, a);
     gemm(a, g);
