@@ -359,6 +359,17 @@ MIGAN_DEVICE MIGAN_INLINE f4 pack_pixel(const unsigned char* img, const unsigned
   const unsigned char* q = img + pix * 3;
   return f4{mk - 0.5f, unit_image(q[0]) * mk, unit_image(q[1]) * mk, unit_image(q[2]) * mk};
 }
+// the same in two halves, for kernels that request a pixel's bytes early and use them later: the four loads without any arithmetic on
+// them (a use would make the wave wait for the loads -- and, vmcnt retiring in order, for every store it issued before them) ...
+MIGAN_DEVICE MIGAN_INLINE u4v fetch_pixel_bytes(const unsigned char* img, const unsigned char* mask, size_t pix) {
+  const unsigned char* q = img + pix * 3;
+  return u4v{(unsigned)q[0], (unsigned)q[1], (unsigned)q[2], (unsigned)mask[pix]};
+}
+// ... and the arithmetic of pack_pixel on them
+MIGAN_DEVICE MIGAN_INLINE f4 pack_pixel_bytes(u4v b) {
+  const float mk = b.w == 255u ? 1.0f : 0.0f;
+  return f4{mk - 0.5f, unit_image(b.x) * mk, unit_image(b.y) * mk, unit_image(b.z) * mk};
+}
 // composed = img * mask + result * (1 - mask) of one pixel, mask in {0, 1} (demo.py:139-140)
 MIGAN_DEVICE MIGAN_INLINE void compose_pixel(const unsigned char* img, const unsigned char* mask, unsigned char* out, size_t pix, float y0,
                                              float y1, float y2) {
@@ -368,6 +379,14 @@ MIGAN_DEVICE MIGAN_INLINE void compose_pixel(const unsigned char* img, const uns
   o[0] = keep ? q[0] : unit_to_u8(y0);
   o[1] = keep ? q[1] : unit_to_u8(y1);
   o[2] = keep ? q[2] : unit_to_u8(y2);
+}
+// ... of compose_pixel on bytes fetched earlier (fetch_pixel_bytes)
+MIGAN_DEVICE MIGAN_INLINE void compose_pixel_bytes(u4v b, unsigned char* out, size_t pix, float y0, float y1, float y2) {
+  const bool keep = b.w == 255u;
+  unsigned char* o = out + pix * 3;
+  o[0] = keep ? (unsigned char)b.x : unit_to_u8(y0);
+  o[1] = keep ? (unsigned char)b.y : unit_to_u8(y1);
+  o[2] = keep ? (unsigned char)b.z : unit_to_u8(y2);
 }
 
 #ifdef MIGAN_PHASE_PROF

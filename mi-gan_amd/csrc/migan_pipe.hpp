@@ -333,6 +333,7 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(pipe_threads(NA), (NA + kPipeBWaves) / 4) 
 
     // ---- FROMRGB: the raw 4-channel network input of the halo tile, one tile ahead, through registers into LDS (this group) ----------
     f4 rraw = {0.f, 0.f, 0.f, 0.f};
+    u4v rbytes = {0u, 0u, 0u, 0u};                         // uint8 input: the pixel's bytes as loaded (packed into x by store_raw, a tile later)
     bool rvalid = false;
     auto load_raw = [&](int b0_, int gy0_, int gx0_) {
       f4 v = {0.f, 0.f, 0.f, 0.f};
@@ -343,7 +344,7 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(pipe_threads(NA), (NA + kPipeBWaves) / 4) 
         if (yy >= 0 && yy < p.H && xx >= 0 && xx < p.W) {
           rvalid = true;
           if (p.u8_img) {
-            v = pack_pixel(p.u8_img, p.u8_mask, ((size_t)b0_ * p.H + yy) * p.W + xx);
+            rbytes = fetch_pixel_bytes(p.u8_img, p.u8_mask, ((size_t)b0_ * p.H + yy) * p.W + xx);
           } else {
             const float* src = reinterpret_cast<const float*>(p.x) + ((size_t)b0_ * 4 * p.H + yy) * p.W + xx;
             const size_t plane = (size_t)p.H * p.W;
@@ -357,6 +358,7 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(pipe_threads(NA), (NA + kPipeBWaves) / 4) 
     // bf16; 0 in the others) side by side along K
     auto store_raw = [&](int buf) {
       if (lt < NPIX) {
+        if (p.u8_img) rraw = rvalid ? pack_pixel_bytes(rbytes) : f4{0.f, 0.f, 0.f, 0.f};
         u2v h1, h2, h3;
         split3_bf16(rraw, h1, h2, h3);
         char* d = lds + L::OFF_RGB + buf * L::RGB_BUF + lt * 32;
@@ -684,11 +686,16 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(pipe_threads(NA), (NA + kPipeBWaves) / 4) 
     // Everything the next epilogue loads (noise values, previous-image taps) is requested before the last store slice of the previous
     // tile is issued, and only used a K step later: the wait in front of the first use then leaves those stores in flight.
     // (uniform base pointer + 32-bit lane byte offset: the saddr + voffset form, no 64-bit address arithmetic)
+    u4v u8c = {0u, 0u, 0u, 0u}, u8n = {0u, 0u, 0u, 0u};          // uint8 output: image / mask bytes of the pixel this lane composes (tile being finished, next)
     auto request_next = [&]() {
       if (has_noise) {
         const unsigned px = (unsigned)((cgy0 + 2 * rb) * p.WO + cgx0 + prow) * 4u;
 #pragma unroll
         for (int q = 0; q < 4; ++q) nzn[q] = *at_bytes(p.noise + ((q >> 1) * p.WO + (q & 1) * 8), px);
+      }
+      if constexpr (TORGB) {
+        if (p.u8_out && cbk == 0 && q4 < 4)
+          u8n = fetch_pixel_bytes(p.u8_img, p.u8_mask, (size_t)cb0 * p.HO * p.WO + (size_t)(cgy0 + 2 * rb + (q4 >> 1)) * p.WO + cgx0 + (q4 & 1) * 8 + prow);
       }
     };
     auto begin_tile_epilogue = [&]() {
@@ -696,6 +703,7 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(pipe_threads(NA), (NA + kPipeBWaves) / 4) 
 #pragma unroll
       for (int q = 0; q < 4; ++q) nz[q] = nzn[q];
       if constexpr (TORGB) {
+        u8c = u8n;
 #pragma unroll
         for (int q = 0; q < 4; ++q) rs[q][0] = rs[q][1] = rs[q][2] = 0.0f;
       }
@@ -763,7 +771,7 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(pipe_threads(NA), (NA + kPipeBWaves) / 4) 
           }
         }
         if (p.u8_out) {
-          compose_pixel(p.u8_img, p.u8_mask, p.u8_out, (size_t)pb0 * plane + (size_t)oy * p.WO + ox, o3[0], o3[1], o3[2]);
+          compose_pixel_bytes(u8c, p.u8_out, (size_t)pb0 * plane + (size_t)oy * p.WO + ox, o3[0], o3[1], o3[2]);      // (bytes requested a K step before the hand-over)
         } else {
           const unsigned po = (unsigned)(oy * p.WO + ox) * 4u;
 #pragma unroll
