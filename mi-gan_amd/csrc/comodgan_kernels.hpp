@@ -381,6 +381,10 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, ((MTI * NT * (UP4 ? 4 : 1) > 512) ? 1
   const float inv_wscale = 1.0f / reinterpret_cast<const float*>(p.wsplit)[-2];      // power of two (cm_split_conv_kernel)
   const float ns = p.noise ? p.noise_strength[0] : 0.0f;
   constexpr int QN = NT / 4;
+  static_assert(256 % QN == 0 && (64 * QN) % 256 == 0, "epilogue items: one channel quad per thread");
+  const int eq_q4 = tid % QN, eq_row = tid / QN, eq_co = co0 + eq_q4 * 4;
+  const f4 eq_cf = (p.coef ? ld4(p.coef + (size_t)b * p.CO + eq_co) : f4{p.cgain, p.cgain, p.cgain, p.cgain}) * inv_wscale;
+  const f4 eq_bias = p.raw ? f4{0.f, 0.f, 0.f, 0.f} : ld4(p.bias + eq_co);
 #pragma unroll
   for (int ph = 0; ph < NPH; ++ph) {
     // four-phase mode: phase (ey, ex) writes raw[2 g + e]; its grid extent is H + (ey == 0) by W + (ex == 0)
@@ -399,23 +403,43 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, ((MTI * NT * (UP4 ? 4 : 1) > 512) ? 1
           g_s[lrow * GS + col] = acc[ph][i][j][r];
         }
       __syncthreads();
-      for (int item = tid; item < 64 * QN; item += 256) {
-        const int q4 = item % QN, lrow = item / QN;
-        const int m = cm_pixel_of_row((lrow >> 5) * WROWS + i * 32 + (lrow & 31));
-        const int gy = gy0 + (m >> 4), gx = gx0 + (m & 15);
-        if (gy >= ghn || gx >= gwn) continue;
-        const int oy = gy * oym + oya, ox = gx * oxm + oxa;
-        const int co = co0 + q4 * 4;
-        f4 cf = p.coef ? ld4(p.coef + (size_t)b * p.CO + co) : f4{p.cgain, p.cgain, p.cgain, p.cgain};
-        cf = cf * inv_wscale;
-        f4 v = ld4(g_s + lrow * GS + q4 * 4) * cf;
-        const size_t o = (((size_t)b * p.HO + oy) * p.WO + ox) * p.CO + co;
-        if (!p.raw) {
-          if (p.noise) v = v + MIGAN_FMUL_RN(p.noise[(size_t)b * p.noise_bstride + (size_t)oy * p.WO + ox], ns);
-          v = act4(v + ld4(p.bias + co));
-          if (p.skip) v = v + ld4once(p.skip + o);
+      // a thread's items of a pass share the channel quad (256 % QN == 0): coefficient and bias are read once per workgroup (above);
+      // the per-pixel operands (noise, skip) of FOUR items are requested before the first of them is finished and stored -- a load
+      // consumed right behind the previous item's store made every item wait for that store (vmcnt retires in order)
+      constexpr int IPT = 64 * QN / 256, GRP = IPT < 4 ? IPT : 4;
+#pragma unroll
+      for (int k0 = 0; k0 < IPT; k0 += GRP) {
+        size_t o[GRP];
+        bool ok[GRP];
+        float nz[GRP];
+        f4 sk[GRP];
+#pragma unroll
+        for (int g = 0; g < GRP; ++g) {
+          const int lrow = eq_row + (k0 + g) * (256 / QN);
+          const int m = cm_pixel_of_row((lrow >> 5) * WROWS + i * 32 + (lrow & 31));
+          const int gy = gy0 + (m >> 4), gx = gx0 + (m & 15);
+          ok[g] = gy < ghn && gx < gwn;
+          const int oy = gy * oym + oya, ox = gx * oxm + oxa;
+          o[g] = ok[g] ? (((size_t)b * p.HO + oy) * p.WO + ox) * p.CO + eq_co : 0;
+          nz[g] = 0.0f;
+          sk[g] = f4{0.f, 0.f, 0.f, 0.f};
+          if (!p.raw && ok[g]) {
+            if (p.noise) nz[g] = p.noise[(size_t)b * p.noise_bstride + (size_t)oy * p.WO + ox];
+            if (p.skip) sk[g] = ld4once(p.skip + o[g]);
+          }
         }
-        st4o(p.y + o, v);
+#pragma unroll
+        for (int g = 0; g < GRP; ++g) {
+          if (!ok[g]) continue;
+          const int lrow = eq_row + (k0 + g) * (256 / QN);
+          f4 v = ld4(g_s + lrow * GS + eq_q4 * 4) * eq_cf;
+          if (!p.raw) {
+            if (p.noise) v = v + MIGAN_FMUL_RN(nz[g], ns);
+            v = act4(v + eq_bias);
+            if (p.skip) v = v + sk[g];
+          }
+          st4o(p.y + o[g], v);
+        }
       }
     }
   }
@@ -808,7 +832,9 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, 2) cm_fir_kernel(const CmFirArgs p) {
     // the 35 window loads instead of after the arithmetic that needs them last
     f4 sk[2][4];
     float nz[2][4];
+    f4 bias4 = {0.f, 0.f, 0.f, 0.f};                             // (read here, not between the stores below: a load behind a store waits for that store)
     if constexpr (EPI == 1) {
+      bias4 = ld4(p.bias + c4 * 4);
 #pragma unroll
       for (int r = 0; r < 2; ++r)
 #pragma unroll
@@ -856,7 +882,7 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, 2) cm_fir_kernel(const CmFirArgs p) {
         f4 v = acc[r][c];
         if constexpr (EPI == 1) {
           if (p.noise) v = v + MIGAN_FMUL_RN(nz[r][c], ns);
-          v = act4(v + ld4(p.bias + c4 * 4));
+          v = act4(v + bias4);
           if (p.skip) v = v + sk[r][c];
         }
         st4o(p.y + o, v);
