@@ -384,7 +384,8 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, ((MTI * NT * (UP4 ? 4 : 1) > 512) ? 1
   static_assert(256 % QN == 0 && (64 * QN) % 256 == 0, "epilogue items: one channel quad per thread");
   const int eq_q4 = tid % QN, eq_row = tid / QN, eq_co = co0 + eq_q4 * 4;
   const f4 eq_cf = (p.coef ? ld4(p.coef + (size_t)b * p.CO + eq_co) : f4{p.cgain, p.cgain, p.cgain, p.cgain}) * inv_wscale;
-  const f4 eq_bias = p.raw ? f4{0.f, 0.f, 0.f, 0.f} : ld4(p.bias + eq_co);
+  const bool raw_out = UP4 || p.raw != 0;                      // (the four-phase launch always writes the raw tensor: cm_fir_kernel<1> finishes the layer)
+  const f4 eq_bias = raw_out ? f4{0.f, 0.f, 0.f, 0.f} : ld4(p.bias + eq_co);
 #pragma unroll
   for (int ph = 0; ph < NPH; ++ph) {
     // four-phase mode: phase (ey, ex) writes raw[2 g + e]; its grid extent is H + (ey == 0) by W + (ex == 0)
@@ -406,7 +407,7 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, ((MTI * NT * (UP4 ? 4 : 1) > 512) ? 1
       // a thread's items of a pass share the channel quad (256 % QN == 0): coefficient and bias are read once per workgroup (above);
       // the per-pixel operands (noise, skip) of FOUR items are requested before the first of them is finished and stored -- a load
       // consumed right behind the previous item's store made every item wait for that store (vmcnt retires in order)
-      constexpr int IPT = 64 * QN / 256, GRP = IPT < 4 ? IPT : 4;
+      constexpr int IPT = 64 * QN / 256, GRP = UP4 ? 2 : (IPT < 4 ? IPT : 4);       // (the four-phase form sits at its 256-register cap: two items ahead there)
 #pragma unroll
       for (int k0 = 0; k0 < IPT; k0 += GRP) {
         size_t o[GRP];
@@ -423,7 +424,7 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, ((MTI * NT * (UP4 ? 4 : 1) > 512) ? 1
           o[g] = ok[g] ? (((size_t)b * p.HO + oy) * p.WO + ox) * p.CO + eq_co : 0;
           nz[g] = 0.0f;
           sk[g] = f4{0.f, 0.f, 0.f, 0.f};
-          if (!p.raw && ok[g]) {
+          if (!raw_out && ok[g]) {
             if (p.noise) nz[g] = p.noise[(size_t)b * p.noise_bstride + (size_t)oy * p.WO + ox];
             if (p.skip) sk[g] = ld4once(p.skip + o[g]);
           }
@@ -433,7 +434,7 @@ MIGAN_GLOBAL void MIGAN_LAUNCH_BOUNDS(256, ((MTI * NT * (UP4 ? 4 : 1) > 512) ? 1
           if (!ok[g]) continue;
           const int lrow = eq_row + (k0 + g) * (256 / QN);
           f4 v = ld4(g_s + lrow * GS + eq_q4 * 4) * eq_cf;
-          if (!p.raw) {
+          if (!raw_out) {
             if (p.noise) v = v + MIGAN_FMUL_RN(nz[g], ns);
             v = act4(v + eq_bias);
             if (p.skip) v = v + sk[g];
