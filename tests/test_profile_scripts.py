@@ -38,3 +38,15 @@ def test_sq_counter_table(tmp_path):
     # 2e8 VALU instructions over 1024 SIMDs in 1 ms at 2 GHz: 195 per SIMD and microsecond, one per 10.2 cycles; wait 40 %, conflicts 10 %
     assert cells[3] == "1.000" and cells[7] == "195" and cells[8] == "10.2" and cells[11] == "10%" and cells[12] == "40%" and cells[13] == "30%"
     assert "(e.b512.conv2)" in rows[1] and "| 0.500 |" in rows[1]                                     # the placeholder row of the fused launch is not averaged in
+
+
+def test_isa_wait_scan_tokens():
+    """scripts/isa_wait_scan.py: runs of loads / stores / LDS-DMAs are counted, waits keep their count, barriers are marked"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("isa_wait_scan", os.path.join(ROOT, "scripts", "isa_wait_scan.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    body = ["global_load_dwordx4 v[0:3], v[4:5], off", "global_load_dword v6, v[4:5], off", "s_waitcnt vmcnt(1)", "v_add_f32 v0, v0, v1",
+            "global_store_dwordx4 v[4:5], v[0:3], off nt", "buffer_load_dword v0, s[8:11], 0 offen lds", "buffer_load_dword v0, s[8:11], 0 offen lds",
+            "s_waitcnt vmcnt(0)", "s_barrier", "s_waitcnt lgkmcnt(0)", "buffer_load_dwordx4 v[0:3], v9, s[8:11], 0 offen"]
+    assert m.tokens(body) == "L2 w1 S1 D2 w0 | L1"
